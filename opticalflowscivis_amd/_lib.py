@@ -1,0 +1,66 @@
+"""ctypes binding of libflowsci_hip.so (the C-ABI declared in include/flowsci_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  `lib()` raises
+`FlowsciLibraryError` when the shared object is missing or a symbol is absent, and every op in
+`opticalflowscivis_amd.ops` goes through `lib()`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libflowsci_hip.so")
+
+_f32p = ctypes.c_void_p  # device pointers travel as integers
+_int = ctypes.c_int
+_stream = ctypes.c_void_p
+
+# name -> argtypes; restype is int unless listed in _RESTYPES
+SIGNATURES = {
+    "fs_version": [],
+    "fs_error_string": [_int],
+    "fs_warp3d_fwd": [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _stream],
+    "fs_warp3d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _stream],
+    "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _stream],
+    "fs_warp2d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
+                      _stream],
+}
+_RESTYPES = {"fs_error_string": ctypes.c_char_p}
+
+
+class FlowsciLibraryError(RuntimeError):
+    pass
+
+
+class FlowsciKernelError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; fail loudly if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlowsciLibraryError(
+            "libflowsci_hip.so not found at %s -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C opticalflowscivis_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise FlowsciLibraryError("libflowsci_hip.so does not export %s" % name) from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _int)
+    _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().fs_error_string(code)
+        raise FlowsciKernelError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))

@@ -1,0 +1,15 @@
+// api.hip -- version / error-string entry points of the C-ABI.
+#include "common.hpp"
+
+extern "C" int fs_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* fs_error_string(int code) {
+  switch (code) {
+    case FS_OK: return "ok";
+    case FS_ERR_NULLPTR: return "required pointer is NULL";
+    case FS_ERR_SHAPE: return "size out of the supported range";
+    case FS_ERR_ARG: return "invalid option / mode";
+    case FS_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown error code";
+  }
+}

@@ -1,0 +1,283 @@
+// warp2d.hip -- the four 2-D bilinear backward warps of the reference (SURVEY §8 a1, a5, a6,
+// a7, a11) as one templated gfx950 kernel pair.
+//
+// All four are "gather 4 corners at (x+u, y+v) under some coordinate convention"; they differ
+// only in how (ix, iy) is derived from (x, y, u, v), in the padding rule and in an optional
+// validity mask.  One thread owns one output pixel (lanes on x: flow reads, output stores and,
+// for smooth flows, the corner gathers are all coalesced) and loops over the C channels that
+// share its flow vector.  HBM-bound: 8 B flow + 4 B gather + 4 B store per pixel-channel.
+//
+//  RIFE    Flow-2D/model/warplayer.py:7-26        border, align_corners=True
+//  PWC     UPFlow/model/pwc_modules.py:184-207    zeros,  align_corners=False, optional mask
+//          UPFlow/utils/tools.py:1317-1361
+//  PHOTO   Flow-2D/model/RIFE.py:244-262          zeros,  align_corners=False, grid=(x+u)*2/W-1
+//  DILATED UPFlow/utils/tools.py:412-541          clamped indices, unclamped weights
+#include "common.hpp"
+
+namespace {
+
+struct W2P {
+  int B, C, H, W;
+  float stepH, stepW, sH, sW;  // RIFE: linspace steps and (n-1)/2
+  float dW, dH;                // PWC: max(W-1,1), max(H-1,1)
+  float fW, fH;                // PHOTO: float(2/W), float(2/H)
+};
+
+struct Samp2 {
+  int x0, x1, y0, y1;      // addressing indices (always inside the image)
+  int v00, v10, v01, v11;  // corner participates (ATen within_bounds)
+  float ax, bx, ay, by;    // weights: corner (x0,y0) gets bx*by, (x1,y0) ax*by, ...
+  float mx, my;            // d ix / d u, d iy / d v (chain to the flow)
+};
+
+template <int MODE>
+__device__ __forceinline__ Samp2 w2_sample(const W2P& p, int b, int x, int y, float u, float v,
+                                           const float* __restrict__ start) {
+#pragma clang fp contract(off)
+  Samp2 s;
+  float ix, iy;
+  if (MODE == FS_WARP2D_RIFE) {
+    const float gx = fs::linspace_pm1(x, p.W, p.stepW) + u / p.sW;  // warplayer.py:12,18
+    const float gy = fs::linspace_pm1(y, p.H, p.stepH) + v / p.sH;  // warplayer.py:14,19
+    ix = ((gx + 1.0f) / 2.0f) * (float)(p.W - 1);
+    iy = ((gy + 1.0f) / 2.0f) * (float)(p.H - 1);
+    float cx, cy;
+    ix = fs::clip_border(ix, p.W, &cx);
+    iy = fs::clip_border(iy, p.H, &cy);
+    s.mx = cx * ((float)(p.W - 1) / 2.0f) / p.sW;
+    s.my = cy * ((float)(p.H - 1) / 2.0f) / p.sH;
+  } else if (MODE == FS_WARP2D_PWC) {
+    const float vx = 2.0f * ((float)x + u) / p.dW - 1.0f;  // pwc_modules.py:199-200
+    const float vy = 2.0f * ((float)y + v) / p.dH - 1.0f;
+    ix = ((vx + 1.0f) * (float)p.W - 1.0f) / 2.0f;  // unnormalize, align_corners=False
+    iy = ((vy + 1.0f) * (float)p.H - 1.0f) / 2.0f;
+    s.mx = ((float)p.W / 2.0f) * (2.0f / p.dW);
+    s.my = ((float)p.H / 2.0f) * (2.0f / p.dH);
+  } else if (MODE == FS_WARP2D_PHOTO) {
+    const float gx = (u + (float)x) * p.fW - 1.0f;  // RIFE.py:256-259
+    const float gy = (v + (float)y) * p.fH - 1.0f;
+    ix = ((gx + 1.0f) * (float)p.W - 1.0f) / 2.0f;
+    iy = ((gy + 1.0f) * (float)p.H - 1.0f) / 2.0f;
+    s.mx = ((float)p.W / 2.0f) * p.fW;
+    s.my = ((float)p.H / 2.0f) * p.fH;
+  } else {  // DILATED
+    const float sx = start ? start[2 * b + 0] : 0.0f;
+    const float sy = start ? start[2 * b + 1] : 0.0f;
+    ix = ((float)x + sx) + u;  // tools.py:409,538
+    iy = ((float)y + sy) + v;
+    s.mx = 1.0f;
+    s.my = 1.0f;
+  }
+  // keep the float->int conversion defined for wild flows; outside [-2, size+1] every
+  // corner is out of range (zeros modes) or clamps to the same edge (DILATED)
+  const float fx = fminf(fmaxf(ix, -2.0f), (float)p.W + 1.0f);
+  const float fy = fminf(fmaxf(iy, -2.0f), (float)p.H + 1.0f);
+  const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+  const int x1 = x0 + 1, y1 = y0 + 1;
+  if (MODE == FS_WARP2D_DILATED) {
+    s.x0 = min(max(x0, 0), p.W - 1); s.x1 = min(max(x1, 0), p.W - 1);
+    s.y0 = min(max(y0, 0), p.H - 1); s.y1 = min(max(y1, 0), p.H - 1);
+    s.v00 = s.v10 = s.v01 = s.v11 = 1;
+    s.ax = ix - (float)s.x0; s.bx = (float)s.x1 - ix;  // tools.py:504-507 (clamped corners)
+    s.ay = iy - (float)s.y0; s.by = (float)s.y1 - iy;
+  } else {
+    const int x0ok = (x0 >= 0 && x0 < p.W), x1ok = (x1 >= 0 && x1 < p.W);
+    const int y0ok = (y0 >= 0 && y0 < p.H), y1ok = (y1 >= 0 && y1 < p.H);
+    s.v00 = x0ok & y0ok; s.v10 = x1ok & y0ok; s.v01 = x0ok & y1ok; s.v11 = x1ok & y1ok;
+    s.x0 = min(max(x0, 0), p.W - 1); s.x1 = min(max(x1, 0), p.W - 1);
+    s.y0 = min(max(y0, 0), p.H - 1); s.y1 = min(max(y1, 0), p.H - 1);
+    s.ax = ix - (float)x0; s.bx = (float)x1 - ix;
+    s.ay = iy - (float)y0; s.by = (float)y1 - iy;
+  }
+  return s;
+}
+
+// validity mask of WarpingLayer_no_div: grid_sample(ones) >= 1.0 (pwc_modules.py:202-206)
+__device__ __forceinline__ float w2_mask(const Samp2& s) {
+#pragma clang fp contract(off)
+  float m = 0.0f;
+  if (s.v00) m += s.bx * s.by;
+  if (s.v10) m += s.ax * s.by;
+  if (s.v01) m += s.bx * s.ay;
+  if (s.v11) m += s.ax * s.ay;
+  return (m >= 1.0f) ? 1.0f : 0.0f;
+}
+
+template <int MODE, bool MASK>
+__global__ __launch_bounds__(256) void warp2d_fwd_kernel(const float* __restrict__ in,
+                                                         const float* __restrict__ flow,
+                                                         const float* __restrict__ start,
+                                                         float* __restrict__ out, W2P p) {
+  const int HW = p.H * p.W;
+  const long long n = (long long)p.B * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW);
+    const int r = (int)(i - (long long)b * HW);
+    const int y = r / p.W, x = r - y * p.W;
+    const float* fb = flow + (size_t)b * 2 * HW;
+    const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
+    const float mk = MASK ? w2_mask(s) : 1.0f;
+    const int o00 = s.y0 * p.W + s.x0, o10 = s.y0 * p.W + s.x1;
+    const int o01 = s.y1 * p.W + s.x0, o11 = s.y1 * p.W + s.x1;
+    for (int c = 0; c < p.C; ++c) {
+#pragma clang fp contract(off)
+      const float* ic = in + ((size_t)b * p.C + c) * HW;
+      const float q00 = s.v00 ? ic[o00] : 0.f, q10 = s.v10 ? ic[o10] : 0.f;
+      const float q01 = s.v01 ? ic[o01] : 0.f, q11 = s.v11 ? ic[o11] : 0.f;
+      float acc;
+      if (MODE == FS_WARP2D_DILATED) {  // wa*Ia + wb*Ib + wc*Ic + wd*Id (tools.py:508)
+        acc = (s.bx * s.by) * q00 + (s.bx * s.ay) * q01 + (s.ax * s.by) * q10 + (s.ax * s.ay) * q11;
+      } else {  // ATen: nw, ne, sw, se
+        acc = q00 * (s.bx * s.by);
+        acc += q10 * (s.ax * s.by);
+        acc += q01 * (s.bx * s.ay);
+        acc += q11 * (s.ax * s.ay);
+      }
+      out[((size_t)b * p.C + c) * HW + r] = MASK ? acc * mk : acc;
+    }
+  }
+}
+
+template <int MODE, bool MASK, bool WITH_GIN>
+__global__ __launch_bounds__(256) void warp2d_bwd_kernel(const float* __restrict__ in,
+                                                         const float* __restrict__ flow,
+                                                         const float* __restrict__ start,
+                                                         const float* __restrict__ gout,
+                                                         float* __restrict__ gin,
+                                                         float* __restrict__ gflow, W2P p) {
+  const int HW = p.H * p.W;
+  const long long n = (long long)p.B * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW);
+    const int r = (int)(i - (long long)b * HW);
+    const int y = r / p.W, x = r - y * p.W;
+    const float* fb = flow + (size_t)b * 2 * HW;
+    const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
+    const float mk = MASK ? w2_mask(s) : 1.0f;
+    const int o00 = s.y0 * p.W + s.x0, o10 = s.y0 * p.W + s.x1;
+    const int o01 = s.y1 * p.W + s.x0, o11 = s.y1 * p.W + s.x1;
+    float gx = 0.f, gy = 0.f;
+    for (int c = 0; c < p.C; ++c) {
+      const size_t pl = ((size_t)b * p.C + c) * HW;
+      const float g = gout[pl + r] * mk;
+      const float* ic = in + pl;
+      const float q00 = s.v00 ? ic[o00] : 0.f, q10 = s.v10 ? ic[o10] : 0.f;
+      const float q01 = s.v01 ? ic[o01] : 0.f, q11 = s.v11 ? ic[o11] : 0.f;
+      gx += g * (s.by * (q10 - q00) + s.ay * (q11 - q01));
+      gy += g * (s.bx * (q01 - q00) + s.ax * (q11 - q10));
+      if (WITH_GIN) {
+        float* gc = gin + pl;
+        if (s.v00) atomicAdd(gc + o00, g * (s.bx * s.by));
+        if (s.v10) atomicAdd(gc + o10, g * (s.ax * s.by));
+        if (s.v01) atomicAdd(gc + o01, g * (s.bx * s.ay));
+        if (s.v11) atomicAdd(gc + o11, g * (s.ax * s.ay));
+      }
+    }
+    if (gflow != nullptr) {
+      float* gb = gflow + (size_t)b * 2 * HW;
+      gb[r] = gx * s.mx;
+      gb[HW + r] = gy * s.my;
+    }
+  }
+}
+
+int make_params(W2P& p, int B, int C, int H, int W, int mode) {
+  if (B < 1 || C < 1 || H < 1 || W < 1) return FS_ERR_SHAPE;
+  if (mode == FS_WARP2D_RIFE && (H < 2 || W < 2)) return FS_ERR_SHAPE;  // (dim-1)/2 divisor
+  if ((long long)H * W >= (1ll << 31)) return FS_ERR_SHAPE;
+  p.B = B; p.C = C; p.H = H; p.W = W;
+  p.stepH = 2.0f / (float)(H - 1);
+  p.stepW = 2.0f / (float)(W - 1);
+  p.sH = ((float)H - 1.0f) / 2.0f;
+  p.sW = ((float)W - 1.0f) / 2.0f;
+  p.dW = (float)(W - 1 > 1 ? W - 1 : 1);
+  p.dH = (float)(H - 1 > 1 ? H - 1 : 1);
+  p.fW = (float)(2.0 / (double)W);  // python float 2/w, then FloatTensor (RIFE.py:258)
+  p.fH = (float)(2.0 / (double)H);
+  return FS_OK;
+}
+
+unsigned grid_for(const W2P& p) {
+  const long long n = (long long)p.B * p.H * p.W;
+  const long long g = (n + 255) / 256;
+  return (unsigned)(g < 16384 ? g : 16384);  // grid-stride above 64 blocks per CU
+}
+
+template <int MODE, bool MASK>
+void launch_fwd(const float* in, const float* flow, const float* start, float* out, const W2P& p,
+                hipStream_t st) {
+  hipLaunchKernelGGL((warp2d_fwd_kernel<MODE, MASK>), dim3(grid_for(p)), dim3(256), 0, st, in, flow,
+                     start, out, p);
+}
+
+template <int MODE, bool MASK>
+void launch_bwd(const float* in, const float* flow, const float* start, const float* gout,
+                float* gin, float* gflow, const W2P& p, hipStream_t st) {
+  if (gin != nullptr)
+    hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, true>), dim3(grid_for(p)), dim3(256), 0, st, in,
+                       flow, start, gout, gin, gflow, p);
+  else
+    hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, false>), dim3(grid_for(p)), dim3(256), 0, st,
+                       in, flow, start, gout, gin, gflow, p);
+}
+
+}  // namespace
+
+extern "C" int fs_warp2d_fwd(const float* in, const float* flow, const float* start, float* out,
+                             int B, int C, int H, int W, int mode, int with_mask,
+                             fs_stream_t stream) {
+  FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(out);
+  if (mode < FS_WARP2D_RIFE || mode > FS_WARP2D_DILATED) return FS_ERR_ARG;
+  if (with_mask && mode != FS_WARP2D_PWC) return FS_ERR_ARG;
+  if (start != nullptr && mode != FS_WARP2D_DILATED) return FS_ERR_ARG;
+  W2P p;
+  const int rc = make_params(p, B, C, H, W, mode);
+  if (rc != FS_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case FS_WARP2D_RIFE: launch_fwd<FS_WARP2D_RIFE, false>(in, flow, start, out, p, st); break;
+    case FS_WARP2D_PWC:
+      if (with_mask) launch_fwd<FS_WARP2D_PWC, true>(in, flow, start, out, p, st);
+      else launch_fwd<FS_WARP2D_PWC, false>(in, flow, start, out, p, st);
+      break;
+    case FS_WARP2D_PHOTO: launch_fwd<FS_WARP2D_PHOTO, false>(in, flow, start, out, p, st); break;
+    default: launch_fwd<FS_WARP2D_DILATED, false>(in, flow, start, out, p, st); break;
+  }
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+extern "C" int fs_warp2d_bwd(const float* in, const float* flow, const float* start,
+                             const float* grad_out, float* grad_in, float* grad_flow, int B, int C,
+                             int H, int W, int mode, int with_mask, fs_stream_t stream) {
+  FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(grad_out);
+  if (grad_in == nullptr && grad_flow == nullptr) return FS_ERR_NULLPTR;
+  if (mode < FS_WARP2D_RIFE || mode > FS_WARP2D_DILATED) return FS_ERR_ARG;
+  if (with_mask && mode != FS_WARP2D_PWC) return FS_ERR_ARG;
+  if (start != nullptr && mode != FS_WARP2D_DILATED) return FS_ERR_ARG;
+  W2P p;
+  const int rc = make_params(p, B, C, H, W, mode);
+  if (rc != FS_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case FS_WARP2D_RIFE:
+      launch_bwd<FS_WARP2D_RIFE, false>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
+      break;
+    case FS_WARP2D_PWC:
+      if (with_mask)
+        launch_bwd<FS_WARP2D_PWC, true>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
+      else
+        launch_bwd<FS_WARP2D_PWC, false>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
+      break;
+    case FS_WARP2D_PHOTO:
+      launch_bwd<FS_WARP2D_PHOTO, false>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
+      break;
+    default:
+      launch_bwd<FS_WARP2D_DILATED, false>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
+      break;
+  }
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}

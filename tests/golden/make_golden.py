@@ -1,0 +1,286 @@
+"""Generates the golden vectors under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+Build-container only: needs /root/reference (read-only).  The reference never travels to the
+GPU box; only the .npz fixtures written here (inputs + expected outputs / gradients) do.
+Usage (each group imports a different reference package layout, so one process per group):
+
+    python tests/golden/make_golden.py rife_ops     # Flow-2D / Flow-3D warplayer.warp
+    python tests/golden/make_golden.py upflow_ops   # Corr_pyTorch, warps, census, photo losses
+    python tests/golden/make_golden.py flow3d_e2e   # Flow-3D Model.update / inference
+    python tests/golden/make_golden.py flow2d_e2e   # Flow-2D Model.update / inference
+    python tests/golden/make_golden.py all          # runs the groups above as subprocesses
+
+Third-party modules the reference imports at module scope but that are absent from this
+image (cv2, torchvision, ...) are replaced by inert stubs; none of them is on the hot path.
+"""
+import importlib.util
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_stubs():
+    class _Any:
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    for name in ["cv2", "imageio", "png", "pyimof", "plotly", "plotly.graph_objects", "torchvision",
+                 "torchvision.models", "skimage", "skimage.transform", "correlation_cuda",
+                 "ensurepip", "matplotlib", "matplotlib.pyplot", "matplotlib.colors",
+                 "mpl_toolkits", "mpl_toolkits.axes_grid1"]:
+        if name in sys.modules:
+            continue
+        try:
+            if name.startswith("matplotlib") or name.startswith("mpl_toolkits"):
+                __import__(name)
+                continue
+        except Exception:
+            pass
+        m = types.ModuleType(name)
+        m.__file__ = "/dev/null/%s.py" % name
+
+        def _ga(k, _Any=_Any):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _Any()
+
+        m.__getattr__ = _ga
+        sys.modules[name] = m
+
+
+def _load_file(modname, path):
+    spec = importlib.util.spec_from_file_location(modname, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _grads(out, inputs, seed):
+    g = torch.Generator().manual_seed(seed)
+    G = torch.randn(out.shape, generator=g)
+    grads = torch.autograd.grad((out * G).sum(), inputs, allow_unused=True)
+    return G, grads
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _flow_cases(shape, gen, amp):
+    """A smooth-ish random flow with a few wild vectors that leave the domain."""
+    f = (torch.rand(shape, generator=gen) * 2 - 1) * amp
+    wild = torch.rand(shape, generator=gen) < 0.03
+    f = torch.where(wild, f * 6.0, f)
+    return f
+
+
+# ------------------------------------------------------------------------------------------
+def rife_ops():
+    w2 = _load_file("ref_warp2d", REF + "/Flow-2D/model/warplayer.py")
+    w3 = _load_file("ref_warp3d", REF + "/Flow-3D/model/warplayer.py")
+    w2.device = torch.device("cpu")
+    w3.device = torch.device("cpu")
+    gen = torch.Generator().manual_seed(20241)
+    store = {}
+    # 2-D: a1
+    for tag, (B, C, H, W), amp in [("a", (2, 3, 16, 24), 2.5), ("b", (1, 1, 9, 7), 1.5)]:
+        x = torch.rand(B, C, H, W, generator=gen).requires_grad_()
+        f = _flow_cases((B, 2, H, W), gen, amp).requires_grad_()
+        out = w2.warp(x, f)
+        G, (gx, gf) = _grads(out, [x, f], 7)
+        for k, v in dict(x=x, f=f, out=out, G=G, gx=gx, gf=gf).items():
+            store["w2_%s_%s" % (tag, k)] = _np(v)
+    x = torch.rand(1, 2, 8, 12, generator=gen)
+    store["w2_zero_x"] = _np(x)
+    store["w2_zero_out"] = _np(w2.warp(x, torch.zeros(1, 2, 8, 12)))
+    # 3-D: a2, non-cubic (pins every axis role) and cubic
+    for tag, (B, C, D, H, W), amp in [("nc", (1, 2, 6, 8, 10), 1.5), ("cu", (2, 1, 8, 8, 8), 2.0),
+                                      ("tile", (1, 1, 3, 70, 37), 2.0)]:
+        x = torch.rand(B, C, D, H, W, generator=gen).requires_grad_()
+        f = _flow_cases((B, 3, D, H, W), gen, amp).requires_grad_()
+        out = w3.warp(x, f)
+        G, (gx, gf) = _grads(out, [x, f], 11)
+        for k, v in dict(x=x, f=f, out=out, G=G, gx=gx, gf=gf).items():
+            store["w3_%s_%s" % (tag, k)] = _np(v)
+    x = torch.rand(1, 1, 5, 6, 7, generator=gen)
+    store["w3_zero_x"] = _np(x)
+    store["w3_zero_out"] = _np(w3.warp(x, torch.zeros(1, 3, 5, 6, 7)))
+    np.savez_compressed(os.path.join(OUT, "rife_ops.npz"), **store)
+    print("wrote rife_ops.npz", len(store), "arrays")
+
+
+# ------------------------------------------------------------------------------------------
+def upflow_ops():
+    _install_stubs()
+    sys.path[:0] = [REF + "/UPFlow"]
+    from utils.pytorch_correlation import Corr_pyTorch
+    from utils.loss import loss_functions
+    from utils.tools import tools
+    from model.pwc_modules import WarpingLayer_no_div
+    import model.upflow as U
+    U.device = torch.device("cpu")
+    gen = torch.Generator().manual_seed(777)
+    store = {}
+    # a3/a4 correlation (Corr_pyTorch, the reference's stand-in for correlation_cuda)
+    corr = Corr_pyTorch(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1,
+                        corr_multiply=1)
+    for tag, (B, C, H, W) in [("c3", (2, 3, 10, 14)), ("c32", (1, 32, 10, 14)), ("tiny", (1, 5, 3, 8))]:
+        f1 = torch.randn(B, C, H, W, generator=gen).requires_grad_()
+        f2 = torch.randn(B, C, H, W, generator=gen).requires_grad_()
+        out = corr(f1, f2)
+        G, (g1, g2) = _grads(out, [f1, f2], 3)
+        for k, v in dict(f1=f1, f2=f2, out=out, G=G, g1=g1, g2=g2).items():
+            store["corr_%s_%s" % (tag, k)] = _np(v)
+    # a5 WarpingLayer_no_div, a6 torch_warp
+    wl = WarpingLayer_no_div()
+    B, C, H, W = 2, 4, 12, 20
+    x = torch.rand(B, C, H, W, generator=gen).requires_grad_()
+    f = _flow_cases((B, 2, H, W), gen, 2.0).requires_grad_()
+    out = wl(x, f)
+    G, (gx, gf) = _grads(out, [x, f], 5)
+    for k, v in dict(x=x, f=f, out=out, G=G, gx=gx, gf=gf).items():
+        store["pwcmask_%s" % k] = _np(v)
+    out = tools.torch_warp(x, f)
+    G, (gx, gf) = _grads(out, [x, f], 6)
+    for k, v in dict(out=out, G=G, gx=gx, gf=gf).items():
+        store["pwc_%s" % k] = _np(v)
+    # a7 boundary_dilated_warp.warp_im
+    B, C, H, W = 2, 3, 14, 18
+    I = torch.rand(B, C, H, W, generator=gen).requires_grad_()
+    f = _flow_cases((B, 2, H, W), gen, 2.0).requires_grad_()
+    for tag, start in [("s0", torch.zeros(B, 2, 1, 1)),
+                       ("s1", torch.tensor([[1.0, 2.0], [0.0, -1.0]]).view(B, 2, 1, 1))]:
+        out = tools.boundary_dilated_warp.warp_im(I, f, start)
+        G, (gI, gf) = _grads(out, [I, f], 8)
+        for k, v in dict(I=I, f=f, start=start, out=out, G=G, gI=gI, gf=gf).items():
+            store["dil_%s_%s" % (tag, k)] = _np(v)
+    # a8 census loss, a10 photo_loss_function
+    B, H, W = 2, 32, 48
+    im1 = torch.rand(B, 3, H, W, generator=gen).requires_grad_()
+    im2 = (im1.detach() + 0.1 * torch.randn(B, 3, H, W, generator=gen)).requires_grad_()
+    occ = (torch.rand(B, 1, H, W, generator=gen) > 0.3).float()
+    store.update(cen_im1=_np(im1), cen_im2=_np(im2), cen_occ=_np(occ))
+    for tag, (cha, useocc) in [("abs", (False, False)), ("absocc", (False, True)),
+                               ("cha", (True, False)), ("chaocc", (True, True))]:
+        loss = loss_functions.census_loss_torch(im1, im2, occ, q=0.4, charbonnier_or_abs_robust=cha,
+                                                if_use_occ=useocc, averge=True)
+        g1, g2 = torch.autograd.grad(loss, [im1, im2])
+        store["cen_%s_loss" % tag] = _np(loss)
+        store["cen_%s_g1" % tag] = _np(g1)
+        store["cen_%s_g2" % tag] = _np(g2)
+    # a9 photo_loss_multi_type
+    for typ in ["abs_robust", "charbonnier", "L1", "SSIM"]:
+        for useocc in [False, True]:
+            loss = U.network_tools.photo_loss_multi_type(im1, im2, occ, photo_loss_type=typ,
+                                                         photo_loss_delta=0.4,
+                                                         photo_loss_use_occ=useocc)
+            g1, g2 = torch.autograd.grad(loss, [im1, im2])
+            tag = "%s_%d" % (typ, int(useocc))
+            store["photo_%s_loss" % tag] = _np(loss)
+            store["photo_%s_g1" % tag] = _np(g1)
+            store["photo_%s_g2" % tag] = _np(g2)
+    np.savez_compressed(os.path.join(OUT, "upflow_ops.npz"), **store)
+    print("wrote upflow_ops.npz", len(store), "arrays")
+
+
+# ------------------------------------------------------------------------------------------
+def _quiet(fn, *a, **k):
+    """The reference prints on every forward; keep the generator's output readable."""
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def flow3d_e2e():
+    _install_stubs()
+    sys.path[:0] = [REF + "/Flow-3D", REF]
+    import model.RIFE as R
+    import model.warplayer as WL
+    R.device = torch.device("cpu")
+    WL.device = torch.device("cpu")
+    torch.manual_seed(1234)
+    m = _quiet(R.Model, local_rank=-1)
+    gen = torch.Generator().manual_seed(99)
+    S = 32
+    data = torch.rand(1, 3, S, S, S, generator=gen)
+    imgs, gt = data[:, :2], data[:, 2:3]
+    store = dict(data=_np(data))
+    nparam = sum(p.numel() for p in m.flownet.parameters())
+    store["nparam"] = np.array(nparam)
+    # parameter fingerprint (seed-compatibility check for the oracle / product models)
+    store["param_sums"] = np.array([float(p.double().sum()) for p in m.flownet.parameters()])
+    m.eval()
+    with torch.no_grad():
+        merged, flows, mask = _quiet(m.inference, imgs[:, :1], imgs[:, 1:2], [4, 2, 1])
+    store["inf_merged"] = _np(merged)
+    store["inf_flow2"] = _np(flows[2])
+    store["inf_mask"] = _np(mask)
+    losses = []
+    for step in range(2):
+        pred, info = _quiet(m.update, imgs, gt, learning_rate=1e-4, training=True)
+        losses.append([float(info[k]) for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G")])
+    store["update_losses"] = np.array(losses)
+    store["update_pred_last"] = _np(pred)
+    store["param_sums_after"] = np.array([float(p.double().sum()) for p in m.flownet.parameters()])
+    np.savez_compressed(os.path.join(OUT, "flow3d_e2e.npz"), **store)
+    print("wrote flow3d_e2e.npz; losses", losses, "nparam", nparam)
+
+
+def flow2d_e2e():
+    _install_stubs()
+    sys.path[:0] = [REF + "/Flow-2D", REF]
+    import model.RIFE as R
+    import model.warplayer as WL
+    R.device = torch.device("cpu")
+    WL.device = torch.device("cpu")
+    torch.manual_seed(1234)
+    m = _quiet(R.Model, local_rank=-1)
+    gen = torch.Generator().manual_seed(98)
+    H, W = 64, 96
+    data = torch.rand(2, 3, H, W, generator=gen)
+    imgs, gt = data[:, :2], data[:, 2:3]
+    store = dict(data=_np(data))
+    store["nparam"] = np.array(sum(p.numel() for p in m.flownet.parameters()))
+    store["param_sums"] = np.array([float(p.double().sum()) for p in m.flownet.parameters()])
+    m.eval()
+    with torch.no_grad():
+        merged, flows, mask = _quiet(m.inference, imgs[:, :1], imgs[:, 1:2], [4, 2, 1])
+    store["inf_merged"] = _np(merged)
+    store["inf_flow2"] = _np(flows[2])
+    store["inf_mask"] = _np(mask)
+    losses, keys = [], None
+    for step in range(2):
+        pred, info = _quiet(m.update, imgs, gt, "droplet2d", learning_rate=1e-4, training=True)
+        keys = [k for k in info if k.startswith("loss")]
+        losses.append([float(info[k]) for k in keys])
+    store["update_loss_keys"] = np.array(keys)
+    store["update_losses"] = np.array(losses)
+    store["update_pred_last"] = _np(pred)
+    store["param_sums_after"] = np.array([float(p.double().sum()) for p in m.flownet.parameters()])
+    np.savez_compressed(os.path.join(OUT, "flow2d_e2e.npz"), **store)
+    print("wrote flow2d_e2e.npz; keys", keys, "losses", losses)
+
+
+GROUPS = dict(rife_ops=rife_ops, upflow_ops=upflow_ops, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e)
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    torch.set_num_threads(8)
+    if which == "all":
+        for g in GROUPS:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), g])
+    else:
+        GROUPS[which]()
