@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- volume-pairs/s of one full unsupervised Flow-3D train step on MI355X.
+
+Workload (BASELINE.json metric / config "Flow-3D Droplet 256^3 volumes ... batch 2, 1xMI355X"):
+synthetic Droplet-3D triplets [B=2, 3, 256, 256, 256] per GPU, random-init RIFE IFNet-3D, one step =
+forward (3 student blocks + teacher, 4 warp-pair launches) + L1/distillation losses + backward +
+AdamW.  The convolutions are stock torch.nn (MIOpen); the backward warps are this repo's HIP kernels.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, DDP over RCCL; each rank draws its own volume pairs (seed 1234+rank):
+weak scaling, the only collective is DDP's gradient all-reduce.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+
+# algorithmic HBM bytes per voxel of ONE warp (DESIGN.md "warp3d"):
+#   fwd: 12 flow + 4 gather + 4 store = 20;  bwd (grad_flow only; images carry no grad in
+#   training): 12 flow + 4 gather + 4 grad_out + 12 grad_flow = 32.  A pair launch does two warps.
+BYTES_PER_VOXEL = {"fs_warp3d_pair_fwd": 2 * 20, "fs_warp3d_pair_bwd": 2 * 32}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=256, help="volume edge (BASELINE: 256)")
+    ap.add_argument("--batch", type=int, default=2, help="volume pairs per GPU (BASELINE: 2)")
+    ap.add_argument("--dataset", default="droplet3d", choices=["droplet3d", "jets3d"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=128, help="edge of the bounded CPU sample")
+    return ap.parse_args()
+
+
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return min(n, 64)
+
+
+def log(msg):
+    print("[bench %6.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_baseline(size, steps=2):
+    """The oracle's Flow-3D train step (the reference's CPU PyTorch path, restated) on this box's
+    host cores, on a bounded sample: B=1 at `size`^3, reported as 256^3-equivalent pairs/s."""
+    from oracle.ifnet_ref import ModelRef
+    from opticalflowscivis_amd.data import synthetic
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log("cpu_baseline: oracle step at %d^3 on %d cores" % (size, cores))
+    torch.manual_seed(1234)
+    m = ModelRef(3)
+    data = synthetic.droplet3d_batch(1, size, seed=1234)
+    imgs, gt = data[:, :2], data[:, 2:3]
+    m.update(imgs, gt, learning_rate=1e-4, training=True)  # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.update(imgs, gt, learning_rate=1e-4, training=True)
+    dt = (time.perf_counter() - t0) / steps
+    vox_ratio = (size / 256.0) ** 3
+    return {"value": (1.0 / dt) * vox_ratio, "unit": "volume-pairs/s (256^3-equivalent)",
+            "cores": cores, "kind": "port",
+            "sample": "oracle Flow-3D train step, B=1 at %d^3, %d timed steps, %.2f s/step; scaled "
+                      "by voxel count (x%.4f) to 256^3" % (size, steps, dt, vox_ratio)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d (see docstring)" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank)  # RCCL on ROCm
+
+    from opticalflowscivis_amd import ops
+    from opticalflowscivis_amd.data import synthetic
+    from opticalflowscivis_amd.flow3d.model.RIFE import Model
+
+    torch.manual_seed(1234)  # same initial weights on every rank (DDP would broadcast anyway)
+    model = Model(local_rank=local_rank if world > 1 else -1, device=dev)
+    S, B = args.size, args.batch
+    gen = synthetic.droplet3d_batch if args.dataset == "droplet3d" else synthetic.jets3d_batch
+    data = gen(B, S, seed=1234 + rank, device=dev)  # resident in HBM before the timed region
+    imgs, gt = data[:, :2].contiguous(), data[:, 2:3].contiguous()
+    # reference LR schedule scaled by world_size / 4 (Flow-3D/train.py:167), warm-up phase value
+    lr = 3e-4 * (10 / 2000.) * world / 4
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        log("data + model ready; %d warm-up steps" % args.warmup)
+    for i in range(args.warmup):
+        model.update(imgs, gt, learning_rate=lr, training=True)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log("warm-up step %d done" % i)
+    barrier()
+    ops.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred, info = model.update(imgs, gt, learning_rate=lr, training=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = ops.kernel_timings()
+    ops.enable_kernel_timing(False)
+    loss = float(info["loss_G"].detach())
+    if rank == 0:
+        log("timed region: %d steps in %.3f s" % (args.steps, dt))
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        nvox = B * S ** 3
+        kern = {}
+        for name, ms in ktimes.items():
+            avg = sum(ms) / len(ms)
+            gbs = BYTES_PER_VOXEL.get(name, 0) * nvox / (avg * 1e-3) / 1e9
+            kern[name] = {"launches": len(ms), "avg_ms": round(avg, 4), "algo_GBps": round(gbs, 1)}
+        # dominant hand-written kernel = the one with the largest total time in the timed region
+        dom = max(ktimes, key=lambda k: sum(ktimes[k]))
+        out = {
+            "metric": "volume-pairs/sec, Flow-3D unsupervised train step (fwd+loss+bwd+AdamW)",
+            "value": world * B * args.steps / dt,
+            "unit": "volume-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Flow-3D %s %d^3, batch %d per GPU, IFNet-3D random init, "
+                                   "3D trilinear warp HIP kernels" % (args.dataset, S, B),
+                       "global_batch": world * B, "volume": [S, S, S],
+                       "parallelism": "dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom + " (warp3d_%s_kernel)" %
+                         ("bwd" if dom.endswith("bwd") else "fwd"),
+                         "achieved": kern[dom]["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(kern[dom]["algo_GBps"] / HBM_PEAK_GBS, 4), "traffic": None},
+            "kernels": kern,
+            "loss_G": loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,14 +43,32 @@ const char* fs_error_string(int code);
  *   5-D grid_sample(bilinear, border, align_corners=True)               (:36)
  *   i.e. the axis-rotating sampling  out[d,h,w] = in[(w+F2)(D-1)/(W-1), (d+F1)(H-1)/(D-1),
  *   (h+F0)(W-1)/(H-1)]  with border clamp.  D,H,W >= 2.
+ *   D,H,W are the extent of the FLOW (= of the output).  The reference builds its grid from
+ *   the flow's shape and its divisors from the input's (:11-26), so the sampled volume may
+ *   have a different extent: `in_dhw` = {Din,Hin,Win} (HOST pointer to 3 ints) or NULL when
+ *   the input has the flow's extent.  (IFNet-3D hits this for sizes that are not multiples
+ *   of 16: Flow-3D/model/IFNet.py:151-191.)
  * bwd: grad_in (nullable; must be zero-filled by the caller, accumulated with float
  *   atomics) and grad_flow (nullable; fully overwritten).
  */
 int fs_warp3d_fwd(const float* in, const float* flow, float* out,
-                  int B, int C, int D, int H, int W, fs_stream_t stream);
+                  int B, int C, const int* in_dhw, int D, int H, int W, fs_stream_t stream);
 int fs_warp3d_bwd(const float* in, const float* flow, const float* grad_out,
                   float* grad_in, float* grad_flow,
-                  int B, int C, int D, int H, int W, fs_stream_t stream);
+                  int B, int C, const int* in_dhw, int D, int H, int W, fs_stream_t stream);
+
+/* The IFNet call site warps BOTH frames with the two halves of one 6-channel flow:
+ *   warped_img0 = warp(img0, flow[:, :3]); warped_img1 = warp(img1, flow[:, 3:6])
+ *   (Flow-3D/model/IFNet.py:190-191, 233-234).  One launch serves both and uses flow6 /
+ * grad_flow6 [B,6,D,H,W] in place (no slice copies).  grad_img0/grad_img1: both or neither.
+ */
+int fs_warp3d_pair_fwd(const float* img0, const float* img1, const float* flow6,
+                       float* out0, float* out1,
+                       int B, int C, const int* in_dhw, int D, int H, int W, fs_stream_t stream);
+int fs_warp3d_pair_bwd(const float* img0, const float* img1, const float* flow6,
+                       const float* grad_out0, const float* grad_out1,
+                       float* grad_img0, float* grad_img1, float* grad_flow6,
+                       int B, int C, const int* in_dhw, int D, int H, int W, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 2-D bilinear backward warps.  in [B,C,H,W], flow [B,2,H,W] (ch0 = x, ch1 = y),
@@ -78,6 +96,17 @@ int fs_warp2d_fwd(const float* in, const float* flow, const float* start, float*
 int fs_warp2d_bwd(const float* in, const float* flow, const float* start,
                   const float* grad_out, float* grad_in, float* grad_flow,
                   int B, int C, int H, int W, int mode, int with_mask, fs_stream_t stream);
+
+/* Pair form for the IFNet call site (Flow-2D/model/IFNet.py:191-192, 230-231):
+ *   warp(img0, flow[:, :2]); warp(img1, flow[:, 2:4])  with flow4 [B,4,H,W] used in place.
+ * No mask, no start. */
+int fs_warp2d_pair_fwd(const float* img0, const float* img1, const float* flow4,
+                       float* out0, float* out1,
+                       int B, int C, int H, int W, int mode, fs_stream_t stream);
+int fs_warp2d_pair_bwd(const float* img0, const float* img1, const float* flow4,
+                       const float* grad_out0, const float* grad_out1,
+                       float* grad_img0, float* grad_img1, float* grad_flow4,
+                       int B, int C, int H, int W, int mode, fs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -13,13 +13,18 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libflowsci_hip.so")
 _f32p = ctypes.c_void_p  # device pointers travel as integers
 _int = ctypes.c_int
 _stream = ctypes.c_void_p
+_intp = ctypes.POINTER(ctypes.c_int)  # host array of ints (or None)
 
 # name -> argtypes; restype is int unless listed in _RESTYPES
 SIGNATURES = {
     "fs_version": [],
     "fs_error_string": [_int],
-    "fs_warp3d_fwd": [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _stream],
-    "fs_warp3d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _stream],
+    "fs_warp3d_fwd": [_f32p] * 3 + [_int, _int, _intp, _int, _int, _int, _stream],
+    "fs_warp3d_bwd": [_f32p] * 5 + [_int, _int, _intp, _int, _int, _int, _stream],
+    "fs_warp3d_pair_fwd": [_f32p] * 5 + [_int, _int, _intp, _int, _int, _int, _stream],
+    "fs_warp3d_pair_bwd": [_f32p] * 8 + [_int, _int, _intp, _int, _int, _int, _stream],
+    "fs_warp2d_pair_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
+    "fs_warp2d_pair_bwd": [_f32p] * 8 + [_int] * 5 + [_stream],
     "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _stream],
     "fs_warp2d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                       _stream],

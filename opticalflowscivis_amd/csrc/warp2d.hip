@@ -21,7 +21,13 @@ struct W2P {
   float stepH, stepW, sH, sW;  // RIFE: linspace steps and (n-1)/2
   float dW, dH;                // PWC: max(W-1,1), max(H-1,1)
   float fW, fH;                // PHOTO: float(2/W), float(2/H)
+  int flowC;                   // channels of the flow tensor: 2 (single) or 4 (IFNet pair)
 };
+
+// blockIdx.y selects the member of a pair (img0 with flow[:, :2], img1 with flow[:, 2:4]:
+// Flow-2D/model/IFNet.py:191-192); the 4-channel flow tensors are used in place.
+struct W2Fwd { const float* in[2]; float* out[2]; };
+struct W2Bwd { const float* in[2]; const float* gout[2]; float* gin[2]; };
 
 struct Samp2 {
   int x0, x1, y0, y1;      // addressing indices (always inside the image)
@@ -104,10 +110,10 @@ __device__ __forceinline__ float w2_mask(const Samp2& s) {
 }
 
 template <int MODE, bool MASK>
-__global__ __launch_bounds__(256) void warp2d_fwd_kernel(const float* __restrict__ in,
-                                                         const float* __restrict__ flow,
-                                                         const float* __restrict__ start,
-                                                         float* __restrict__ out, W2P p) {
+__global__ __launch_bounds__(256) void warp2d_fwd_kernel(W2Fwd io, const float* __restrict__ flow,
+                                                         const float* __restrict__ start, W2P p) {
+  const float* __restrict__ in = io.in[blockIdx.y];
+  float* __restrict__ out = io.out[blockIdx.y];
   const int HW = p.H * p.W;
   const long long n = (long long)p.B * HW;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256) void warp2d_fwd_kernel(const float* __restrict
     const int b = (int)(i / HW);
     const int r = (int)(i - (long long)b * HW);
     const int y = r / p.W, x = r - y * p.W;
-    const float* fb = flow + (size_t)b * 2 * HW;
+    const float* fb = flow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
     const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
     const float mk = MASK ? w2_mask(s) : 1.0f;
     const int o00 = s.y0 * p.W + s.x0, o10 = s.y0 * p.W + s.x1;
@@ -140,12 +146,12 @@ __global__ __launch_bounds__(256) void warp2d_fwd_kernel(const float* __restrict
 }
 
 template <int MODE, bool MASK, bool WITH_GIN>
-__global__ __launch_bounds__(256) void warp2d_bwd_kernel(const float* __restrict__ in,
-                                                         const float* __restrict__ flow,
+__global__ __launch_bounds__(256) void warp2d_bwd_kernel(W2Bwd io, const float* __restrict__ flow,
                                                          const float* __restrict__ start,
-                                                         const float* __restrict__ gout,
-                                                         float* __restrict__ gin,
                                                          float* __restrict__ gflow, W2P p) {
+  const float* __restrict__ in = io.in[blockIdx.y];
+  const float* __restrict__ gout = io.gout[blockIdx.y];
+  float* __restrict__ gin = io.gin[blockIdx.y];
   const int HW = p.H * p.W;
   const long long n = (long long)p.B * HW;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) void warp2d_bwd_kernel(const float* __restrict
     const int b = (int)(i / HW);
     const int r = (int)(i - (long long)b * HW);
     const int y = r / p.W, x = r - y * p.W;
-    const float* fb = flow + (size_t)b * 2 * HW;
+    const float* fb = flow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
     const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
     const float mk = MASK ? w2_mask(s) : 1.0f;
     const int o00 = s.y0 * p.W + s.x0, o10 = s.y0 * p.W + s.x1;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void warp2d_bwd_kernel(const float* __restrict
       }
     }
     if (gflow != nullptr) {
-      float* gb = gflow + (size_t)b * 2 * HW;
+      float* gb = gflow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
       gb[r] = gx * s.mx;
       gb[HW + r] = gy * s.my;
     }
@@ -206,21 +212,60 @@ unsigned grid_for(const W2P& p) {
 }
 
 template <int MODE, bool MASK>
-void launch_fwd(const float* in, const float* flow, const float* start, float* out, const W2P& p,
+void launch_fwd(const W2Fwd& io, int npair, const float* flow, const float* start, W2P& p,
                 hipStream_t st) {
-  hipLaunchKernelGGL((warp2d_fwd_kernel<MODE, MASK>), dim3(grid_for(p)), dim3(256), 0, st, in, flow,
-                     start, out, p);
+  p.flowC = 2 * npair;
+  hipLaunchKernelGGL((warp2d_fwd_kernel<MODE, MASK>), dim3(grid_for(p), npair), dim3(256), 0, st, io,
+                     flow, start, p);
 }
 
 template <int MODE, bool MASK>
-void launch_bwd(const float* in, const float* flow, const float* start, const float* gout,
-                float* gin, float* gflow, const W2P& p, hipStream_t st) {
-  if (gin != nullptr)
-    hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, true>), dim3(grid_for(p)), dim3(256), 0, st, in,
-                       flow, start, gout, gin, gflow, p);
+void launch_bwd(const W2Bwd& io, int npair, const float* flow, const float* start, float* gflow,
+                W2P& p, hipStream_t st) {
+  p.flowC = 2 * npair;
+  if (io.gin[0] != nullptr)
+    hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, true>), dim3(grid_for(p), npair), dim3(256), 0,
+                       st, io, flow, start, gflow, p);
   else
-    hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, false>), dim3(grid_for(p)), dim3(256), 0, st,
-                       in, flow, start, gout, gin, gflow, p);
+    hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, false>), dim3(grid_for(p), npair), dim3(256), 0,
+                       st, io, flow, start, gflow, p);
+}
+
+int dispatch_fwd(const W2Fwd& io, int npair, const float* flow, const float* start, W2P& p, int mode,
+                 int with_mask, hipStream_t st) {
+  switch (mode) {
+    case FS_WARP2D_RIFE: launch_fwd<FS_WARP2D_RIFE, false>(io, npair, flow, start, p, st); break;
+    case FS_WARP2D_PWC:
+      if (with_mask) launch_fwd<FS_WARP2D_PWC, true>(io, npair, flow, start, p, st);
+      else launch_fwd<FS_WARP2D_PWC, false>(io, npair, flow, start, p, st);
+      break;
+    case FS_WARP2D_PHOTO: launch_fwd<FS_WARP2D_PHOTO, false>(io, npair, flow, start, p, st); break;
+    default: launch_fwd<FS_WARP2D_DILATED, false>(io, npair, flow, start, p, st); break;
+  }
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int dispatch_bwd(const W2Bwd& io, int npair, const float* flow, const float* start, float* gflow,
+                 W2P& p, int mode, int with_mask, hipStream_t st) {
+  switch (mode) {
+    case FS_WARP2D_RIFE: launch_bwd<FS_WARP2D_RIFE, false>(io, npair, flow, start, gflow, p, st); break;
+    case FS_WARP2D_PWC:
+      if (with_mask) launch_bwd<FS_WARP2D_PWC, true>(io, npair, flow, start, gflow, p, st);
+      else launch_bwd<FS_WARP2D_PWC, false>(io, npair, flow, start, gflow, p, st);
+      break;
+    case FS_WARP2D_PHOTO: launch_bwd<FS_WARP2D_PHOTO, false>(io, npair, flow, start, gflow, p, st); break;
+    default: launch_bwd<FS_WARP2D_DILATED, false>(io, npair, flow, start, gflow, p, st); break;
+  }
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int check_mode(int mode, int with_mask, const float* start) {
+  if (mode < FS_WARP2D_RIFE || mode > FS_WARP2D_DILATED) return FS_ERR_ARG;
+  if (with_mask && mode != FS_WARP2D_PWC) return FS_ERR_ARG;
+  if (start != nullptr && mode != FS_WARP2D_DILATED) return FS_ERR_ARG;
+  return FS_OK;
 }
 
 }  // namespace
@@ -229,24 +274,13 @@ extern "C" int fs_warp2d_fwd(const float* in, const float* flow, const float* st
                              int B, int C, int H, int W, int mode, int with_mask,
                              fs_stream_t stream) {
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(out);
-  if (mode < FS_WARP2D_RIFE || mode > FS_WARP2D_DILATED) return FS_ERR_ARG;
-  if (with_mask && mode != FS_WARP2D_PWC) return FS_ERR_ARG;
-  if (start != nullptr && mode != FS_WARP2D_DILATED) return FS_ERR_ARG;
-  W2P p;
-  const int rc = make_params(p, B, C, H, W, mode);
+  int rc = check_mode(mode, with_mask, start);
   if (rc != FS_OK) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  switch (mode) {
-    case FS_WARP2D_RIFE: launch_fwd<FS_WARP2D_RIFE, false>(in, flow, start, out, p, st); break;
-    case FS_WARP2D_PWC:
-      if (with_mask) launch_fwd<FS_WARP2D_PWC, true>(in, flow, start, out, p, st);
-      else launch_fwd<FS_WARP2D_PWC, false>(in, flow, start, out, p, st);
-      break;
-    case FS_WARP2D_PHOTO: launch_fwd<FS_WARP2D_PHOTO, false>(in, flow, start, out, p, st); break;
-    default: launch_fwd<FS_WARP2D_DILATED, false>(in, flow, start, out, p, st); break;
-  }
-  FS_LAUNCH_CHECK();
-  return FS_OK;
+  W2P p;
+  rc = make_params(p, B, C, H, W, mode);
+  if (rc != FS_OK) return rc;
+  W2Fwd io = {{in, nullptr}, {out, nullptr}};
+  return dispatch_fwd(io, 1, flow, start, p, mode, with_mask, (hipStream_t)stream);
 }
 
 extern "C" int fs_warp2d_bwd(const float* in, const float* flow, const float* start,
@@ -254,30 +288,42 @@ extern "C" int fs_warp2d_bwd(const float* in, const float* flow, const float* st
                              int H, int W, int mode, int with_mask, fs_stream_t stream) {
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(grad_out);
   if (grad_in == nullptr && grad_flow == nullptr) return FS_ERR_NULLPTR;
-  if (mode < FS_WARP2D_RIFE || mode > FS_WARP2D_DILATED) return FS_ERR_ARG;
-  if (with_mask && mode != FS_WARP2D_PWC) return FS_ERR_ARG;
-  if (start != nullptr && mode != FS_WARP2D_DILATED) return FS_ERR_ARG;
-  W2P p;
-  const int rc = make_params(p, B, C, H, W, mode);
+  int rc = check_mode(mode, with_mask, start);
   if (rc != FS_OK) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  switch (mode) {
-    case FS_WARP2D_RIFE:
-      launch_bwd<FS_WARP2D_RIFE, false>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
-      break;
-    case FS_WARP2D_PWC:
-      if (with_mask)
-        launch_bwd<FS_WARP2D_PWC, true>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
-      else
-        launch_bwd<FS_WARP2D_PWC, false>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
-      break;
-    case FS_WARP2D_PHOTO:
-      launch_bwd<FS_WARP2D_PHOTO, false>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
-      break;
-    default:
-      launch_bwd<FS_WARP2D_DILATED, false>(in, flow, start, grad_out, grad_in, grad_flow, p, st);
-      break;
-  }
-  FS_LAUNCH_CHECK();
-  return FS_OK;
+  W2P p;
+  rc = make_params(p, B, C, H, W, mode);
+  if (rc != FS_OK) return rc;
+  W2Bwd io = {{in, nullptr}, {grad_out, nullptr}, {grad_in, nullptr}};
+  return dispatch_bwd(io, 1, flow, start, grad_flow, p, mode, with_mask, (hipStream_t)stream);
+}
+
+extern "C" int fs_warp2d_pair_fwd(const float* img0, const float* img1, const float* flow4,
+                                  float* out0, float* out1, int B, int C, int H, int W, int mode,
+                                  fs_stream_t stream) {
+  FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow4);
+  FS_REQUIRE_PTR(out0); FS_REQUIRE_PTR(out1);
+  int rc = check_mode(mode, 0, nullptr);
+  if (rc != FS_OK) return rc;
+  W2P p;
+  rc = make_params(p, B, C, H, W, mode);
+  if (rc != FS_OK) return rc;
+  W2Fwd io = {{img0, img1}, {out0, out1}};
+  return dispatch_fwd(io, 2, flow4, nullptr, p, mode, 0, (hipStream_t)stream);
+}
+
+extern "C" int fs_warp2d_pair_bwd(const float* img0, const float* img1, const float* flow4,
+                                  const float* grad_out0, const float* grad_out1, float* grad_img0,
+                                  float* grad_img1, float* grad_flow4, int B, int C, int H, int W,
+                                  int mode, fs_stream_t stream) {
+  FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow4);
+  FS_REQUIRE_PTR(grad_out0); FS_REQUIRE_PTR(grad_out1);
+  if ((grad_img0 == nullptr) != (grad_img1 == nullptr)) return FS_ERR_NULLPTR;
+  if (grad_img0 == nullptr && grad_flow4 == nullptr) return FS_ERR_NULLPTR;
+  int rc = check_mode(mode, 0, nullptr);
+  if (rc != FS_OK) return rc;
+  W2P p;
+  rc = make_params(p, B, C, H, W, mode);
+  if (rc != FS_OK) return rc;
+  W2Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
+  return dispatch_bwd(io, 2, flow4, nullptr, grad_flow4, p, mode, 0, (hipStream_t)stream);
 }

@@ -34,11 +34,20 @@ constexpr int TH = 64;   // tile extent along h = one wave of lanes in phase 2
 constexpr int NT = 256;  // 4 waves
 
 struct W3P {
-  int B, C, D, H, W;
+  int B, C, D, H, W;          // batch, image channels, extent of the flow == of the output
+  int Di, Hi, Wi;             // extent of the sampled volume (the reference lets it differ:
+                              // the grid comes from the flow's shape, warplayer.py:11-22)
   int tilesH, tilesW;
-  float stepD, stepH, stepW;  // linspace steps 2/(n-1)
-  float sD, sH, sW;           // (n-1)/2
+  float stepD, stepH, stepW;  // linspace steps 2/(n-1) over the FLOW dims
+  float sD, sH, sW;           // (n-1)/2 of the INPUT dims (warplayer.py:24-26)
+  int flowC;                  // channels of the flow tensor: 3 (single) or 6 (IFNet pair)
 };
+
+// blockIdx.y selects the member of a pair: IFNet warps img0 with flow[:, :3] and img1 with
+// flow[:, 3:6] (Flow-3D/model/IFNet.py:190-191); one launch serves both and reads / writes the
+// 6-channel flow tensors in place (no slicing copies).
+struct W3Fwd { const float* in[2]; float* out[2]; };
+struct W3Bwd { const float* in[2]; const float* gout[2]; float* gin[2]; };
 
 struct Samp3 {
   float ix, iy, iz;     // clipped, un-normalised coordinates
@@ -54,12 +63,12 @@ __device__ __forceinline__ Samp3 w3_coords(const W3P& p, int d, int h, int w, fl
   const float gy = fs::linspace_pm1(d, p.D, p.stepD) + f1 / p.sD;  // warplayer.py:17,25
   const float gz = fs::linspace_pm1(w, p.W, p.stepW) + f2 / p.sW;  // warplayer.py:19,26
   // grid_sampler_unnormalize, align_corners=True; x -> dim W, y -> dim H, z -> dim D
-  float ix = ((gx + 1.0f) / 2.0f) * (float)(p.W - 1);
-  float iy = ((gy + 1.0f) / 2.0f) * (float)(p.H - 1);
-  float iz = ((gz + 1.0f) / 2.0f) * (float)(p.D - 1);
-  s.ix = fs::clip_border(ix, p.W, &s.mx);
-  s.iy = fs::clip_border(iy, p.H, &s.my);
-  s.iz = fs::clip_border(iz, p.D, &s.mz);
+  float ix = ((gx + 1.0f) / 2.0f) * (float)(p.Wi - 1);
+  float iy = ((gy + 1.0f) / 2.0f) * (float)(p.Hi - 1);
+  float iz = ((gz + 1.0f) / 2.0f) * (float)(p.Di - 1);
+  s.ix = fs::clip_border(ix, p.Wi, &s.mx);
+  s.iy = fs::clip_border(iy, p.Hi, &s.my);
+  s.iz = fs::clip_border(iz, p.Di, &s.mz);
   s.x0 = (int)floorf(s.ix);
   s.y0 = (int)floorf(s.iy);
   s.z0 = (int)floorf(s.iz);
@@ -74,13 +83,13 @@ struct Corners {
 
 __device__ __forceinline__ Corners w3_gather(const float* __restrict__ vol, const W3P& p,
                                              const Samp3& s) {
-  const int x1ok = (s.x0 + 1 < p.W), y1ok = (s.y0 + 1 < p.H), z1ok = (s.z0 + 1 < p.D);
+  const int x1ok = (s.x0 + 1 < p.Wi), y1ok = (s.y0 + 1 < p.Hi), z1ok = (s.z0 + 1 < p.Di);
   const int x1 = x1ok ? s.x0 + 1 : s.x0;
   const int y1 = y1ok ? s.y0 + 1 : s.y0;
   const int z1 = z1ok ? s.z0 + 1 : s.z0;
-  const int HW = p.H * p.W;
-  const int r00 = s.z0 * HW + s.y0 * p.W, r01 = s.z0 * HW + y1 * p.W;
-  const int r10 = z1 * HW + s.y0 * p.W, r11 = z1 * HW + y1 * p.W;
+  const int HW = p.Hi * p.Wi;
+  const int r00 = s.z0 * HW + s.y0 * p.Wi, r01 = s.z0 * HW + y1 * p.Wi;
+  const int r10 = z1 * HW + s.y0 * p.Wi, r11 = z1 * HW + y1 * p.Wi;
   Corners c;
   c.v000 = vol[r00 + s.x0];
   c.v001 = vol[r00 + x1];
@@ -108,9 +117,10 @@ __device__ __forceinline__ int decode_tile(const W3P& p, int& b, int& d, int& h0
 }
 
 template <int TW>
-__global__ __launch_bounds__(NT) void warp3d_fwd_kernel(const float* __restrict__ in,
-                                                        const float* __restrict__ flow,
-                                                        float* __restrict__ out, W3P p) {
+__global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* __restrict__ flow,
+                                                        W3P p) {
+  const float* __restrict__ in = io.in[blockIdx.y];
+  float* __restrict__ out = io.out[blockIdx.y];
   constexpr int LDW = TW + 1;
   constexpr int RP = NT / TW;  // tile rows covered per pass in the w-major phases
   constexpr int NW = TW / 4;   // voxels per thread in the h-major phase
@@ -122,10 +132,11 @@ __global__ __launch_bounds__(NT) void warp3d_fwd_kernel(const float* __restrict_
   const int t = threadIdx.x;
   const int HW = p.H * p.W;
   const size_t vol = (size_t)p.D * HW;
+  const size_t ivol = (size_t)p.Di * p.Hi * p.Wi;
 
   // phase 1: flow tile, lanes on w
   {
-    const float* fb = flow + (size_t)b * 3 * vol + (size_t)d * HW;
+    const float* fb = flow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol + (size_t)d * HW;
     const int lw = t % TW, r = t / TW;
     const int w = min(w0 + lw, p.W - 1);
 #pragma unroll
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(NT) void warp3d_fwd_kernel(const float* __restrict_
   const int lane = t & 63, wv = t >> 6;
   const int h = min(h0 + lane, p.H - 1);
   for (int c = 0; c < p.C; ++c) {
-    const float* __restrict__ vin = in + ((size_t)b * p.C + c) * vol;
+    const float* __restrict__ vin = in + ((size_t)b * p.C + c) * ivol;
     // phase 2: lanes on h; each wave takes NW consecutive w of the tile
 #pragma unroll 4
     for (int k = 0; k < NW; ++k) {
@@ -183,11 +194,11 @@ __global__ __launch_bounds__(NT) void warp3d_fwd_kernel(const float* __restrict_
 }
 
 template <int TW, bool WITH_GIN>
-__global__ __launch_bounds__(NT) void warp3d_bwd_kernel(const float* __restrict__ in,
-                                                        const float* __restrict__ flow,
-                                                        const float* __restrict__ gout,
-                                                        float* __restrict__ gin,
+__global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* __restrict__ flow,
                                                         float* __restrict__ gflow, W3P p) {
+  const float* __restrict__ in = io.in[blockIdx.y];
+  const float* __restrict__ gout = io.gout[blockIdx.y];
+  float* __restrict__ gin = io.gin[blockIdx.y];
   constexpr int LDW = TW + 1;
   constexpr int RP = NT / TW;
   constexpr int NW = TW / 4;
@@ -199,10 +210,12 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(const float* __restrict_
   const int t = threadIdx.x;
   const int HW = p.H * p.W;
   const size_t vol = (size_t)p.D * HW;
+  const size_t ivol = (size_t)p.Di * p.Hi * p.Wi;
+  const int iHW = p.Hi * p.Wi;
   const int lwW = t % TW, rW = t / TW;  // w-major phase coordinates
 
   {
-    const float* fb = flow + (size_t)b * 3 * vol + (size_t)d * HW;
+    const float* fb = flow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol + (size_t)d * HW;
     const int w = min(w0 + lwW, p.W - 1);
 #pragma unroll
     for (int row = rW; row < 3 * TH; row += RP) {
@@ -232,8 +245,8 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(const float* __restrict_
       }
     }
     __syncthreads();
-    const float* __restrict__ vin = in + ((size_t)b * p.C + c) * vol;
-    float* __restrict__ gvin = WITH_GIN ? gin + ((size_t)b * p.C + c) * vol : nullptr;
+    const float* __restrict__ vin = in + ((size_t)b * p.C + c) * ivol;
+    float* __restrict__ gvin = WITH_GIN ? gin + ((size_t)b * p.C + c) * ivol : nullptr;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
       const int lw = wv * NW + k;
@@ -256,9 +269,9 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(const float* __restrict_
       acc[k][2] += g * dz * s.mz;
       if (WITH_GIN) {
         if (hq < p.H && w0 + lw < p.W) {
-          const int x1ok = (s.x0 + 1 < p.W), y1ok = (s.y0 + 1 < p.H), z1ok = (s.z0 + 1 < p.D);
-          const int r00 = s.z0 * HW + s.y0 * p.W, r01 = r00 + p.W;
-          const int r10 = r00 + HW, r11 = r10 + p.W;
+          const int x1ok = (s.x0 + 1 < p.Wi), y1ok = (s.y0 + 1 < p.Hi), z1ok = (s.z0 + 1 < p.Di);
+          const int r00 = s.z0 * iHW + s.y0 * p.Wi, r01 = r00 + p.Wi;
+          const int r10 = r00 + iHW, r11 = r10 + p.Wi;
           atomicAdd(gvin + r00 + s.x0, g * (bx * by * bz));
           if (x1ok) atomicAdd(gvin + r00 + s.x0 + 1, g * (ax * by * bz));
           if (y1ok) atomicAdd(gvin + r01 + s.x0, g * (bx * ay * bz));
@@ -277,9 +290,9 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(const float* __restrict_
   if (gflow == nullptr) return;
   // chain rule through unnormalize ((size-1)/2) and through flow/((dim-1)/2):
   //   F0 -> gx (H-normalised) -> ix (W),  F1 -> gy (D) -> iy (H),  F2 -> gz (W) -> iz (D)
-  const float k0 = ((float)(p.W - 1) * 0.5f) / p.sH;
-  const float k1 = ((float)(p.H - 1) * 0.5f) / p.sD;
-  const float k2 = ((float)(p.D - 1) * 0.5f) / p.sW;
+  const float k0 = ((float)(p.Wi - 1) * 0.5f) / p.sH;
+  const float k1 = ((float)(p.Hi - 1) * 0.5f) / p.sD;
+  const float k2 = ((float)(p.Di - 1) * 0.5f) / p.sW;
 #pragma unroll
   for (int k = 0; k < NW; ++k) {
     const int lw = wv * NW + k;  // own slots: nobody else reads or writes them
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(const float* __restrict_
   }
   __syncthreads();
   {
-    float* gb = gflow + (size_t)b * 3 * vol + (size_t)d * HW;
+    float* gb = gflow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol + (size_t)d * HW;
     const int w = w0 + lwW;
 #pragma unroll
     for (int row = rW; row < 3 * TH; row += RP) {
@@ -300,10 +313,13 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(const float* __restrict_
   }
 }
 
-int make_params(W3P& p, int B, int C, int D, int H, int W, int TW) {
-  if (B < 1 || C < 1 || D < 2 || H < 2 || W < 2) return FS_ERR_SHAPE;
-  if ((long long)D * H * W >= (1ll << 31)) return FS_ERR_SHAPE;
+int make_params(W3P& p, int B, int C, const int* in_dhw, int D, int H, int W, int TW) {
+  const int Di = in_dhw ? in_dhw[0] : D, Hi = in_dhw ? in_dhw[1] : H, Wi = in_dhw ? in_dhw[2] : W;
+  if (B < 1 || C < 1 || D < 2 || H < 2 || W < 2 || Di < 2 || Hi < 2 || Wi < 2) return FS_ERR_SHAPE;
+  if ((long long)D * H * W >= (1ll << 31) || (long long)Di * Hi * Wi >= (1ll << 31))
+    return FS_ERR_SHAPE;
   p.B = B; p.C = C; p.D = D; p.H = H; p.W = W;
+  p.Di = Di; p.Hi = Hi; p.Wi = Wi;
   p.tilesH = fs::cdiv(H, TH);
   p.tilesW = fs::cdiv(W, TW);
   if ((long long)B * D * p.tilesH * p.tilesW >= (1ll << 31)) return FS_ERR_SHAPE;
@@ -311,45 +327,85 @@ int make_params(W3P& p, int B, int C, int D, int H, int W, int TW) {
   p.stepD = 2.0f / (float)(D - 1);
   p.stepH = 2.0f / (float)(H - 1);
   p.stepW = 2.0f / (float)(W - 1);
-  p.sD = ((float)D - 1.0f) / 2.0f;
-  p.sH = ((float)H - 1.0f) / 2.0f;
-  p.sW = ((float)W - 1.0f) / 2.0f;
+  p.sD = ((float)Di - 1.0f) / 2.0f;
+  p.sH = ((float)Hi - 1.0f) / 2.0f;
+  p.sW = ((float)Wi - 1.0f) / 2.0f;
   return FS_OK;
 }
 
 constexpr int kTW = 32;
 
-}  // namespace
 
-extern "C" int fs_warp3d_fwd(const float* in, const float* flow, float* out, int B, int C, int D,
-                             int H, int W, fs_stream_t stream) {
-  FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(out);
-  W3P p;
-  const int rc = make_params(p, B, C, D, H, W, kTW);
-  if (rc != FS_OK) return rc;
-  const unsigned grid = (unsigned)((long long)B * D * p.tilesH * p.tilesW);
-  hipLaunchKernelGGL(warp3d_fwd_kernel<kTW>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, flow,
-                     out, p);
+int launch_fwd(const W3Fwd& io, int npair, const float* flow, W3P& p, fs_stream_t stream) {
+  const unsigned grid = (unsigned)((long long)p.B * p.D * p.tilesH * p.tilesW);
+  p.flowC = 3 * npair;
+  hipLaunchKernelGGL(warp3d_fwd_kernel<kTW>, dim3(grid, npair), dim3(NT), 0, (hipStream_t)stream, io,
+                     flow, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
+int launch_bwd(const W3Bwd& io, int npair, bool with_gin, const float* flow, float* gflow, W3P& p,
+               fs_stream_t stream) {
+  const unsigned grid = (unsigned)((long long)p.B * p.D * p.tilesH * p.tilesW);
+  p.flowC = 3 * npair;
+  if (with_gin)
+    hipLaunchKernelGGL((warp3d_bwd_kernel<kTW, true>), dim3(grid, npair), dim3(NT), 0,
+                       (hipStream_t)stream, io, flow, gflow, p);
+  else
+    hipLaunchKernelGGL((warp3d_bwd_kernel<kTW, false>), dim3(grid, npair), dim3(NT), 0,
+                       (hipStream_t)stream, io, flow, gflow, p);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+}  // namespace
+
+extern "C" int fs_warp3d_fwd(const float* in, const float* flow, float* out, int B, int C,
+                             const int* in_dhw, int D, int H, int W, fs_stream_t stream) {
+  FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(out);
+  W3P p;
+  const int rc = make_params(p, B, C, in_dhw, D, H, W, kTW);
+  if (rc != FS_OK) return rc;
+  W3Fwd io = {{in, nullptr}, {out, nullptr}};
+  return launch_fwd(io, 1, flow, p, stream);
+}
+
 extern "C" int fs_warp3d_bwd(const float* in, const float* flow, const float* grad_out,
-                             float* grad_in, float* grad_flow, int B, int C, int D, int H, int W,
-                             fs_stream_t stream) {
+                             float* grad_in, float* grad_flow, int B, int C, const int* in_dhw,
+                             int D, int H, int W, fs_stream_t stream) {
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(grad_out);
   if (grad_in == nullptr && grad_flow == nullptr) return FS_ERR_NULLPTR;
   W3P p;
-  const int rc = make_params(p, B, C, D, H, W, kTW);
+  const int rc = make_params(p, B, C, in_dhw, D, H, W, kTW);
   if (rc != FS_OK) return rc;
-  const unsigned grid = (unsigned)((long long)B * D * p.tilesH * p.tilesW);
-  if (grad_in != nullptr) {
-    hipLaunchKernelGGL((warp3d_bwd_kernel<kTW, true>), dim3(grid), dim3(NT), 0, (hipStream_t)stream,
-                       in, flow, grad_out, grad_in, grad_flow, p);
-  } else {
-    hipLaunchKernelGGL((warp3d_bwd_kernel<kTW, false>), dim3(grid), dim3(NT), 0,
-                       (hipStream_t)stream, in, flow, grad_out, grad_in, grad_flow, p);
-  }
-  FS_LAUNCH_CHECK();
-  return FS_OK;
+  W3Bwd io = {{in, nullptr}, {grad_out, nullptr}, {grad_in, nullptr}};
+  return launch_bwd(io, 1, grad_in != nullptr, flow, grad_flow, p, stream);
+}
+
+extern "C" int fs_warp3d_pair_fwd(const float* img0, const float* img1, const float* flow6,
+                                  float* out0, float* out1, int B, int C, const int* in_dhw,
+                                  int D, int H, int W, fs_stream_t stream) {
+  FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow6);
+  FS_REQUIRE_PTR(out0); FS_REQUIRE_PTR(out1);
+  W3P p;
+  const int rc = make_params(p, B, C, in_dhw, D, H, W, kTW);
+  if (rc != FS_OK) return rc;
+  W3Fwd io = {{img0, img1}, {out0, out1}};
+  return launch_fwd(io, 2, flow6, p, stream);
+}
+
+extern "C" int fs_warp3d_pair_bwd(const float* img0, const float* img1, const float* flow6,
+                                  const float* grad_out0, const float* grad_out1, float* grad_img0,
+                                  float* grad_img1, float* grad_flow6, int B, int C,
+                                  const int* in_dhw, int D, int H, int W, fs_stream_t stream) {
+  FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow6);
+  FS_REQUIRE_PTR(grad_out0); FS_REQUIRE_PTR(grad_out1);
+  if ((grad_img0 == nullptr) != (grad_img1 == nullptr)) return FS_ERR_NULLPTR;  // both or neither
+  if (grad_img0 == nullptr && grad_flow6 == nullptr) return FS_ERR_NULLPTR;
+  W3P p;
+  const int rc = make_params(p, B, C, in_dhw, D, H, W, kTW);
+  if (rc != FS_OK) return rc;
+  W3Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
+  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6, p, stream);
 }

@@ -1,0 +1,166 @@
+"""RIFE-style IFNet for 2-D frames and 3-D volumes, built around the HIP warp kernels.
+
+Mirrors Flow-2D/model/IFNet.py:34-335 and Flow-3D/model/IFNet.py:31-280 (one dimension-generic
+implementation instead of two copies).  The module tree (block0/block1/block2/block_tea, and
+conv0/convblock0..3/conv1/conv2 inside each block) and the construction order are the
+reference's, so `state_dict()` keys match reference checkpoints and `torch.manual_seed(s)`
+followed by construction yields the reference's initial weights.
+
+The convolutions stay `torch.nn` (MIOpen); the per-frame-pair hot path -- the two backward warps
+per block -- is `ops.warp_pair`, one HIP launch on the 4/6-channel flow in place.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+_CONV = {2: nn.Conv2d, 3: nn.Conv3d}
+_DECONV = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
+_INTERP = {2: "bilinear", 3: "trilinear"}
+
+
+def _conv(nd, cin, cout, kernel_size=3, stride=1, padding=1):
+    return nn.Sequential(_CONV[nd](cin, cout, kernel_size, stride, padding, bias=True),
+                         nn.PReLU(cout))
+
+
+def _head(nd, c, cout):
+    return nn.Sequential(_DECONV[nd](c, c // 2, 4, 2, 1), nn.PReLU(c // 2),
+                         _DECONV[nd](c // 2, cout, 4, 2, 1))
+
+
+def _resize(t, factor, mode):
+    if factor == 1:
+        # scale_factor=1 with align_corners=False reproduces its input exactly (source index ==
+        # destination index, weights (1, 0)); the reference still launches it.  Skip the pass.
+        return t
+    return F.interpolate(t, scale_factor=factor, mode=mode, align_corners=False,
+                         recompute_scale_factor=False)
+
+
+def _min_spatial(a, b):
+    return tuple(min(x, y) for x, y in zip(a.shape[2:], b.shape[2:]))
+
+
+def _crop(t, spatial):
+    if tuple(t.shape[2:]) == tuple(spatial):
+        return t
+    return t[(slice(None), slice(None)) + tuple(slice(0, s) for s in spatial)]
+
+
+class IFBlock(nn.Module):
+    """Flow-2D/model/IFNet.py:34-122 (conv0 kernel 3) / Flow-3D/model/IFNet.py:31-120 (kernel 4)."""
+
+    def __init__(self, nd, in_planes, c=64):
+        super().__init__()
+        self.nd = nd
+        k0 = 3 if nd == 2 else 4
+        self.conv0 = nn.Sequential(_conv(nd, in_planes, c // 2, k0, 2, 1),
+                                   _conv(nd, c // 2, c, k0, 2, 1))
+        self.convblock0 = nn.Sequential(_conv(nd, c, c), _conv(nd, c, c))
+        self.convblock1 = nn.Sequential(_conv(nd, c, c), _conv(nd, c, c))
+        self.convblock2 = nn.Sequential(_conv(nd, c, c), _conv(nd, c, c))
+        self.convblock3 = nn.Sequential(_conv(nd, c, c), _conv(nd, c, c))
+        self.conv1 = _head(nd, c, 2 * nd)  # flow: 4 (2-D) or 6 (3-D) channels
+        self.conv2 = _head(nd, c, 1)       # blend-mask logit
+
+    def forward(self, x, flow, scale):
+        mode = _INTERP[self.nd]
+        if scale != 1:
+            x = F.interpolate(x, scale_factor=1. / scale, mode=mode, align_corners=False)
+        if flow is not None:
+            if scale != 1:
+                flow = F.interpolate(flow, scale_factor=1. / scale, mode=mode,
+                                     align_corners=False) * 1. / scale
+            x = torch.cat((x, flow), 1)
+        x = self.conv0(x)
+        x = self.convblock0(x) + x
+        x = self.convblock1(x) + x
+        x = self.convblock2(x) + x
+        x = self.convblock3(x) + x
+        flow = self.conv1(x)
+        mask = self.conv2(x)
+        if scale != 1:
+            flow = _resize(flow, scale, mode) * scale
+            mask = _resize(mask, scale, mode)
+        return flow, mask
+
+
+class IFNet(nn.Module):
+    """Three student blocks (scales 4, 2, 1) + a teacher that also sees the ground-truth middle
+    frame.  Flow-2D/model/IFNet.py:124-335, Flow-3D/model/IFNet.py:122-280."""
+
+    def __init__(self, nd):
+        super().__init__()
+        assert nd in (2, 3)
+        self.nd = nd
+        fc = 2 * nd
+        c1 = 96 if nd == 2 else 64
+        self.block0 = IFBlock(nd, 2, c=128)
+        self.block1 = IFBlock(nd, 5 + fc, c=c1)
+        self.block2 = IFBlock(nd, 5 + fc, c=64)
+        self.block_tea = IFBlock(nd, 6 + fc, c=64)
+
+    def forward(self, x, scale=(4, 2, 1), timestep=0.5):
+        img0, img1 = x[:, :1], x[:, 1:2]
+        gt = x[:, 2:3] if self.nd == 2 else x[:, 2:]  # empty at inference time
+        flow_list, merged, mask_list = [], [], []
+        warped_img0, warped_img1 = img0, img1
+        flow = mask = None
+        loss_distill = 0
+        stu = [self.block0, self.block1, self.block2]
+        for i in range(3):
+            if flow is not None:
+                # the reference crops everything to the common extent (sizes that are not
+                # multiples of 16 make block outputs and inputs differ)
+                sp = _min_spatial(img0, warped_img0)
+                img0, img1 = _crop(img0, sp), _crop(img1, sp)
+                warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
+                mask, flow = _crop(mask, sp), _crop(flow, sp)
+                flow_d, mask_d = stu[i](torch.cat((img0, img1, warped_img0, warped_img1, mask), 1),
+                                        flow, scale=scale[i])
+                flow = flow + _crop(flow_d, img0.shape[2:])
+                mask = mask + _crop(mask_d, img0.shape[2:])
+            else:
+                flow, mask = stu[i](torch.cat((img0, img1), 1), None, scale=scale[i])
+            if self.nd == 2:
+                flow, mask = _crop(flow, img0.shape[2:]), _crop(mask, img0.shape[2:])
+            sp = _min_spatial(img0, warped_img0)
+            if self.nd == 3:
+                flow, mask = _crop(flow, sp), _crop(mask, sp)
+            img0, img1 = _crop(img0, sp), _crop(img1, sp)
+            mask_list.append(torch.sigmoid(mask))
+            flow_list.append(flow)
+            # hot path: both backward warps of this block in one HIP launch
+            warped_img0, warped_img1 = ops.warp_pair(img0, img1, flow)
+            merged.append((warped_img0, warped_img1))
+
+        if gt.shape[1] == 1:
+            sp = _min_spatial(img0, warped_img0)
+            img0, img1 = _crop(img0, sp), _crop(img1, sp)
+            warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
+            mask, flow, gt = _crop(mask, sp), _crop(flow, sp), _crop(gt, sp)
+            flow_d, mask_d = self.block_tea(
+                torch.cat((img0, img1, warped_img0, warped_img1, mask, gt), 1), flow, scale=1)
+            flow_teacher = flow + _crop(flow_d, sp)
+            w0t, w1t = ops.warp_pair(img0, img1, flow_teacher)
+            mask_teacher = torch.sigmoid(mask + _crop(mask_d, sp))
+            merged_teacher = w0t * mask_teacher + w1t * (1 - mask_teacher)
+        else:
+            flow_teacher = None
+            merged_teacher = None
+
+        for i in range(3):
+            m = merged[i][0] * mask_list[i] + merged[i][1] * (1 - mask_list[i])
+            merged[i] = _crop(m, _min_spatial(m, gt))
+            if gt.shape[1] == 1:
+                flow_list[i] = _crop(flow_list[i], flow_teacher.shape[2:])
+                loss_mask = ((merged[i] - gt).abs().mean(1, True) >
+                             (merged_teacher - gt).abs().mean(1, True) + 0.01).float().detach()
+                loss_distill = loss_distill + (
+                    ((flow_teacher.detach() - flow_list[i]) ** 2).mean(1, True) ** 0.5 * loss_mask
+                ).mean()
+        # Flow-2D returns every block's mask (IFNet.py:276), Flow-3D the last one (IFNet.py:280)
+        masks = mask_list if self.nd == 2 else mask_list[2]
+        return flow_list, masks, merged, flow_teacher, merged_teacher, loss_distill

@@ -1,0 +1,230 @@
+"""RIFE `Model` wrapper (optimiser, DDP, update / inference, checkpoints) shared by the Flow-2D
+and Flow-3D entry points.  Mirrors Flow-2D/model/RIFE.py:19-336 and Flow-3D/model/RIFE.py:18-275.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch.nn.parallel import DistributedDataParallel as DDP
+from torch.optim import AdamW
+
+from . import ops
+from .ifnet import IFNet
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("opticalflowscivis_amd needs a ROCm GPU: the HIP hot path has no CPU "
+                           "fallback (the reference hard-codes torch.device('cuda') as well, "
+                           "Flow-3D/model/RIFE.py:16)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class ModelBase:
+    nd = None
+
+    def __init__(self, local_rank=-1, arbitrary=False, device=None):
+        if arbitrary:
+            raise NotImplementedError("IFNet_m (arbitrary-timestep variant) is legacy upstream code "
+                                      "not reached by train.py; out of scope (SURVEY §2 #18)")
+        self.dev = torch.device(device) if device is not None else default_device()
+        self.flownet = IFNet(self.nd)
+        self.device()
+        # large weight decay "may avoid NaN loss" (RIFE.py:28)
+        self.optimG = AdamW(self.flownet.parameters(), lr=1e-6, weight_decay=1e-3)
+        if local_rank != -1:
+            self.flownet = DDP(self.flownet, device_ids=[local_rank], output_device=local_rank)
+
+    def train(self):
+        self.flownet.train()
+
+    def eval(self):
+        self.flownet.eval()
+
+    def device(self):
+        self.flownet.to(self.dev)
+
+    # ---- checkpoints: the reference saves the (DDP-wrapped) state_dict, so its keys carry a
+    # "module." prefix and load_model keeps only such keys (RIFE.py:44-58).  Accept both forms.
+    def load_model(self, model_name, path, rank=0):
+        if rank > 0:
+            return
+        sd = torch.load('{}/{}'.format(path, model_name), map_location=self.dev)
+        wrapped = isinstance(self.flownet, DDP)
+        fixed = {}
+        for k, v in sd.items():
+            has = k.startswith("module.")
+            if wrapped and not has:
+                k = "module." + k
+            elif not wrapped and has:
+                k = k[len("module."):]
+            fixed[k] = v
+        self.flownet.load_state_dict(fixed)
+
+    def save_model(self, model_name, path, rank=0):
+        if rank == 0:
+            torch.save(self.flownet.state_dict(), '{}/{}'.format(path, model_name))
+
+    def _set_lr(self, learning_rate):
+        for g in self.optimG.param_groups:
+            g['lr'] = learning_rate
+
+
+class Model3D(ModelBase):
+    """Flow-3D/model/RIFE.py:18-275."""
+    nd = 3
+
+    def inference(self, img0, img1, scale_list=(4, 2, 1), TTA=False, timestep=0.5):
+        imgs = torch.cat((img0, img1), 1)
+        flow, mask, merged, _, _, _ = self.flownet(imgs, scale_list, timestep=timestep)
+        if TTA:
+            raise NotImplementedError("TTA is 'not implemented' in the reference too (RIFE.py:76)")
+        return merged[2], flow, mask
+
+    def update(self, imgs, gt, learning_rate=0, mul=1, training=True, flow_gt=None):
+        self._set_lr(learning_rate)
+        if training:
+            self.train()
+        else:
+            self.eval()
+        flow, mask, merged, flow_teacher, merged_teacher, loss_distill = self.flownet(
+            torch.cat((imgs, gt), 1), scale=[4, 2, 1])
+        sp = tuple(min(a, b) for a, b in zip(imgs.shape[2:], mask.shape[2:]))
+        gt = gt[(slice(None), slice(None)) + tuple(slice(0, s) for s in sp)]
+        loss_l1 = F.l1_loss(merged[2], gt)            # RIFE.py:132
+        loss_tea = F.l1_loss(merged_teacher, gt)      # RIFE.py:134
+        # RIFE.py:141-143 also sums an L1 norm of all parameters that never reaches loss_G
+        # (lambda_reg = 0 and the term is commented out of :158); it is not computed here.
+        loss_G = loss_l1 * 1 + loss_tea * 1 + loss_distill * 0.1  # RIFE.py:151-158
+        if training:
+            self.optimG.zero_grad()
+            loss_G.backward()
+            self.optimG.step()
+        else:
+            flow_teacher = flow[2]
+            merged_teacher = merged[2]
+        return merged[2], {
+            'merged_tea': merged_teacher, 'mask': mask, 'mask_tea': mask, 'flow': flow[2],
+            'flow_tea': flow_teacher, 'loss_l1': loss_l1, 'loss_tea': loss_tea,
+            'loss_distill': loss_distill, 'loss_G': loss_G,
+        }
+
+
+# ---- Laplacian pyramid loss of Flow-2D (Flow-2D/model/laplacian.py:10-88): stock PyTorch ops;
+# it is the reference's dominant 2-D loss term but not on the named hot path.
+def _gauss_kernel(channels, device):
+    k = torch.tensor([[1., 4., 6., 4., 1.], [4., 16., 24., 16., 4.], [6., 24., 36., 24., 6.],
+                      [4., 16., 24., 16., 4.], [1., 4., 6., 4., 1.]], device=device) / 256.
+    return k.repeat(channels, 1, 1, 1)
+
+
+def _conv_gauss(img, kernel):
+    return F.conv2d(F.pad(img, (2, 2, 2, 2), mode='reflect'), kernel, groups=img.shape[1])
+
+
+def _lap_upsample(x, kernel):
+    # zero-interleave to twice the size, then 4 * gauss (laplacian.py:24-31)
+    B, C, H, W = x.shape
+    up = x.new_zeros(B, C, 2 * H, 2 * W)
+    up[:, :, ::2, ::2] = x
+    return _conv_gauss(up, 4 * kernel)
+
+
+def _laplacian_pyramid(img, kernel, max_levels):
+    current, pyr = img, []
+    for _ in range(max_levels):
+        down = _conv_gauss(current, kernel)[:, :, ::2, ::2]
+        up = _lap_upsample(down, kernel)
+        h, w = min(current.shape[2], up.shape[2]), min(current.shape[3], up.shape[3])
+        pyr.append(current[:, :, :h, :w] - up[:, :, :h, :w])
+        current = down
+    return pyr
+
+
+class LapLoss(torch.nn.Module):
+    def __init__(self, max_levels=5, channels=1):
+        super().__init__()
+        self.max_levels, self.channels = max_levels, channels
+
+    def forward(self, input, target):
+        k = _gauss_kernel(self.channels, input.device)
+        a = _laplacian_pyramid(input, k, self.max_levels)
+        b = _laplacian_pyramid(target, k, self.max_levels)
+        return sum(F.l1_loss(x, y) for x, y in zip(a, b))
+
+
+_FLOW_GT_DATASETS = ("pipedcylinder2d", "cylinder2d", "FluidSimML2d", "rectangle2d", "lbs2d")
+
+
+class Model2D(ModelBase):
+    """Flow-2D/model/RIFE.py:19-336."""
+    nd = 2
+
+    def __init__(self, local_rank=-1, arbitrary=False, device=None):
+        super().__init__(local_rank, arbitrary, device)
+        self.lap = LapLoss()
+
+    def inference(self, img0, img1, scale_list=(4, 2, 1), TTA=False, timestep=0.5):
+        imgs = torch.cat((img0, img1), 1)
+        flow, mask, merged, _, _, _ = self.flownet(imgs, scale_list, timestep=timestep)
+        if not TTA:
+            return merged, flow, mask  # all three frames (RIFE.py:75)
+        flow2, mask2, merged2, _, _, _ = self.flownet(imgs.flip(2).flip(3), scale_list,
+                                                      timestep=timestep)
+        return (merged[2] + merged2[2].flip(2).flip(3)) / 2
+
+    def update(self, imgs, gt, dataset, learning_rate=0, mul=1, training=True, flow_gt=None):
+        self._set_lr(learning_rate)
+        gt_flow = None
+        if dataset in _FLOW_GT_DATASETS:  # these loaders pack (data, u, v) per frame (RIFE.py:90-105)
+            gt_flow = gt[:, 0, 1:3]
+            img0, img1 = imgs[:, 0, :1], imgs[:, 1, :1]
+            imgs = torch.cat((img0, img1), 1)
+            gt = gt[:, 0, :1]
+        else:
+            img0, img1 = imgs[:, :1], imgs[:, 1:2]
+        if training:
+            self.train()
+        else:
+            self.eval()
+        flow, mask, merged, flow_teacher, merged_teacher, loss_distill = self.flownet(
+            torch.cat((imgs, gt), 1), scale=[4, 2, 1])
+        mask = mask[2]
+        h, w = min(img0.shape[2], mask.shape[2]), min(img0.shape[3], mask.shape[3])
+        gt = gt[:, :, :h, :w]
+        loss_flow = torch.tensor(0.)
+        if gt_flow is not None:  # RIFE.py:134-146
+            gt_flow = gt_flow[:, :, :h, :w]
+            loss_flow = sum(F.l1_loss(f[:, 2:4], gt_flow) + F.l1_loss(f[:, :2], -gt_flow)
+                            for f in (flow[0], flow[1], flow[2], flow_teacher)) / 8.
+        loss_l1 = self.lap(merged[2], gt).mean()          # RIFE.py:148
+        loss_tea = self.lap(merged_teacher, gt).mean()    # RIFE.py:152
+        # L1 "regulariser" over block2/block_tea read from state_dict(): detached, so it shifts
+        # loss_G but contributes no gradient (RIFE.py:177-188)
+        with torch.no_grad():
+            l1_reg = sum(p.abs().sum() for n, p in self.flownet.state_dict().items()
+                         if "block2" in n or "block_tea" in n)
+        # hot path a11: two half-pixel-shifted backward warps of merged[2] + Charbonnier
+        loss_photo = ops.rife2d_photometric(flow[2], merged[2], img0, img1)  # RIFE.py:274-279
+        lambda_l1, lambda_tea, lambda_distill = 1, 1, 0.01  # RIFE.py:283-289
+        lambda_reg, lambda_photo, lambda_flow = 1e-6, 1e-5, 0
+        if math.isnan(float(loss_distill)) or float(loss_distill) > 10.:  # RIFE.py:295-296
+            loss_distill = torch.tensor(0.)
+        if dataset in ("droplet2d", "vimeo2d"):
+            loss_flow = torch.tensor(0.)
+        loss_G = loss_l1 * lambda_l1 + loss_tea * lambda_tea + loss_distill * lambda_distill + \
+            l1_reg * lambda_reg + loss_photo * lambda_photo + loss_flow * lambda_flow
+        if training:
+            self.optimG.zero_grad()
+            loss_G.backward()
+            self.optimG.step()
+        else:
+            flow_teacher = flow[2]
+            merged_teacher = merged[2]
+        return merged[2], {
+            'merged_tea': merged_teacher, 'mask': mask, 'mask_tea': mask, 'flow': flow[2][:, :2],
+            'flow_tea': flow_teacher, 'loss_l1': loss_l1 * lambda_l1, 'loss_tea': loss_tea * lambda_tea,
+            'loss_distill': loss_distill * lambda_distill, 'l1_reg': l1_reg * lambda_reg,
+            'loss_photo': loss_photo * lambda_photo, 'loss_flow': loss_flow * lambda_flow,
+            'loss_G': loss_G,
+        }

@@ -1,0 +1,220 @@
+"""Oracle (TEST INFRASTRUCTURE): the reference's IFNet + RIFE Model.update on CPU PyTorch fp32.
+
+A dimension-generic restatement of Flow-2D/model/{IFNet,RIFE,laplacian}.py and
+Flow-3D/model/{IFNet,RIFE}.py with the reference's own ATen calls (grid_sample, interpolate at
+every scale including 1, the unused L1-norm pass), i.e. what the reference's CPU path executes.
+Same module tree and construction order as the reference, so a seed reproduces its weights and
+state_dicts are interchangeable with the product model (opticalflowscivis_amd.ifnet).
+Pinned by tests/golden/flow{2,3}d_e2e.npz (losses / outputs of the real reference).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.optim import AdamW
+
+from . import losses as olosses
+from . import warps as owarps
+
+
+def _conv(nd, cin, cout, k=3, s=1, p=1):
+    Conv = nn.Conv2d if nd == 2 else nn.Conv3d
+    return nn.Sequential(Conv(cin, cout, kernel_size=k, stride=s, padding=p, bias=True), nn.PReLU(cout))
+
+
+class IFBlockRef(nn.Module):
+    def __init__(self, nd, in_planes, c=64):
+        super().__init__()
+        self.nd = nd
+        De = nn.ConvTranspose2d if nd == 2 else nn.ConvTranspose3d
+        k0 = 3 if nd == 2 else 4  # Flow-2D IFNet.py:37-40 vs Flow-3D IFNet.py:35-38
+        self.conv0 = nn.Sequential(_conv(nd, in_planes, c // 2, k0, 2, 1), _conv(nd, c // 2, c, k0, 2, 1))
+        self.convblock0 = nn.Sequential(_conv(nd, c, c), _conv(nd, c, c))
+        self.convblock1 = nn.Sequential(_conv(nd, c, c), _conv(nd, c, c))
+        self.convblock2 = nn.Sequential(_conv(nd, c, c), _conv(nd, c, c))
+        self.convblock3 = nn.Sequential(_conv(nd, c, c), _conv(nd, c, c))
+        self.conv1 = nn.Sequential(De(c, c // 2, 4, 2, 1), nn.PReLU(c // 2), De(c // 2, 2 * nd, 4, 2, 1))
+        self.conv2 = nn.Sequential(De(c, c // 2, 4, 2, 1), nn.PReLU(c // 2), De(c // 2, 1, 4, 2, 1))
+
+    def forward(self, x, flow, scale):
+        mode = "bilinear" if self.nd == 2 else "trilinear"
+        if scale != 1:
+            x = F.interpolate(x, scale_factor=1. / scale, mode=mode, align_corners=False)
+        if flow is not None:
+            flow = F.interpolate(flow, scale_factor=1. / scale, mode=mode, align_corners=False) * 1. / scale
+            x = torch.cat((x, flow), 1)
+        x = self.conv0(x)
+        x = self.convblock0(x) + x
+        x = self.convblock1(x) + x
+        x = self.convblock2(x) + x
+        x = self.convblock3(x) + x
+        flow = self.conv1(x)
+        mask = self.conv2(x)
+        flow = F.interpolate(flow, scale_factor=scale, mode=mode, align_corners=False,
+                             recompute_scale_factor=False) * scale
+        mask = F.interpolate(mask, scale_factor=scale, mode=mode, align_corners=False,
+                             recompute_scale_factor=False)
+        return flow, mask
+
+
+def _cut(t, ref_spatial):
+    return t[(slice(None), slice(None)) + tuple(slice(0, s) for s in ref_spatial)]
+
+
+def _mins(a, b):
+    return tuple(min(x, y) for x, y in zip(a.shape[2:], b.shape[2:]))
+
+
+class IFNetRef(nn.Module):
+    def __init__(self, nd):
+        super().__init__()
+        self.nd = nd
+        fc = 2 * nd
+        self.block0 = IFBlockRef(nd, 2, c=128)
+        self.block1 = IFBlockRef(nd, 5 + fc, c=96 if nd == 2 else 64)
+        self.block2 = IFBlockRef(nd, 5 + fc, c=64)
+        self.block_tea = IFBlockRef(nd, 6 + fc, c=64)
+
+    def _warp(self, img, flow):
+        return owarps.warp2d_rife_ref(img, flow) if self.nd == 2 else owarps.warp3d_ref(img, flow)
+
+    def forward(self, x, scale=(4, 2, 1), timestep=0.5):
+        nd = self.nd
+        img0, img1 = x[:, :1], x[:, 1:2]
+        gt = x[:, 2:3] if nd == 2 else x[:, 2:]
+        flow_list, merged, mask_list = [], [], []
+        warped_img0, warped_img1 = img0, img1
+        flow = mask = None
+        loss_distill = 0
+        stu = [self.block0, self.block1, self.block2]
+        for i in range(3):
+            if flow is not None:
+                sp = _mins(img0, warped_img0)
+                img0, img1 = _cut(img0, sp), _cut(img1, sp)
+                warped_img0, warped_img1 = _cut(warped_img0, sp), _cut(warped_img1, sp)
+                mask, flow = _cut(mask, sp), _cut(flow, sp)
+                flow_d, mask_d = stu[i](torch.cat((img0, img1, warped_img0, warped_img1, mask), 1), flow,
+                                        scale=scale[i])
+                flow = flow + _cut(flow_d, img0.shape[2:])
+                mask = mask + _cut(mask_d, img0.shape[2:])
+            else:
+                flow, mask = stu[i](torch.cat((img0, img1), 1), None, scale=scale[i])
+            if nd == 2:
+                flow, mask = _cut(flow, img0.shape[2:]), _cut(mask, img0.shape[2:])
+            sp = _mins(img0, warped_img0)
+            if nd == 3:
+                flow, mask = _cut(flow, sp), _cut(mask, sp)
+            img0, img1 = _cut(img0, sp), _cut(img1, sp)
+            mask_list.append(torch.sigmoid(mask))
+            flow_list.append(flow)
+            warped_img0 = self._warp(img0, flow[:, :nd])
+            warped_img1 = self._warp(img1, flow[:, nd:2 * nd])
+            merged.append((warped_img0, warped_img1))
+        if gt.shape[1] == 1:
+            sp = _mins(img0, warped_img0)
+            img0, img1 = _cut(img0, sp), _cut(img1, sp)
+            warped_img0, warped_img1 = _cut(warped_img0, sp), _cut(warped_img1, sp)
+            mask, flow, gt = _cut(mask, sp), _cut(flow, sp), _cut(gt, sp)
+            flow_d, mask_d = self.block_tea(torch.cat((img0, img1, warped_img0, warped_img1, mask, gt), 1),
+                                            flow, scale=1)
+            flow_teacher = flow + _cut(flow_d, sp)
+            w0t = self._warp(img0, flow_teacher[:, :nd])
+            w1t = self._warp(img1, flow_teacher[:, nd:2 * nd])
+            mask_teacher = torch.sigmoid(mask + _cut(mask_d, sp))
+            merged_teacher = w0t * mask_teacher + w1t * (1 - mask_teacher)
+        else:
+            flow_teacher = merged_teacher = None
+        for i in range(3):
+            merged[i] = merged[i][0] * mask_list[i] + merged[i][1] * (1 - mask_list[i])
+            merged[i] = _cut(merged[i], _mins(merged[i], gt))
+            if gt.shape[1] == 1:
+                flow_list[i] = _cut(flow_list[i], flow_teacher.shape[2:])
+                loss_distill = loss_distill + olosses.distill_term(merged[i], merged_teacher, gt,
+                                                                   flow_list[i], flow_teacher)
+        return flow_list, (mask_list if nd == 2 else mask_list[2]), merged, flow_teacher, merged_teacher, \
+            loss_distill
+
+
+# ---- Flow-2D/model/laplacian.py:10-88 --------------------------------------------------------
+def _gauss(channels):
+    k = torch.tensor([[1., 4., 6., 4., 1], [4., 16., 24., 16., 4.], [6., 24., 36., 24., 6.],
+                      [4., 16., 24., 16., 4.], [1., 4., 6., 4., 1.]]) / 256.
+    return k.repeat(channels, 1, 1, 1)
+
+
+def _conv_gauss(img, kernel):
+    return F.conv2d(F.pad(img, (2, 2, 2, 2), mode='reflect'), kernel, groups=img.shape[1])
+
+
+def _upsample(x):
+    # laplacian.py:24-31: interleave zeros via cat/view/permute, then 4 * gauss
+    cc = torch.cat([x, torch.zeros_like(x)], dim=3)
+    cc = cc.view(x.shape[0], x.shape[1], x.shape[2] * 2, x.shape[3]).permute(0, 1, 3, 2)
+    cc = torch.cat([cc, torch.zeros(x.shape[0], x.shape[1], x.shape[3], x.shape[2] * 2)], dim=3)
+    cc = cc.view(x.shape[0], x.shape[1], x.shape[3] * 2, x.shape[2] * 2)
+    return _conv_gauss(cc.permute(0, 1, 3, 2), 4 * _gauss(x.shape[1]))
+
+
+def lap_loss(inp, target, max_levels=5):
+    def pyramid(img):
+        cur, pyr = img, []
+        for _ in range(max_levels):
+            down = _conv_gauss(cur, _gauss(img.shape[1]))[:, :, ::2, ::2]
+            up = _upsample(down)
+            h, w = min(cur.shape[2], up.shape[2]), min(cur.shape[3], up.shape[3])
+            pyr.append(cur[:, :, :h, :w] - up[:, :, :h, :w])
+            cur = down
+        return pyr
+    return sum(F.l1_loss(a, b) for a, b in zip(pyramid(inp), pyramid(target)))
+
+
+class ModelRef:
+    """RIFE.Model on CPU (no DDP).  nd=3: Flow-3D/model/RIFE.py:81-275; nd=2: Flow-2D :80-336
+    for the datasets without packed flow ground truth (droplet2d, vimeo2d)."""
+
+    def __init__(self, nd):
+        self.nd = nd
+        self.flownet = IFNetRef(nd)
+        self.optimG = AdamW(self.flownet.parameters(), lr=1e-6, weight_decay=1e-3)
+
+    def inference(self, img0, img1, scale_list=(4, 2, 1)):
+        flow, mask, merged, _, _, _ = self.flownet(torch.cat((img0, img1), 1), scale_list)
+        return (merged[2] if self.nd == 3 else merged), flow, mask
+
+    def update(self, imgs, gt, learning_rate=0, training=True):
+        for g in self.optimG.param_groups:
+            g['lr'] = learning_rate
+        self.flownet.train(training)
+        img0, img1 = imgs[:, :1], imgs[:, 1:2]
+        flow, mask, merged, flow_teacher, merged_teacher, loss_distill = self.flownet(
+            torch.cat((imgs, gt), 1), scale=[4, 2, 1])
+        if self.nd == 3:
+            gt = _cut(gt, _mins(img0, mask))
+            loss_l1 = F.l1_loss(merged[2], gt)
+            loss_tea = F.l1_loss(merged_teacher, gt)
+            _ = 1e-5 * sum(torch.norm(p, 1) for p in self.flownet.parameters())  # :141-143, unused
+            loss_G = loss_l1 + loss_tea + loss_distill * 0.1
+            info = dict(loss_l1=loss_l1, loss_tea=loss_tea, loss_distill=loss_distill, loss_G=loss_G)
+        else:
+            mask = mask[2]
+            gt = _cut(gt, _mins(img0, mask))
+            loss_l1 = lap_loss(merged[2], gt).mean()
+            loss_tea = lap_loss(merged_teacher, gt).mean()
+            l1_reg = 0.
+            for name in self.flownet.state_dict():  # :177-188 (detached values)
+                if "block2" in name or "block_tea" in name:
+                    l1_reg = l1_reg + torch.norm(self.flownet.state_dict()[name], 1)
+            loss_photo = olosses.rife2d_photometric(flow[2], merged[2], img0, img1)
+            if math.isnan(float(loss_distill)) or float(loss_distill) > 10.:
+                loss_distill = torch.tensor(0.)
+            loss_G = loss_l1 + loss_tea + loss_distill * 0.01 + l1_reg * 1e-6 + loss_photo * 1e-5
+            info = dict(loss_l1=loss_l1, loss_tea=loss_tea, loss_distill=loss_distill * 0.01,
+                        l1_reg=l1_reg * 1e-6, loss_photo=loss_photo * 1e-5,
+                        loss_flow=torch.tensor(0.) * 0, loss_G=loss_G)
+        if training:
+            self.optimG.zero_grad()
+            loss_G.backward()
+            self.optimG.step()
+        info.update(flow=flow[2], merged_tea=merged_teacher, flow_tea=flow_teacher)
+        return merged[2], info

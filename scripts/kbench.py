@@ -24,7 +24,16 @@ def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     B = 2
     x = torch.rand(B, 1, S, S, S, device=dev)
-    f = ((torch.rand(B, 3, S, S, S, device=dev) * 2 - 1) * 4).requires_grad_()
+    kind = sys.argv[2] if len(sys.argv) > 2 else "smooth"
+    if kind == "noise":
+        f = ((torch.rand(B, 3, S, S, S, device=dev) * 2 - 1) * 4)
+    else:  # low-frequency field, |F| <= 4 voxels, like an upsampled coarse flow
+        ax = torch.linspace(0, 6.28318, S, device=dev)
+        f = torch.stack([4 * torch.sin(ax).view(1, S, 1, 1) * torch.cos(ax).view(1, 1, S, 1).expand(B, S, S, S),
+                         3 * torch.cos(ax * 2).view(1, 1, 1, S).expand(B, S, S, S) + 0 * ax.view(1, S, 1, 1),
+                         2 * torch.sin(ax * 3).view(1, 1, S, 1) * torch.sin(ax).view(1, 1, 1, S).expand(B, S, S, S)], 1).contiguous()
+    print("flow kind:", kind, tuple(f.shape))
+    f.requires_grad_()
     G = torch.randn(B, 1, S, S, S, device=dev)
     nvox = B * S ** 3
     t = timeit(lambda: ops.warp3d(x, f.detach()))

@@ -117,6 +117,13 @@ def rife_ops():
     x = torch.rand(1, 1, 5, 6, 7, generator=gen)
     store["w3_zero_x"] = _np(x)
     store["w3_zero_out"] = _np(w3.warp(x, torch.zeros(1, 3, 5, 6, 7)))
+    # input extent != flow extent (IFNet-3D on sizes that are not multiples of 16)
+    x = torch.rand(1, 2, 10, 9, 12, generator=gen).requires_grad_()
+    f = _flow_cases((1, 3, 8, 8, 8), gen, 1.5).requires_grad_()
+    out = w3.warp(x, f)
+    G, (gx, gf) = _grads(out, [x, f], 13)
+    for k, v in dict(x=x, f=f, out=out, G=G, gx=gx, gf=gf).items():
+        store["w3_mixed_%s" % k] = _np(v)
     np.savez_compressed(os.path.join(OUT, "rife_ops.npz"), **store)
     print("wrote rife_ops.npz", len(store), "arrays")
 
@@ -221,7 +228,7 @@ def flow3d_e2e():
     nparam = sum(p.numel() for p in m.flownet.parameters())
     store["nparam"] = np.array(nparam)
     # parameter fingerprint (seed-compatibility check for the oracle / product models)
-    store["param_sums"] = np.array([float(p.double().sum()) for p in m.flownet.parameters()])
+    store["param_sums"] = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
     m.eval()
     with torch.no_grad():
         merged, flows, mask = _quiet(m.inference, imgs[:, :1], imgs[:, 1:2], [4, 2, 1])
@@ -234,7 +241,7 @@ def flow3d_e2e():
         losses.append([float(info[k]) for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G")])
     store["update_losses"] = np.array(losses)
     store["update_pred_last"] = _np(pred)
-    store["param_sums_after"] = np.array([float(p.double().sum()) for p in m.flownet.parameters()])
+    store["param_sums_after"] = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
     np.savez_compressed(os.path.join(OUT, "flow3d_e2e.npz"), **store)
     print("wrote flow3d_e2e.npz; losses", losses, "nparam", nparam)
 
@@ -254,13 +261,13 @@ def flow2d_e2e():
     imgs, gt = data[:, :2], data[:, 2:3]
     store = dict(data=_np(data))
     store["nparam"] = np.array(sum(p.numel() for p in m.flownet.parameters()))
-    store["param_sums"] = np.array([float(p.double().sum()) for p in m.flownet.parameters()])
+    store["param_sums"] = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
     m.eval()
     with torch.no_grad():
         merged, flows, mask = _quiet(m.inference, imgs[:, :1], imgs[:, 1:2], [4, 2, 1])
-    store["inf_merged"] = _np(merged)
+    store["inf_merged"] = _np(merged[2])  # Flow-2D inference returns all three frames / masks
     store["inf_flow2"] = _np(flows[2])
-    store["inf_mask"] = _np(mask)
+    store["inf_mask"] = _np(mask[2])
     losses, keys = [], None
     for step in range(2):
         pred, info = _quiet(m.update, imgs, gt, "droplet2d", learning_rate=1e-4, training=True)
@@ -269,7 +276,7 @@ def flow2d_e2e():
     store["update_loss_keys"] = np.array(keys)
     store["update_losses"] = np.array(losses)
     store["update_pred_last"] = _np(pred)
-    store["param_sums_after"] = np.array([float(p.double().sum()) for p in m.flownet.parameters()])
+    store["param_sums_after"] = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
     np.savez_compressed(os.path.join(OUT, "flow2d_e2e.npz"), **store)
     print("wrote flow2d_e2e.npz; keys", keys, "losses", losses)
 

@@ -45,7 +45,7 @@ def test_warp2d_rife_closed(golden):
 
 def test_warp3d_ref(golden):
     g = golden("rife_ops")
-    for tag in ("nc", "cu", "tile"):
+    for tag in ("nc", "cu", "tile", "mixed"):
         _check_warp(owarps.warp3d_ref, g, "w3_%s_" % tag)
     close(owarps.warp3d_ref(T(g["w3_zero_x"]), torch.zeros(1, 3, 5, 6, 7)), g["w3_zero_out"], 1e-6)
 
