@@ -5,3 +5,16 @@ hand-written HIP kernels for gfx950 behind a C-ABI (include/flowsci_hip.h), plus
 mirrors of the reference's call sites (`flow2d`, `flow3d`, `upflow` sub-packages).
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# MIOpen has no gfx950 find-db in ROCm 7.2, so the first call of every convolution shape runs a
+# "find" that also times its naive direct kernels -- 1.4 s per call for a 128^3 IFNet-3D layer,
+# minutes per step at 256^3 -- although they never win forward / backward-data.  The convolutions
+# are not part of this package's hot path (they stay on MIOpen), but its entry points must start in
+# bounded time, so the naive fwd/bwd solvers are taken out of the search unless the user has
+# already chosen otherwise.  (Weight-gradient is left alone: for a few IFNet layers naive_wrw IS
+# MIOpen's fastest applicable solver.)
+for _k in ("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD"):
+    _os.environ.setdefault(_k, "0")
+del _k
