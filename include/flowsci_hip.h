@@ -108,6 +108,87 @@ int fs_warp2d_pair_bwd(const float* img0, const float* img1, const float* flow4,
                        float* grad_img0, float* grad_img1, float* grad_flow4,
                        int B, int C, int H, int W, int mode, fs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * a3/a4. Local-window correlation (cost volume) -- replaces the `correlation_cuda` torch
+ * extension bound at UPFlow/model/correlation_package/correlation.py:4,26-27,42-43
+ * (sources absent from the reference tree; semantics pinned by Corr_pyTorch,
+ * UPFlow/utils/pytorch_correlation.py:27-50) for the only configuration the reference uses:
+ * pad_size = max_displacement = md, kernel_size = 1, stride1 = stride2 = 1, corr_multiply = 1
+ * (UPFlow/model/upflow.py:649,652: md = 4).
+ *   f1, f2 [B,C,H,W] -> out [B,(2md+1)^2,H,W],
+ *   out[b,(dy+md)(2md+1)+(dx+md),y,x] = (1/C) sum_c f1[b,c,y,x] f2[b,c,y+dy,x+dx], zero pad.
+ * md in 1..4.  bwd: grad_f1 / grad_f2 nullable (at least one), fully overwritten; no atomics,
+ * bitwise reproducible.  The reference's rbot1/rbot2 scratch tensors have no equivalent.
+ */
+int fs_corr2d_fwd(const float* f1, const float* f2, float* out,
+                  int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
+int fs_corr2d_bwd(const float* f1, const float* f2, const float* grad_out,
+                  float* grad_f1, float* grad_f2,
+                  int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a9/a10. Robust penalty + (masked) reduction -- the arithmetic of
+ *   loss_functions.photo_loss_function   UPFlow/utils/loss.py:17-48   (tail of the census loss)
+ *   network_tools.photo_loss_multi_type  UPFlow/model/upflow.py:267-289
+ *   torch.nn.functional.l1_loss          Flow-3D/model/RIFE.py:132-134 (FS_PEN_L1)
+ * in one pass:  S1 = sum_e pen(x[e] - y[e]) * w,  S2 = sum w   (w broadcast over C; S2 counts
+ * each pixel once).  x, y [B,C,S] (y NULL => pen(x)), w [B,1,S] or NULL (then S2 = 0).
+ * pen: ABS_ROBUST (|v|+0.01)^q | CHARBONNIER (v^2+eps)^q | L1_EPS |v+1e-6| | L1 |v|.
+ * `border` > 0 (needs S == H*W): weights within `border` px of the image edge are zeroed --
+ * the inner mask of census_loss_torch (loss.py:74-88, max_distance = 3).
+ * sums: 2 device floats.  ws: device scratch, 2*FS_REDUCE_BLOCKS floats (caller-owned).
+ * The caller turns (S1, S2) into the reference's mean / ratio forms.  Deterministic.
+ * bwd: grad_x[e] = coef[0] * pen'(x-y) * w ; grad_y = -grad_x.  coef = device scalar
+ * (upstream gradient times d loss / d S1).
+ */
+enum { FS_PEN_ABS_ROBUST = 0, FS_PEN_CHARBONNIER = 1, FS_PEN_L1_EPS = 2, FS_PEN_L1 = 3 };
+#define FS_REDUCE_BLOCKS 1024
+
+int fs_robust_sum(const float* x, const float* y, const float* w, float* sums, float* ws,
+                  int B, int C, int S, int H, int W, int border, int mode, float q, float eps,
+                  fs_stream_t stream);
+int fs_robust_sum_bwd(const float* x, const float* y, const float* w, const float* coef,
+                      float* grad_x, float* grad_y,
+                      int B, int C, int S, int H, int W, int border, int mode, float q, float eps,
+                      fs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a8. Census (soft ternary) distance -- loss_functions.census_loss_torch,
+ * UPFlow/utils/loss.py:51-72: grey = .2989R+.5870G+.1140B; 7x7 zero-padded neighbourhood
+ * differences t = d/sqrt(0.81+d^2); dist = sum_49 (t1-t2)^2/(0.1+(t1-t2)^2).
+ *   img1, img2 [B,3,H,W] -> dist [B,1,H,W].  max_distance must be 3.
+ * The loss is fs_robust_sum(dist, w = occ mask, border = 3, ...).
+ * bwd: grad_dist [B,1,H,W] -> grad_img1 / grad_img2 [B,3,H,W] (nullable, overwritten);
+ * gather-formulated, no atomics.
+ */
+int fs_census_dist_fwd(const float* img1, const float* img2, float* dist,
+                       int B, int H, int W, int max_distance, fs_stream_t stream);
+int fs_census_dist_bwd(const float* img1, const float* img2, const float* grad_dist,
+                       float* grad_img1, float* grad_img2,
+                       int B, int H, int W, int max_distance, fs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a12. IFNet epilogues (Flow-2D/model/IFNet.py:239-248, Flow-3D/model/IFNet.py:241-267).
+ * merge:   merged[B,C,S] = w0 * sigmoid(m) + w1 * (1 - sigmoid(m)),  m [B,1,S];
+ *          sigmoid_out [B,1,S] nullable (the reference keeps it as mask_list[i]).
+ * distill: sums[0] = sum_voxels sqrt(mean_c (flow_tea - flow_i)^2) * loss_mask,
+ *          sums[1] = sum loss_mask,  loss_mask = mean_c|merged_i-gt| > mean_c|merged_tea-gt| + 0.01;
+ *          merged_*, gt [B,C,S]; flow_* [B,F,S].  The term of loss_distill is sums[0] / (B*S).
+ *          bwd: grad_flow_i only (teacher flow and mask are detached in the reference).
+ */
+int fs_merge_fwd(const float* w0, const float* w1, const float* mask_logit,
+                 float* merged, float* sigmoid_out, int B, int C, int S, fs_stream_t stream);
+int fs_merge_bwd(const float* w0, const float* w1, const float* mask_logit,
+                 const float* grad_merged, const float* grad_sigmoid,
+                 float* grad_w0, float* grad_w1, float* grad_mask_logit,
+                 int B, int C, int S, fs_stream_t stream);
+int fs_distill_fwd(const float* merged_i, const float* merged_tea, const float* gt,
+                   const float* flow_i, const float* flow_tea, float* sums, float* ws,
+                   int B, int C, int F, int S, fs_stream_t stream);
+int fs_distill_bwd(const float* merged_i, const float* merged_tea, const float* gt,
+                   const float* flow_i, const float* flow_tea, const float* coef,
+                   float* grad_flow_i, int B, int C, int F, int S, fs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

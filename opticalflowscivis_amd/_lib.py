@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libflowsci_hip.so")
 
 _f32p = ctypes.c_void_p  # device pointers travel as integers
 _int = ctypes.c_int
+_float = ctypes.c_float
 _stream = ctypes.c_void_p
 _intp = ctypes.POINTER(ctypes.c_int)  # host array of ints (or None)
 
@@ -25,6 +26,16 @@ SIGNATURES = {
     "fs_warp3d_pair_bwd": [_f32p] * 8 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_warp2d_pair_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_warp2d_pair_bwd": [_f32p] * 8 + [_int] * 5 + [_stream],
+    "fs_corr2d_fwd": [_f32p] * 3 + [_int] * 5 + [_stream],
+    "fs_corr2d_bwd": [_f32p] * 5 + [_int] * 5 + [_stream],
+    "fs_robust_sum": [_f32p] * 5 + [_int] * 7 + [_float, _float, _stream],
+    "fs_robust_sum_bwd": [_f32p] * 6 + [_int] * 7 + [_float, _float, _stream],
+    "fs_census_dist_fwd": [_f32p] * 3 + [_int] * 4 + [_stream],
+    "fs_census_dist_bwd": [_f32p] * 5 + [_int] * 4 + [_stream],
+    "fs_merge_fwd": [_f32p] * 5 + [_int] * 3 + [_stream],
+    "fs_merge_bwd": [_f32p] * 8 + [_int] * 3 + [_stream],
+    "fs_distill_fwd": [_f32p] * 7 + [_int] * 4 + [_stream],
+    "fs_distill_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _stream],
     "fs_warp2d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                       _stream],

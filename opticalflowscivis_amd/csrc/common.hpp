@@ -44,4 +44,39 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Second stage of the deterministic reductions: `nblocks` pairs of per-block partial sums in
+// `ws` -> sums[0..1].  One block, fixed order, fp64 accumulation: bitwise reproducible.
+static __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ ws, int nblocks,
+                                                           float* __restrict__ sums) {
+  __shared__ double red[2][256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { a += (double)ws[2 * i]; b += (double)ws[2 * i + 1]; }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sums[0] = (float)red[0][0]; sums[1] = (float)red[1][0]; }
+}
+
+
+// block-level (256 threads) pair reduction into ws[2*blockIdx.x .. +1]
+__device__ __forceinline__ void block_pair_to_ws(float s1, float s2, float* __restrict__ ws) {
+  __shared__ float red_[2][4];
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red_[0][wv] = s1; red_[1][wv] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws[2 * blockIdx.x] = (red_[0][0] + red_[0][1]) + (red_[0][2] + red_[0][3]);
+    ws[2 * blockIdx.x + 1] = (red_[1][0] + red_[1][1]) + (red_[1][2] + red_[1][3]);
+  }
+}
+
 }  // namespace fs

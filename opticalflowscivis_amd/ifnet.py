@@ -105,7 +105,7 @@ class IFNet(nn.Module):
     def forward(self, x, scale=(4, 2, 1), timestep=0.5):
         img0, img1 = x[:, :1], x[:, 1:2]
         gt = x[:, 2:3] if self.nd == 2 else x[:, 2:]  # empty at inference time
-        flow_list, merged, mask_list = [], [], []
+        flow_list, merged, mask_list, mask_logits = [], [], [], []
         warped_img0, warped_img1 = img0, img1
         flow = mask = None
         loss_distill = 0
@@ -130,7 +130,7 @@ class IFNet(nn.Module):
             if self.nd == 3:
                 flow, mask = _crop(flow, sp), _crop(mask, sp)
             img0, img1 = _crop(img0, sp), _crop(img1, sp)
-            mask_list.append(torch.sigmoid(mask))
+            mask_logits.append(mask)
             flow_list.append(flow)
             # hot path: both backward warps of this block in one HIP launch
             warped_img0, warped_img1 = ops.warp_pair(img0, img1, flow)
@@ -145,22 +145,20 @@ class IFNet(nn.Module):
                 torch.cat((img0, img1, warped_img0, warped_img1, mask, gt), 1), flow, scale=1)
             flow_teacher = flow + _crop(flow_d, sp)
             w0t, w1t = ops.warp_pair(img0, img1, flow_teacher)
-            mask_teacher = torch.sigmoid(mask + _crop(mask_d, sp))
-            merged_teacher = w0t * mask_teacher + w1t * (1 - mask_teacher)
+            merged_teacher, _ = ops.merge(w0t, w1t, mask + _crop(mask_d, sp))
         else:
             flow_teacher = None
             merged_teacher = None
 
         for i in range(3):
-            m = merged[i][0] * mask_list[i] + merged[i][1] * (1 - mask_list[i])
+            # fused epilogues (a12): sigmoid + blend in one pass, mask test + distillation in another
+            m, sig = ops.merge(merged[i][0], merged[i][1], mask_logits[i])
+            mask_list.append(sig)
             merged[i] = _crop(m, _min_spatial(m, gt))
             if gt.shape[1] == 1:
                 flow_list[i] = _crop(flow_list[i], flow_teacher.shape[2:])
-                loss_mask = ((merged[i] - gt).abs().mean(1, True) >
-                             (merged_teacher - gt).abs().mean(1, True) + 0.01).float().detach()
-                loss_distill = loss_distill + (
-                    ((flow_teacher.detach() - flow_list[i]) ** 2).mean(1, True) ** 0.5 * loss_mask
-                ).mean()
+                loss_distill = loss_distill + ops.distill_term(merged[i], merged_teacher, gt,
+                                                               flow_list[i], flow_teacher.detach())
         # Flow-2D returns every block's mask (IFNet.py:276), Flow-3D the last one (IFNet.py:280)
         masks = mask_list if self.nd == 2 else mask_list[2]
         return flow_list, masks, merged, flow_teacher, merged_teacher, loss_distill

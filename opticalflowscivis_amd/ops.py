@@ -270,3 +270,315 @@ def rife2d_photometric(flow4, merged, img0, img1):
         return torch.sum(torch.sum(p, dim=1) / 3) / frame.size(0)
 
     return (term(flow4[:, 2:4], img0) + term(flow4[:, :2], img1)) / 2
+
+
+# --------------------------------------------------------------------------------------------
+# a3/a4: local-window correlation (UPFlow/model/correlation_package/correlation.py:8-45)
+# --------------------------------------------------------------------------------------------
+def corr2d_forward_into(input1, input2, output, max_displacement):
+    """correlation_cuda.forward semantics: `output` is resized and filled in place."""
+    input1 = _need_cuda_f32("input1", input1, 4)
+    input2 = _need_cuda_f32("input2", input2, 4)
+    if input1.shape != input2.shape or input1.device != input2.device:
+        raise ValueError("input1 %s and input2 %s must match" %
+                         (tuple(input1.shape), tuple(input2.shape)))
+    B, C, H, W = input1.shape
+    nd = 2 * max_displacement + 1
+    output.resize_(B, nd * nd, H, W)
+    with torch.cuda.device(input1.device):
+        _call("fs_corr2d_fwd", input1.data_ptr(), input2.data_ptr(), output.data_ptr(), B, C, H, W,
+              int(max_displacement), _stream(input1))
+    return output
+
+
+def corr2d_backward_into(input1, input2, grad_output, grad_input1, grad_input2, max_displacement):
+    """correlation_cuda.backward semantics: grad tensors are resized and filled in place
+    (pass None to skip one of them)."""
+    input1 = _need_cuda_f32("input1", input1, 4)
+    input2 = _need_cuda_f32("input2", input2, 4)
+    grad_output = _need_cuda_f32("grad_output", grad_output, 4)
+    B, C, H, W = input1.shape
+    nd = 2 * max_displacement + 1
+    if tuple(grad_output.shape) != (B, nd * nd, H, W):
+        raise ValueError("grad_output must be %s, got %s" % ((B, nd * nd, H, W),
+                                                             tuple(grad_output.shape)))
+    for g in (grad_input1, grad_input2):
+        if g is not None:
+            g.resize_(B, C, H, W)
+    with torch.cuda.device(input1.device):
+        _call("fs_corr2d_bwd", input1.data_ptr(), input2.data_ptr(), grad_output.data_ptr(),
+              _ptr(grad_input1), _ptr(grad_input2), B, C, H, W, int(max_displacement),
+              _stream(input1))
+
+
+class _Corr2D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, md):
+        out = corr2d_forward_into(f1, f2, f1.new_empty(0), md)
+        ctx.save_for_backward(f1.contiguous(), f2.contiguous())
+        ctx.md = md
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        f1, f2 = ctx.saved_tensors
+        g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        if g1 is None and g2 is None:
+            return None, None, None
+        corr2d_backward_into(f1, f2, gout, g1, g2, ctx.md)
+        return g1, g2, None
+
+
+def corr2d(f1, f2, max_displacement=4):
+    """Cost volume [B,(2md+1)^2,H,W] = channel-mean of f1 * shifted f2 (zero padded)."""
+    return _Corr2D.apply(f1, f2, int(max_displacement))
+
+
+# --------------------------------------------------------------------------------------------
+# a9/a10: robust penalty + masked reduction (UPFlow/utils/loss.py:17-48, upflow.py:267-289)
+# --------------------------------------------------------------------------------------------
+PEN_ABS_ROBUST, PEN_CHARBONNIER, PEN_L1_EPS, PEN_L1 = 0, 1, 2, 3
+_REDUCE_BLOCKS = 1024
+
+
+def _flat3(t):
+    """[B,C,*spatial] -> (B, C, S) sizes of a contiguous tensor."""
+    return t.shape[0], t.shape[1], int(t[0, 0].numel())
+
+
+class _RobustLoss(torch.autograd.Function):
+    """loss = form(S1, S2);  S1 = sum pen(x - y) * w,  S2 = sum w  (one HIP pass)."""
+
+    @staticmethod
+    def forward(ctx, x, y, w, mode, q, eps, border, form):
+        x = _need_cuda_f32("x", x, x.dim())
+        if y is not None:
+            y = _need_cuda_f32("y", y, x.dim())
+            if y.shape != x.shape:
+                raise ValueError("x %s and y %s differ" % (tuple(x.shape), tuple(y.shape)))
+        B, C, S = _flat3(x)
+        if w is not None:
+            w = _need_cuda_f32("mask", w, x.dim())
+            if tuple(w.shape) != (B, 1) + tuple(x.shape[2:]):
+                raise ValueError("mask must be [B,1,...] matching x %s, got %s" %
+                                 (tuple(x.shape), tuple(w.shape)))
+        H, W = (x.shape[2], x.shape[3]) if x.dim() == 4 else (1, S)
+        sums = x.new_empty(2)
+        ws = x.new_empty(2 * _REDUCE_BLOCKS)
+        with torch.cuda.device(x.device):
+            _call("fs_robust_sum", x.data_ptr(), _ptr(y), _ptr(w), sums.data_ptr(), ws.data_ptr(),
+                  B, C, S, H, W, border, mode, float(q), float(eps), _stream(x))
+        S1, S2 = sums[0], sums[1]
+        n = float(B * C * S)
+        if form == "mean":
+            loss, dS1 = S1 / n, S1.new_tensor(1.0 / n)
+        elif form == "sum":
+            loss, dS1 = S1 * 1.0, S1.new_tensor(1.0)
+        elif form == "ratio":      # sum(l * w) / (sum(w) + 1e-6)          upflow.py:287
+            dS1 = 1.0 / (S2 + 1e-6)
+            loss = S1 * dS1
+        elif form == "ratio2":     # sum(l * w) / (sum(w) * 2 + 1e-6)      loss.py:39-42
+            dS1 = 1.0 / (S2 * 2 + 1e-6)
+            loss = S1 * dS1
+        elif form == "mean_ratio2":  # mean(l * w) / (mean(w) * 2 + 1e-6)  loss.py:20-29
+            dS1 = (1.0 / n) / ((S2 / float(B * S)) * 2 + 1e-6)
+            loss = S1 * dS1
+        else:
+            raise ValueError("unknown reduction form %r" % form)
+        ctx.save_for_backward(x, y, w, dS1)
+        ctx.cfg = (mode, float(q), float(eps), border)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, w, dS1 = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        need_y = y is not None and ctx.needs_input_grad[1]
+        if not (need_x or need_y):
+            return (None,) * 8
+        mode, q, eps, border = ctx.cfg
+        B, C, S = _flat3(x)
+        H, W = (x.shape[2], x.shape[3]) if x.dim() == 4 else (1, S)
+        coef = (gout * dS1).reshape(1).contiguous()
+        gx = torch.empty_like(x) if need_x else None
+        gy = torch.empty_like(x) if need_y else None
+        with torch.cuda.device(x.device):
+            _call("fs_robust_sum_bwd", x.data_ptr(), _ptr(y), _ptr(w), coef.data_ptr(), _ptr(gx),
+                  _ptr(gy), B, C, S, H, W, border, mode, q, eps, _stream(x))
+        return gx, gy, None, None, None, None, None, None
+
+
+def robust_loss(x, y, mask, mode, q=1.0, eps=0.0, border=0, form="mean"):
+    return _RobustLoss.apply(x, y, mask, mode, q, eps, border, form)
+
+
+def l1_loss(a, b):
+    """torch.nn.functional.l1_loss(a, b) (mean) in one fused pass (Flow-3D/model/RIFE.py:132-134)."""
+    return robust_loss(a, b, None, PEN_L1, form="mean")
+
+
+def photo_loss_function(diff, mask, q, charbonnier_or_abs_robust, if_use_occ, averge=True):
+    """UPFlow/utils/loss.py:17-48."""
+    if charbonnier_or_abs_robust:
+        if if_use_occ:
+            return robust_loss(diff, None, mask, PEN_CHARBONNIER, q, 1e-6,
+                               form="mean_ratio2" if averge else "ratio2")
+        return robust_loss(diff, None, None, PEN_CHARBONNIER, q, 1e-8, form="mean" if averge else "sum")
+    if if_use_occ:
+        return robust_loss(diff, None, mask, PEN_ABS_ROBUST, q, form="ratio2")
+    return robust_loss(diff, None, None, PEN_ABS_ROBUST, q, form="mean" if averge else "sum")
+
+
+def photo_loss_multi_type(x, y, occ_mask, photo_loss_type='abs_robust', photo_loss_delta=0.4,
+                          photo_loss_use_occ=False):
+    """UPFlow/model/upflow.py:267-289 for the abs_robust / charbonnier / L1 types (SSIM lives in
+    the upflow mirror module)."""
+    mode, q, eps = {"abs_robust": (PEN_ABS_ROBUST, photo_loss_delta, 0.0),
+                    "charbonnier": (PEN_CHARBONNIER, photo_loss_delta, 1e-6),
+                    "L1": (PEN_L1_EPS, 1.0, 0.0)}[photo_loss_type]
+    if photo_loss_use_occ:
+        return robust_loss(x, y, occ_mask, mode, q, eps, form="ratio")
+    return robust_loss(x, y, None, mode, q, eps, form="mean")
+
+
+# --------------------------------------------------------------------------------------------
+# a8: census loss (UPFlow/utils/loss.py:51-91)
+# --------------------------------------------------------------------------------------------
+class _CensusDist(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2, max_distance):
+        img1 = _need_cuda_f32("img1", img1, 4)
+        img2 = _need_cuda_f32("img1_warp", img2, 4)
+        if img1.shape != img2.shape or img1.shape[1] != 3:
+            raise ValueError("census needs two [B,3,H,W] images, got %s and %s" %
+                             (tuple(img1.shape), tuple(img2.shape)))
+        B, _, H, W = img1.shape
+        dist = img1.new_empty(B, 1, H, W)
+        with torch.cuda.device(img1.device):
+            _call("fs_census_dist_fwd", img1.data_ptr(), img2.data_ptr(), dist.data_ptr(), B, H, W,
+                  int(max_distance), _stream(img1))
+        ctx.save_for_backward(img1, img2)
+        ctx.md = int(max_distance)
+        return dist
+
+    @staticmethod
+    def backward(ctx, gdist):
+        img1, img2 = ctx.saved_tensors
+        n1, n2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (n1 or n2):
+            return None, None, None
+        gdist = gdist.contiguous()
+        B, _, H, W = img1.shape
+        g1 = torch.empty_like(img1) if n1 else None
+        g2 = torch.empty_like(img2) if n2 else None
+        with torch.cuda.device(img1.device):
+            _call("fs_census_dist_bwd", img1.data_ptr(), img2.data_ptr(), gdist.data_ptr(), _ptr(g1),
+                  _ptr(g2), B, H, W, ctx.md, _stream(img1))
+        return g1, g2, None
+
+
+def census_dist(img1, img1_warp, max_distance=3):
+    return _CensusDist.apply(img1, img1_warp, max_distance)
+
+
+def census_loss(img1, img1_warp, mask, q, charbonnier_or_abs_robust, if_use_occ, averge=True,
+                max_distance=3):
+    """loss_functions.census_loss_torch.  The occ x inner-border mask only matters when
+    if_use_occ is set (reference quirk, loss.py:42-47: otherwise it is built and ignored)."""
+    dist = census_dist(img1, img1_warp, max_distance)
+    if charbonnier_or_abs_robust:
+        if if_use_occ:
+            return robust_loss(dist, None, mask, PEN_CHARBONNIER, q, 1e-6, border=max_distance,
+                               form="mean_ratio2" if averge else "ratio2")
+        return robust_loss(dist, None, None, PEN_CHARBONNIER, q, 1e-8, form="mean" if averge else "sum")
+    if if_use_occ:
+        return robust_loss(dist, None, mask, PEN_ABS_ROBUST, q, border=max_distance, form="ratio2")
+    return robust_loss(dist, None, None, PEN_ABS_ROBUST, q, form="mean" if averge else "sum")
+
+
+# --------------------------------------------------------------------------------------------
+# a12: IFNet epilogues
+# --------------------------------------------------------------------------------------------
+class _Merge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w0, w1, m):
+        w0 = _need_cuda_f32("warped_img0", w0, w0.dim())
+        w1 = _need_cuda_f32("warped_img1", w1, w0.dim())
+        m = _need_cuda_f32("mask", m, w0.dim())
+        B, C, S = _flat3(w0)
+        if w1.shape != w0.shape or tuple(m.shape) != (B, 1) + tuple(w0.shape[2:]):
+            raise ValueError("merge operands mismatch: %s %s %s" %
+                             (tuple(w0.shape), tuple(w1.shape), tuple(m.shape)))
+        merged, sig = torch.empty_like(w0), torch.empty_like(m)
+        with torch.cuda.device(w0.device):
+            _call("fs_merge_fwd", w0.data_ptr(), w1.data_ptr(), m.data_ptr(), merged.data_ptr(),
+                  sig.data_ptr(), B, C, S, _stream(w0))
+        ctx.save_for_backward(w0, w1, m)
+        return merged, sig
+
+    @staticmethod
+    def backward(ctx, gmerged, gsig):
+        w0, w1, m = ctx.saved_tensors
+        n0, n1, nm = ctx.needs_input_grad
+        if not (n0 or n1 or nm):
+            return None, None, None
+        B, C, S = _flat3(w0)
+        gmerged = gmerged.contiguous()
+        gsig = gsig.contiguous() if gsig is not None else None
+        g0 = torch.empty_like(w0) if n0 else None
+        g1 = torch.empty_like(w1) if n1 else None
+        gm = torch.empty_like(m) if nm else None
+        with torch.cuda.device(w0.device):
+            _call("fs_merge_bwd", w0.data_ptr(), w1.data_ptr(), m.data_ptr(), gmerged.data_ptr(),
+                  _ptr(gsig), _ptr(g0), _ptr(g1), _ptr(gm), B, C, S, _stream(w0))
+        return g0, g1, gm
+
+
+def merge(warped_img0, warped_img1, mask_logit):
+    """(merged, sigmoid(mask)) with merged = w0 * sigmoid(m) + w1 * (1 - sigmoid(m))."""
+    return _Merge.apply(warped_img0, warped_img1, mask_logit)
+
+
+class _Distill(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, merged_i, merged_tea, gt, flow_i, flow_tea):
+        d = merged_i.dim()
+        ts = [_need_cuda_f32(n, t, d) for n, t in (("merged", merged_i), ("merged_teacher", merged_tea),
+                                                    ("gt", gt), ("flow", flow_i),
+                                                    ("flow_teacher", flow_tea))]
+        merged_i, merged_tea, gt, flow_i, flow_tea = ts
+        B, C, S = _flat3(merged_i)
+        F_ = flow_i.shape[1]
+        if not (merged_tea.shape == merged_i.shape == gt.shape and flow_tea.shape == flow_i.shape
+                and flow_i.shape[2:] == merged_i.shape[2:]):
+            raise ValueError("distill operands mismatch")
+        sums = merged_i.new_empty(2)
+        ws = merged_i.new_empty(2 * _REDUCE_BLOCKS)
+        with torch.cuda.device(merged_i.device):
+            _call("fs_distill_fwd", merged_i.data_ptr(), merged_tea.data_ptr(), gt.data_ptr(),
+                  flow_i.data_ptr(), flow_tea.data_ptr(), sums.data_ptr(), ws.data_ptr(), B, C, F_, S,
+                  _stream(merged_i))
+        ctx.save_for_backward(merged_i, merged_tea, gt, flow_i, flow_tea)
+        return sums[0] / float(B * S)
+
+    @staticmethod
+    def backward(ctx, gout):
+        merged_i, merged_tea, gt, flow_i, flow_tea = ctx.saved_tensors
+        if not ctx.needs_input_grad[3]:
+            return (None,) * 5
+        B, C, S = _flat3(merged_i)
+        F_ = flow_i.shape[1]
+        coef = (gout / float(B * S)).reshape(1).contiguous()
+        gf = torch.empty_like(flow_i)
+        with torch.cuda.device(merged_i.device):
+            _call("fs_distill_bwd", merged_i.data_ptr(), merged_tea.data_ptr(), gt.data_ptr(),
+                  flow_i.data_ptr(), flow_tea.data_ptr(), coef.data_ptr(), gf.data_ptr(), B, C, F_, S,
+                  _stream(merged_i))
+        return None, None, None, gf, None
+
+
+def distill_term(merged_i, merged_teacher, gt, flow_i, flow_teacher):
+    """One block's term of loss_distill; gradient reaches flow_i only (the reference detaches the
+    teacher flow and the loss mask)."""
+    return _Distill.apply(merged_i, merged_teacher, gt, flow_i, flow_teacher)

@@ -91,8 +91,8 @@ class Model3D(ModelBase):
             torch.cat((imgs, gt), 1), scale=[4, 2, 1])
         sp = tuple(min(a, b) for a, b in zip(imgs.shape[2:], mask.shape[2:]))
         gt = gt[(slice(None), slice(None)) + tuple(slice(0, s) for s in sp)]
-        loss_l1 = F.l1_loss(merged[2], gt)            # RIFE.py:132
-        loss_tea = F.l1_loss(merged_teacher, gt)      # RIFE.py:134
+        loss_l1 = ops.l1_loss(merged[2], gt)          # RIFE.py:132 (fused |a-b| + reduction)
+        loss_tea = ops.l1_loss(merged_teacher, gt)    # RIFE.py:134
         # RIFE.py:141-143 also sums an L1 norm of all parameters that never reaches loss_G
         # (lambda_reg = 0 and the term is commented out of :158); it is not computed here.
         loss_G = loss_l1 * 1 + loss_tea * 1 + loss_distill * 0.1  # RIFE.py:151-158

@@ -1,0 +1,168 @@
+"""-m gpu: correlation, census / photometric losses and IFNet epilogues (HIP, through the C-ABI)
+against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import corr as ocorr
+from oracle import losses as olosses
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a, grad=False):
+    t = torch.from_numpy(np.asarray(a)).clone().to(DEV)
+    return t.requires_grad_() if grad else t
+
+
+def relerr(a, b):
+    b = torch.as_tensor(b, dtype=torch.float32)
+    a = a.detach().cpu().float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from opticalflowscivis_amd import ops as o
+    return o
+
+
+def test_corr2d_golden(ops, golden):
+    g = golden("upflow_ops")
+    for tag in ("c3", "c32", "tiny"):
+        pre = "corr_%s_" % tag
+        f1, f2 = T(g[pre + "f1"], True), T(g[pre + "f2"], True)
+        out = ops.corr2d(f1, f2, 4)
+        assert float((out.detach().cpu() - torch.from_numpy(g[pre + "out"])).abs().max()) < 5e-6
+        g1, g2 = torch.autograd.grad((out * T(g[pre + "G"])).sum(), [f1, f2])
+        assert float((g1.cpu() - torch.from_numpy(g[pre + "g1"])).abs().max()) < 2e-5
+        assert float((g2.cpu() - torch.from_numpy(g[pre + "g2"])).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("shape,md", [((2, 32, 38, 113), 4), ((3, 196, 3, 8), 4), ((1, 7, 19, 57), 4),
+                                      ((2, 5, 9, 40), 2), ((1, 3, 11, 33), 3), ((1, 4, 6, 6), 1)])
+def test_corr2d_vs_oracle(ops, shape, md):
+    g = torch.Generator().manual_seed(shape[1] * 31 + md)
+    f1, f2 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    nd = 2 * md + 1
+    G = torch.randn(shape[0], nd * nd, shape[2], shape[3], generator=g)
+    a, b = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+    ref = ocorr.corr2d_closed(a, b, md)
+    r1, r2 = torch.autograd.grad((ref * G).sum(), [a, b])
+    c, d = f1.to(DEV).requires_grad_(), f2.to(DEV).requires_grad_()
+    out = ops.corr2d(c, d, md)
+    g1, g2 = torch.autograd.grad((out * G.to(DEV)).sum(), [c, d])
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5
+    assert float((g1.cpu() - r1).abs().max()) < 5e-5
+    assert float((g2.cpu() - r2).abs().max()) < 5e-5
+    # only one gradient requested -> the other launch half is skipped
+    c2 = f1.to(DEV).requires_grad_()
+    out2 = ops.corr2d(c2, f2.to(DEV), md)
+    (g1b,) = torch.autograd.grad((out2 * G.to(DEV)).sum(), [c2])
+    assert torch.equal(g1b, g1)
+
+
+def test_correlation_cuda_dropin(ops):
+    """The reference's autograd shim over `correlation_cuda` runs unchanged on the mirror module."""
+    from opticalflowscivis_amd.upflow.model.correlation_package.correlation import CorrelationFunction
+    g = torch.Generator().manual_seed(1)
+    f1 = torch.randn(2, 16, 12, 20, generator=g).to(DEV).requires_grad_()
+    f2 = torch.randn(2, 16, 12, 20, generator=g).to(DEV).requires_grad_()
+    out = CorrelationFunction.apply(f1, f2, 4, 1, 4, 1, 1, 1)  # upflow.py:649
+    ref = ocorr.corr2d_closed(f1.detach().cpu(), f2.detach().cpu(), 4)
+    assert float((out.detach().cpu() - ref).abs().max()) < 1e-5
+    out.sum().backward()
+    assert f1.grad is not None and f2.grad is not None
+    with pytest.raises(ValueError):
+        CorrelationFunction.apply(f1, f2, 3, 1, 4, 1, 1, 1)  # pad != max_displacement unsupported
+
+
+def test_census_golden(ops, golden):
+    g = golden("upflow_ops")
+    occ = T(g["cen_occ"])
+    for tag, (cha, useocc) in [("abs", (False, False)), ("absocc", (False, True)),
+                               ("cha", (True, False)), ("chaocc", (True, True))]:
+        im1, im2 = T(g["cen_im1"], True), T(g["cen_im2"], True)
+        loss = ops.census_loss(im1, im2, occ, 0.4, cha, useocc)
+        assert abs(float(loss) - float(g["cen_%s_loss" % tag])) < 1e-5 * max(1, abs(float(g["cen_%s_loss" % tag])))
+        g1, g2 = torch.autograd.grad(loss, [im1, im2])
+        assert relerr(g1, g["cen_%s_g1" % tag]) < 2e-4
+        assert relerr(g2, g["cen_%s_g2" % tag]) < 2e-4
+
+
+def test_census_vs_oracle_c3_shape(ops):
+    """BASELINE C3 image size (150 x 450, not a multiple of the 16-px tile), B=2."""
+    g = torch.Generator().manual_seed(9)
+    im1 = torch.rand(2, 3, 150, 450, generator=g)
+    im2 = (im1 + 0.05 * torch.randn(2, 3, 150, 450, generator=g)).clamp(0, 1)
+    occ = (torch.rand(2, 1, 150, 450, generator=g) > 0.2).float()
+    a, b = im1.clone().requires_grad_(), im2.clone().requires_grad_()
+    ref = olosses.census_loss(a, b, occ, 0.4, False, True)
+    r1, r2 = torch.autograd.grad(ref, [a, b])
+    c, d = im1.to(DEV).requires_grad_(), im2.to(DEV).requires_grad_()
+    loss = ops.census_loss(c, d, occ.to(DEV), 0.4, False, True)
+    g1, g2 = torch.autograd.grad(loss, [c, d])
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert relerr(g1, r1) < 2e-4 and relerr(g2, r2) < 2e-4
+    dist = ops.census_dist(c, d)
+    assert float((dist.detach().cpu() - olosses.census_dist(im1, im2)).abs().max()) < 2e-4
+
+
+def test_photo_losses_golden(ops, golden):
+    g = golden("upflow_ops")
+    occ = T(g["cen_occ"])
+    for typ in ["abs_robust", "charbonnier", "L1"]:
+        for useocc in (False, True):
+            tag = "%s_%d" % (typ, int(useocc))
+            im1, im2 = T(g["cen_im1"], True), T(g["cen_im2"], True)
+            loss = ops.photo_loss_multi_type(im1, im2, occ, typ, 0.4, useocc)
+            ref = float(g["photo_%s_loss" % tag])
+            assert abs(float(loss) - ref) < 2e-6 * max(1, abs(ref))
+            g1, g2 = torch.autograd.grad(loss, [im1, im2])
+            assert relerr(g1, g["photo_%s_g1" % tag]) < 2e-4
+            assert relerr(g2, g["photo_%s_g2" % tag]) < 2e-4
+
+
+def test_photo_loss_function_vs_oracle(ops):
+    g = torch.Generator().manual_seed(2)
+    diff = torch.randn(2, 3, 20, 30, generator=g)
+    mask = (torch.rand(2, 1, 20, 30, generator=g) > 0.4).float()
+    for cha in (False, True):
+        for occ in (False, True):
+            for av in (True, False):
+                a = diff.clone().requires_grad_()
+                ref = olosses.photo_loss_function(a, mask, 0.4, cha, occ, av)
+                (ra,) = torch.autograd.grad(ref, [a])
+                b = diff.to(DEV).requires_grad_()
+                out = ops.photo_loss_function(b, mask.to(DEV), 0.4, cha, occ, av)
+                (gb,) = torch.autograd.grad(out, [b])
+                assert abs(float(out) - float(ref)) < 1e-5 * max(1.0, abs(float(ref))), (cha, occ, av)
+                assert relerr(gb, ra) < 2e-4, (cha, occ, av)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 12, 20, 16), (3, 1, 40, 56), (2, 3, 17, 23)])
+def test_merge_distill_l1_vs_oracle(ops, shape):
+    nd = len(shape) - 2
+    g = torch.Generator().manual_seed(5 + nd)
+    B, C = shape[:2]
+    sp = shape[2:]
+    w0, w1, gt = (torch.rand(shape, generator=g) for _ in range(3))
+    m = torch.randn((B, 1) + sp, generator=g)
+    mt = torch.rand(shape, generator=g)
+    fi, ft = torch.randn((B, 2 * nd) + sp, generator=g), torch.randn((B, 2 * nd) + sp, generator=g)
+    # oracle
+    a0, a1, am, af = (t.clone().requires_grad_() for t in (w0, w1, m, fi))
+    mo = olosses.merge(a0, a1, am)
+    lo = torch.nn.functional.l1_loss(mo, gt) + 0.1 * olosses.distill_term(mo, mt, gt, af, ft)
+    ro = torch.autograd.grad(lo, [a0, a1, am, af])
+    # HIP
+    b0, b1, bm, bf = (t.to(DEV).requires_grad_() for t in (w0, w1, m, fi))
+    mh, sig = ops.merge(b0, b1, bm)
+    lh = ops.l1_loss(mh, gt.to(DEV)) + 0.1 * ops.distill_term(mh, mt.to(DEV), gt.to(DEV), bf, ft.to(DEV))
+    rh = torch.autograd.grad(lh, [b0, b1, bm, bf])
+    assert float((mh.detach().cpu() - mo.detach()).abs().max()) < 1e-6
+    assert float((sig.detach().cpu() - torch.sigmoid(m)).abs().max()) < 1e-6
+    assert abs(float(lh) - float(lo)) < 2e-6 * max(1.0, abs(float(lo)))
+    for x, y in zip(rh, ro):
+        assert relerr(x, y) < 2e-4
