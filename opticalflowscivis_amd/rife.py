@@ -33,7 +33,10 @@ class ModelBase:
         # large weight decay "may avoid NaN loss" (RIFE.py:28)
         self.optimG = AdamW(self.flownet.parameters(), lr=1e-6, weight_decay=1e-3)
         if local_rank != -1:
-            self.flownet = DDP(self.flownet, device_ids=[local_rank], output_device=local_rank)
+            if self.dev.type == "cuda":
+                self.flownet = DDP(self.flownet, device_ids=[local_rank], output_device=local_rank)
+            else:  # host-side tests of the sharding logic (gloo); the ops themselves need a GPU
+                self.flownet = DDP(self.flownet)
 
     def train(self):
         self.flownet.train()

@@ -1,0 +1,167 @@
+"""Training / evaluation loop shared by the Flow-2D and Flow-3D `train.py` entry points.
+
+Mirrors Flow-2D/train.py:70-553 and Flow-3D/train.py:72-478 (same flags, LR schedule, per-epoch
+evaluation with PSNR, rank-0 checkpointing, one barrier per epoch) with two deliberate changes:
+  * data: seeded synthetic stand-ins (data/synthetic.py) -- the reference's pickles are not in
+    its tree and there is no network;
+  * sharding: `DistributedSampler(shuffle=True)` + `set_epoch` is ON.  The reference left it
+    commented out (Flow-3D/train.py:82-83,139; Flow-2D/train.py:88-89,137), so under
+    torch.distributed every rank trained on the same samples.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
+
+from .data import synthetic
+
+
+class SyntheticTriplets(Dataset):
+    """Triplets (img0, img1, gt) generated on demand; item i depends only on (seed, i)."""
+
+    def __init__(self, kind, n, size, seed=1234):
+        self.kind, self.n, self.size, self.seed = kind, n, size, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        s = self.seed + 7919 * i
+        if self.kind == "droplet3d":
+            return synthetic.droplet3d_batch(1, self.size[0], seed=s)[0]
+        if self.kind == "5jets3d":
+            return synthetic.jets3d_batch(1, self.size[0], seed=s)[0]
+        if self.kind == "droplet2d":
+            h, w = self.size
+            r = (max(4, h // 8), max(8, h // 4))
+            return synthetic.droplet2d_batch(1, h, w, seed=s, radius=r)[0]
+        raise ValueError("no synthetic generator for dataset %r" % self.kind)
+
+
+def get_learning_rate(step, total_steps):
+    """Flow-3D/train.py:50-56: linear warm-up to 3e-4 over 2000 steps, then cosine to 3e-5."""
+    if step < 2000:
+        return 3e-4 * (step / 2000.)
+    mul = np.cos((step - 2000) / (total_steps - 2000.) * math.pi) * 0.5 + 0.5
+    return (3e-4 - 3e-5) * mul + 3e-5
+
+
+def psnr01(pred, gt):
+    """-10 log10(mean((gt - pred)^2)) on [0,1] data (Flow-3D/train.py:385)."""
+    return -10 * math.log10(max(float(torch.mean((gt - pred) * (gt - pred))), 1e-20))
+
+
+def evaluate(model, val_data, nd, dataset, device):
+    """Per-epoch validation: loss means and PSNR of student / teacher (train.py `evaluate`)."""
+    losses, psnr, psnr_tea = [], [], []
+    for data in val_data:
+        data = data.to(device, non_blocking=True)
+        imgs, gt = data[:, :2], data[:, 2:3]
+        with torch.no_grad():
+            if nd == 3:
+                pred, info = model.update(imgs, gt, training=False)
+            else:
+                pred, info = model.update(imgs, gt, dataset, training=False)
+        losses.append(float(info['loss_G']))
+        sp = tuple(min(a, b) for a, b in zip(gt.shape[2:], pred.shape[2:]))
+        cut = (slice(None), slice(None)) + tuple(slice(0, s) for s in sp)
+        for j in range(gt.shape[0]):
+            psnr.append(psnr01(pred[cut][j], gt[cut][j]))
+            psnr_tea.append(psnr01(info['merged_tea'][cut][j], gt[cut][j]))
+    return float(np.mean(losses)), float(np.mean(psnr)), float(np.mean(psnr_tea))
+
+
+def run(args, Model, nd):
+    world = int(os.environ.get("WORLD_SIZE", args.world_size))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", args.local_rank))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank)  # RCCL over xGMI
+    seed = 1234
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    model = Model(local_rank if distributed else -1, device=device)
+    size = tuple(args.size) if nd == 2 else (args.size[0],) * 3
+    train_set = SyntheticTriplets(args.dataset, args.samples, size, seed)
+    val_set = SyntheticTriplets(args.dataset, max(args.batch_size, args.samples // 8), size, seed + 10 ** 6)
+    sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True) if distributed else None
+    train_data = DataLoader(train_set, batch_size=args.batch_size, num_workers=args.workers, pin_memory=True,
+                            drop_last=True, sampler=sampler, shuffle=(sampler is None))
+    val_data = DataLoader(val_set, batch_size=args.batch_size, num_workers=args.workers, pin_memory=True)
+    steps_per_epoch = len(train_data)
+    log_path = args.log_path
+    os.makedirs(log_path, exist_ok=True)
+    model_name = args.model_name
+    try:
+        model.load_model(model_name, log_path)
+        if rank == 0:
+            print("loaded", model_name)
+    except (FileNotFoundError, RuntimeError, KeyError):
+        if rank == 0:
+            print("no weights found, training from scratch")
+
+    if args.mode != "train":
+        loss, p, pt = evaluate(model, val_data, nd, args.dataset, device)
+        if rank == 0:
+            print("test: loss_G %.4e  PSNR %.2f dB  (teacher %.2f dB)" % (loss, p, pt))
+        if distributed:
+            dist.destroy_process_group()
+        return
+
+    step, best = 0, None
+    total = args.epoch * steps_per_epoch
+    for epoch in range(args.epoch):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        t0 = time.time()
+        for i, data in enumerate(train_data):
+            data = data.to(device, non_blocking=True)
+            imgs, gt = data[:, :2], data[:, 2:3]
+            lr = get_learning_rate(step, max(total, 2001)) * world / 4  # train.py:167
+            if nd == 3:
+                pred, info = model.update(imgs, gt, lr, training=True)
+            else:
+                pred, info = model.update(imgs, gt, args.dataset, lr, training=True)
+            if rank == 0 and (i % args.log_every == 0):
+                print('epoch:{}/{} {}/{} time:{:.2f} loss_G:{:.4e}'.format(
+                    epoch, args.epoch, i, steps_per_epoch, time.time() - t0, float(info['loss_G'])))
+                t0 = time.time()
+            step += 1
+        loss, p, pt = evaluate(model, val_data, nd, args.dataset, device)
+        if rank == 0:
+            print("eval epoch %d: loss_G %.4e  PSNR %.2f dB  (teacher %.2f dB)" % (epoch, loss, p, pt))
+            if nd == 2 or best is None or loss <= best:  # 2-D saves every epoch, 3-D on improvement
+                best = loss if best is None else min(best, loss)
+                model.save_model(model_name, log_path, 0)
+        if distributed:
+            dist.barrier()
+    if distributed:
+        dist.destroy_process_group()
+
+
+def add_common_args(parser, nd):
+    parser.add_argument('--epoch', default=100, type=int)
+    parser.add_argument('--batch_size', default=1 if nd == 3 else 16, type=int, help='minibatch size')
+    parser.add_argument('--local_rank', default=0, type=int, help='local rank')
+    parser.add_argument('--world_size', default=1, type=int, help='world size')
+    parser.add_argument('--dataset', dest='dataset', type=str, default=None)
+    parser.add_argument('--mode', dest='mode', type=str, default='test')
+    # additions (synthetic data, no hard-coded checkpoint names)
+    parser.add_argument('--size', type=int, nargs='+', default=[64] if nd == 3 else [160, 224])
+    parser.add_argument('--samples', type=int, default=64, help='synthetic training triplets')
+    parser.add_argument('--workers', type=int, default=0)
+    parser.add_argument('--log_every', type=int, default=10)
+    parser.add_argument('--log_path', default='train_log')
+    parser.add_argument('--model_name', default='flownet.pkl')
+    return parser

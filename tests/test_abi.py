@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads and exports every symbol include/flowsci_hip.h declares; the Python
+binding covers them all; the product path fails loudly instead of falling back to the CPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "flowsci_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from opticalflowscivis_amd import _lib
+    names = _declared()
+    assert len(names) >= 20
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), "libflowsci_hip.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, "Python binding and header disagree"
+    lib = _lib.lib()
+    assert lib.fs_version() >= 100
+    assert lib.fs_error_string(0) == b"ok" and lib.fs_error_string(2) != b"ok"
+
+
+def test_null_and_shape_errors_without_gpu():
+    """Argument validation happens before any launch, so it is testable on the CPU."""
+    from opticalflowscivis_amd import _lib
+    lib = _lib.lib()
+    assert lib.fs_warp3d_fwd(None, None, None, 1, 1, None, 8, 8, 8, None) == 1      # NULLPTR
+    assert lib.fs_warp3d_fwd(1, 1, 1, 1, 1, None, 1, 8, 8, None) == 2               # SHAPE (D < 2)
+    assert lib.fs_warp2d_fwd(1, 1, None, 1, 1, 1, 8, 8, 7, 0, None) == 3            # ARG (mode)
+    assert lib.fs_corr2d_fwd(1, 1, 1, 1, 1, 8, 8, 5, None) == 3                     # ARG (md > 4)
+    assert lib.fs_census_dist_fwd(1, 1, 1, 1, 8, 8, 2, None) == 3                   # ARG (md != 3)
+    with pytest.raises(_lib.FlowsciKernelError):
+        _lib.check(2, "x")
+
+
+def test_ops_refuse_cpu_tensors():
+    from opticalflowscivis_amd import ops
+    x = torch.rand(1, 1, 8, 8, 8)
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        ops.warp3d(x, torch.zeros(1, 3, 8, 8, 8))
+    with pytest.raises(ValueError):
+        ops.corr2d(torch.rand(1, 4, 8, 8), torch.rand(1, 4, 8, 8))
+    with pytest.raises(ValueError):
+        ops.census_loss(torch.rand(1, 3, 16, 16), torch.rand(1, 3, 16, 16), torch.ones(1, 1, 16, 16), 0.4,
+                        False, False)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from opticalflowscivis_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libflowsci_hip.so")
+    with pytest.raises(_lib.FlowsciLibraryError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "opticalflowscivis_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)
+
+
+def test_model_requires_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from opticalflowscivis_amd.flow3d.model.RIFE import Model
+    with pytest.raises(RuntimeError, match="no CPU"):
+        Model(local_rank=-1)
