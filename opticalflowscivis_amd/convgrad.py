@@ -1,0 +1,132 @@
+"""Weight-gradient of the IFNet convolutions as im2col + split-K GEMM (stock PyTorch / rocBLAS).
+
+Why this exists.  The convolutions are NOT part of this package's hot path -- they stay
+`torch.nn.Conv{2,3}d` / `ConvTranspose{2,3}d` on MIOpen.  But ROCm 7.2 ships no gfx950
+tuning database for MIOpen, and for the 3-D IFNet layers its weight-gradient solvers
+(`kernel_batched_gemm_xdlops_bwd_weight` without K-split, `naive_conv_ab_nonpacked_wrw`) take
+10-80 ms PER LAYER at 128^3 -- >90 % of the whole train step (profiles/r01_flow3d_128_*).  The
+weight gradient is a GEMM with a tiny output and a huge reduction:
+
+    dW[co, (ci,kz,ky,kx)] = sum over (b, oz, oy, ox) of  gout[b,co,o] * x[b,ci, o*s + k - p]
+
+so it is computed here as  G[Co, K] @ Col[K, Ci*k^3]  with the reduction axis K = B*Do*Ho*Wo split
+into batches (bmm + sum): every CU gets work although the output is only Co x Ci*k^3.  Forward and
+input-gradient keep using MIOpen (they are fast).  Same math as autograd's convolution backward up
+to fp32 summation order.  `FLOWSCI_CONV_WRW=miopen` restores the stock path.
+
+Module classes subclass the torch.nn ones, so parameter names / state_dicts are unchanged.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_MODE = os.environ.get("FLOWSCI_CONV_WRW", "gemm")
+_COL_BYTES_CAP = int(os.environ.get("FLOWSCI_CONV_COL_GB", "24")) << 30  # im2col scratch per chunk
+
+
+def _tuple(v, nd):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * nd
+
+
+def _splitk_matmul(G, Col):
+    """G [M, K] @ Col [K, N] with the (huge) K axis split into batches."""
+    M, K = G.shape
+    N = Col.shape[1]
+    S = 1
+    while S < 256 and K % (2 * S) == 0 and K // (2 * S) >= 2048:
+        S *= 2
+    if S == 1:
+        return G @ Col
+    return torch.bmm(G.view(M, S, K // S).transpose(0, 1), Col.view(S, K // S, N)).sum(0)
+
+
+def _wrw_from_patches(src, g, k, stride, padding):
+    """dW[gc, sc, *k] = sum_{b, o} g[b, gc, o] * src_padded[b, sc, o*stride + koff]
+    src [B,Cs,*in], g [B,Cg,*out] with out = floor((in + 2p - k)/stride) + 1 (extra src rows unused)."""
+    nd = src.dim() - 2
+    B, Cs = src.shape[:2]
+    Cg = g.shape[1]
+    out = g.shape[2:]
+    pad = []
+    for p in reversed(padding):
+        pad += [p, p]
+    xp = F.pad(src, pad) if any(padding) else src
+    kk = 1
+    for v in k:
+        kk *= v
+    nout = 1
+    for v in out:
+        nout *= v
+    # chunk the batch so that the im2col scratch stays bounded
+    per_sample = nout * Cs * kk * 4
+    bchunk = max(1, min(B, _COL_BYTES_CAP // max(per_sample, 1)))
+    dW = None
+    for b0 in range(0, B, bchunk):
+        xb = xp[b0:b0 + bchunk]
+        v = xb
+        for d in range(nd):
+            v = v.unfold(2 + d, k[d], stride[d])  # [b, Cs, *n_i, *k]
+        # keep exactly the output positions of the convolution
+        v = v[(slice(None), slice(None)) + tuple(slice(0, o) for o in out)]
+        nb = xb.shape[0]
+        perm = (0,) + tuple(range(2, 2 + nd)) + (1,) + tuple(range(2 + nd, 2 + 2 * nd))
+        col = v.permute(perm).reshape(nb * nout, Cs * kk)            # materialises im2col
+        G = g[b0:b0 + bchunk].permute((1, 0) + tuple(range(2, 2 + nd))).reshape(Cg, nb * nout)
+        part = _splitk_matmul(G, col)
+        dW = part if dW is None else dW + part
+    return dW.view((Cg, Cs) + tuple(k))
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, transposed):
+        nd = x.dim() - 2
+        if transposed:
+            y = (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
+        else:
+            y = (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, padding)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, transposed, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, transposed, has_bias = ctx.cfg
+        nd = x.dim() - 2
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:  # MIOpen backward-data (fast)
+            gx = torch.ops.aten.convolution_backward(
+                gy, x, w, None, list(stride), list(padding), [1] * nd, transposed, [0] * nd, 1,
+                [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            k = tuple(w.shape[2:])
+            if transposed:
+                # y = conv_transpose(x, w[Cin,Cout,k]):  dW[ci,co,k] = sum x[b,ci,i] * gy[b,co,i*s+k-p]
+                gw = _wrw_from_patches(gy, x, k, stride, padding)  # [Cin, Cout, *k]
+            else:
+                gw = _wrw_from_patches(x, gy, k, stride, padding)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(0,) + tuple(range(2, 2 + nd)))
+        return gx, gw, gb, None, None, None
+
+
+def _use_gemm(x):
+    return _MODE == "gemm" and x.is_cuda and torch.is_grad_enabled()
+
+
+class Conv3d(nn.Conv3d):
+    def forward(self, x):
+        if not _use_gemm(x):
+            return super().forward(x)
+        return _ConvFn.apply(x, self.weight, self.bias, _tuple(self.stride, 3), _tuple(self.padding, 3), False)
+
+
+class ConvTranspose3d(nn.ConvTranspose3d):
+    def forward(self, x):
+        if not _use_gemm(x):
+            return super().forward(x)
+        return _ConvFn.apply(x, self.weight, self.bias, _tuple(self.stride, 3), _tuple(self.padding, 3), True)

@@ -13,10 +13,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import convgrad, ops
 
-_CONV = {2: nn.Conv2d, 3: nn.Conv3d}
-_DECONV = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
+# 3-D layers: torch.nn modules whose WEIGHT gradient is an im2col + split-K GEMM (convgrad.py);
+# forward and input gradient stay on MIOpen
+_CONV = {2: nn.Conv2d, 3: convgrad.Conv3d}
+_DECONV = {2: nn.ConvTranspose2d, 3: convgrad.ConvTranspose3d}
 _INTERP = {2: "bilinear", 3: "trilinear"}
 
 
