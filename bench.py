@@ -144,15 +144,21 @@ def main():
     barrier()
     ops.enable_kernel_timing(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_marks[0].record()
+    for i in range(args.steps):
         pred, info = model.update(imgs, gt, learning_rate=lr, training=True)
+        step_marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
     ktimes = ops.kernel_timings()
     ops.enable_kernel_timing(False)
     loss = float(info["loss_G"].detach())
     if rank == 0:
-        log("timed region: %d steps in %.3f s" % (args.steps, dt))
+        log("timed region: %d steps in %.3f s; per-step ms: %s; peak HBM %.1f GB" % (
+            args.steps, dt, " ".join("%.0f" % step_marks[i].elapsed_time(step_marks[i + 1])
+                                     for i in range(args.steps)),
+            torch.cuda.max_memory_allocated() / 2 ** 30))
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -189,6 +189,17 @@ int fs_distill_bwd(const float* merged_i, const float* merged_tea, const float* 
                    const float* flow_i, const float* flow_tea, const float* coef,
                    float* grad_flow_i, int B, int C, int F, int S, fs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * §8f.1  Backward of the trilinear resizes inside IFBlock (Flow-3D/model/IFNet.py:85,88,118-119):
+ * F.interpolate(mode="trilinear", align_corners=False, scale_factor = `factor` (upsample = 1) or
+ * 1/`factor` (upsample = 0)), factor in {2, 4}.  grad_out [B,C,Dout,Hout,Wout] ->
+ * grad_in [B,C,Din,Hin,Win], with out = in*factor (up) or in/factor (down, floor).
+ * Gather-formulated adjoint (ATen scatters with atomics): no atomics, reproducible.
+ */
+int fs_interp3d_bwd(const float* grad_out, float* grad_in, int B, int C,
+                    int Din, int Hin, int Win, int Dout, int Hout, int Wout,
+                    int factor, int upsample, fs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

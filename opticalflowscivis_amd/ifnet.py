@@ -37,6 +37,8 @@ def _resize(t, factor, mode):
         # scale_factor=1 with align_corners=False reproduces its input exactly (source index ==
         # destination index, weights (1, 0)); the reference still launches it.  Skip the pass.
         return t
+    if mode == "trilinear":
+        return ops.interpolate3d(t, factor)  # ATen forward, HIP gather backward (no atomics)
     return F.interpolate(t, scale_factor=factor, mode=mode, align_corners=False,
                          recompute_scale_factor=False)
 
@@ -70,11 +72,10 @@ class IFBlock(nn.Module):
     def forward(self, x, flow, scale):
         mode = _INTERP[self.nd]
         if scale != 1:
-            x = F.interpolate(x, scale_factor=1. / scale, mode=mode, align_corners=False)
+            x = _resize(x, 1. / scale, mode)
         if flow is not None:
             if scale != 1:
-                flow = F.interpolate(flow, scale_factor=1. / scale, mode=mode,
-                                     align_corners=False) * 1. / scale
+                flow = _resize(flow, 1. / scale, mode) * 1. / scale
             x = torch.cat((x, flow), 1)
         x = self.conv0(x)
         x = self.convblock0(x) + x

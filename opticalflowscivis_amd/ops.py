@@ -582,3 +582,41 @@ def distill_term(merged_i, merged_teacher, gt, flow_i, flow_teacher):
     """One block's term of loss_distill; gradient reaches flow_i only (the reference detaches the
     teacher flow and the loss mask)."""
     return _Distill.apply(merged_i, merged_teacher, gt, flow_i, flow_teacher)
+
+
+# --------------------------------------------------------------------------------------------
+# §8f.1: trilinear resize of IFBlock with a gather-formulated HIP backward
+# --------------------------------------------------------------------------------------------
+class _Interp3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, factor, up):
+        sf = float(factor) if up else 1.0 / factor
+        y = torch.nn.functional.interpolate(x, scale_factor=sf, mode="trilinear", align_corners=False,
+                                            recompute_scale_factor=False)
+        ctx.cfg = (tuple(x.shape), int(factor), bool(up))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, factor, up = ctx.cfg
+        gy = _need_cuda_f32("grad_output", gy, 5)
+        gx = gy.new_empty(shape)
+        B, C, Di, Hi, Wi = shape
+        Do, Ho, Wo = gy.shape[2:]
+        with torch.cuda.device(gy.device):
+            _call("fs_interp3d_bwd", gy.data_ptr(), gx.data_ptr(), B, C, Di, Hi, Wi, Do, Ho, Wo, factor,
+                  1 if up else 0, _stream(gy))
+        return gx, None, None
+
+
+def interpolate3d(x, scale_factor):
+    """F.interpolate(x, scale_factor, mode="trilinear", align_corners=False) for the IFBlock factors
+    (4, 2, 1/2, 1/4): ATen forward, HIP gather backward.  Other factors: stock autograd."""
+    for f in (2, 4):
+        if scale_factor == f or scale_factor == 1.0 / f:
+            up = scale_factor > 1
+            ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
+            if ok:
+                return _Interp3D.apply(x.contiguous(), f, up)
+    return torch.nn.functional.interpolate(x, scale_factor=scale_factor, mode="trilinear",
+                                           align_corners=False, recompute_scale_factor=False)

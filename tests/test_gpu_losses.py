@@ -166,3 +166,20 @@ def test_merge_distill_l1_vs_oracle(ops, shape):
     assert abs(float(lh) - float(lo)) < 2e-6 * max(1.0, abs(float(lo)))
     for x, y in zip(rh, ro):
         assert relerr(x, y) < 2e-4
+
+
+@pytest.mark.parametrize("shape,sf", [((2, 3, 8, 12, 16), 4.0), ((1, 6, 10, 6, 8), 2.0), ((2, 5, 16, 24, 32), 0.25),
+                                      ((1, 2, 12, 20, 8), 0.5), ((1, 1, 9, 11, 14), 0.5), ((1, 2, 13, 10, 9), 0.25)])
+def test_interpolate3d_backward_vs_aten(ops, shape, sf):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g)
+    a = x.clone().requires_grad_()
+    ref = torch.nn.functional.interpolate(a, scale_factor=sf, mode="trilinear", align_corners=False)
+    G = torch.randn(ref.shape, generator=g)
+    (ga,) = torch.autograd.grad((ref * G).sum(), [a])
+    b = x.to(DEV).requires_grad_()
+    out = ops.interpolate3d(b, sf)
+    (gb,) = torch.autograd.grad((out * G.to(DEV)).sum(), [b])
+    assert out.shape == ref.shape
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5
+    assert float((gb.cpu() - ga).abs().max()) < 1e-5 * max(1.0, float(ga.abs().max()))
