@@ -200,6 +200,18 @@ int fs_interp3d_bwd(const float* grad_out, float* grad_in, int B, int C,
                     int Din, int Hin, int Win, int Dout, int Hout, int Wout,
                     int factor, int upsample, fs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Backward of torch.nn.PReLU(num_parameters = C or 1) as used after every IFNet convolution
+ * (`conv()` in Flow-2D/model/IFNet.py and Flow-3D/model/IFNet.py):  y = x > 0 ? x : a[c] x.
+ *   grad_x[e] = x > 0 ? g : a[c] g ;  grad_weight[c] = sum_{b,spatial} (x > 0 ? 0 : x g).
+ * x, grad_out, grad_x [B,C,S]; weight, grad_weight [num_weights]; ws: device scratch of
+ * B*C*FS_PRELU_MAX_CHUNKS floats.  One pass + a tiny deterministic finishing kernel.
+ */
+#define FS_PRELU_MAX_CHUNKS 64
+int fs_prelu_bwd(const float* x, const float* grad_out, const float* weight,
+                 float* grad_x, float* grad_weight, float* ws,
+                 int B, int C, int S, int num_weights, fs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

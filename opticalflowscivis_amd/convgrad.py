@@ -130,3 +130,13 @@ class ConvTranspose3d(nn.ConvTranspose3d):
         if not _use_gemm(x):
             return super().forward(x)
         return _ConvFn.apply(x, self.weight, self.bias, _tuple(self.stride, 3), _tuple(self.padding, 3), True)
+
+
+class PReLU(nn.PReLU):
+    """torch.nn.PReLU with the one-pass HIP backward (csrc/prelu.hip); same parameters / keys."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.dim() >= 3:
+            from . import ops
+            return ops.prelu(x, self.weight)
+        return super().forward(x)

@@ -24,11 +24,11 @@ _INTERP = {2: "bilinear", 3: "trilinear"}
 
 def _conv(nd, cin, cout, kernel_size=3, stride=1, padding=1):
     return nn.Sequential(_CONV[nd](cin, cout, kernel_size, stride, padding, bias=True),
-                         nn.PReLU(cout))
+                         convgrad.PReLU(cout))
 
 
 def _head(nd, c, cout):
-    return nn.Sequential(_DECONV[nd](c, c // 2, 4, 2, 1), nn.PReLU(c // 2),
+    return nn.Sequential(_DECONV[nd](c, c // 2, 4, 2, 1), convgrad.PReLU(c // 2),
                          _DECONV[nd](c // 2, cout, 4, 2, 1))
 
 

@@ -620,3 +620,35 @@ def interpolate3d(x, scale_factor):
                 return _Interp3D.apply(x.contiguous(), f, up)
     return torch.nn.functional.interpolate(x, scale_factor=scale_factor, mode="trilinear",
                                            align_corners=False, recompute_scale_factor=False)
+
+
+# --------------------------------------------------------------------------------------------
+# PReLU after every IFNet convolution: ATen forward, one-pass HIP backward
+# --------------------------------------------------------------------------------------------
+_PRELU_MAX_CHUNKS = 64
+
+
+class _PReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        y = torch.nn.functional.prelu(x, weight)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        x = _need_cuda_f32("x", x, x.dim())
+        gy = _need_cuda_f32("grad_output", gy, x.dim())
+        B, C, S = _flat3(x)
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(weight)
+        ws = x.new_empty(B * C * _PRELU_MAX_CHUNKS)
+        with torch.cuda.device(x.device):
+            _call("fs_prelu_bwd", x.data_ptr(), gy.data_ptr(), weight.data_ptr(), gx.data_ptr(),
+                  gw.data_ptr(), ws.data_ptr(), B, C, S, weight.numel(), _stream(x))
+        return gx, gw
+
+
+def prelu(x, weight):
+    return _PReLU.apply(x, weight)

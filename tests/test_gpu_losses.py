@@ -183,3 +183,18 @@ def test_interpolate3d_backward_vs_aten(ops, shape, sf):
     assert out.shape == ref.shape
     assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5
     assert float((gb.cpu() - ga).abs().max()) < 1e-5 * max(1.0, float(ga.abs().max()))
+
+
+@pytest.mark.parametrize("shape,nw", [((2, 5, 7, 9, 11), 5), ((1, 3, 40, 56), 3), ((2, 4, 33, 1030), 1),
+                                      ((2, 8, 16, 32, 64), 8)])
+def test_prelu_backward_vs_aten(ops, shape, nw):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(shape, generator=g)
+    w = torch.rand(nw, generator=g) * 0.5
+    G = torch.randn(shape, generator=g)
+    a, wa = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ra, rw = torch.autograd.grad((torch.nn.functional.prelu(a, wa) * G).sum(), [a, wa])
+    b, wb = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    gb, gw = torch.autograd.grad((ops.prelu(b, wb) * G.to(DEV)).sum(), [b, wb])
+    assert torch.equal(gb.cpu(), ra)
+    assert float((gw.cpu() - rw).abs().max()) < 1e-4 * max(1.0, float(rw.abs().max()))
