@@ -8,6 +8,7 @@ Usage (each group imports a different reference package layout, so one process p
     python tests/golden/make_golden.py upflow_ops   # Corr_pyTorch, warps, census, photo losses
     python tests/golden/make_golden.py flow3d_e2e   # Flow-3D Model.update / inference
     python tests/golden/make_golden.py flow2d_e2e   # Flow-2D Model.update / inference
+    python tests/golden/make_golden.py upflow_e2e   # UPFlow_net forward losses / flows / grads
     python tests/golden/make_golden.py all          # runs the groups above as subprocesses
 
 Third-party modules the reference imports at module scope but that are absent from this
@@ -281,7 +282,46 @@ def flow2d_e2e():
     print("wrote flow2d_e2e.npz; keys", keys, "losses", losses)
 
 
-GROUPS = dict(rife_ops=rife_ops, upflow_ops=upflow_ops, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e)
+def upflow_e2e():
+    _install_stubs()
+    sys.path[:0] = [REF + "/UPFlow"]
+    import model.upflow as U
+    U.device = torch.device("cpu")
+    conf = U.UPFlow_net.config()
+    _quiet(conf.update, {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+                         'norm_moments_across_images': False, 'if_use_cor_pytorch': True,
+                         'if_sgu_upsample': False, 'photo_loss_census_weight': 1,
+                         'multi_scale_distillation_weight': 1})
+    torch.manual_seed(0)
+    net = _quiet(conf)
+    # a smooth moving pattern (so that flows / occlusion masks are not pure noise), seeded
+    gen = torch.Generator().manual_seed(4)
+    H, W = 128, 192
+    base = torch.nn.functional.interpolate(torch.rand(2, 3, H // 8, W // 8 + 2, generator=gen), size=(H, W + 16),
+                                           mode="bicubic", align_corners=True).clamp(0, 1)
+    im1, im2 = base[:, :, :, :W].contiguous(), base[:, :, :, 3:W + 3].contiguous()
+    store = dict(im1=_np(im1), im2=_np(im2))
+    store["nparam"] = np.array(sum(p.numel() for p in net.parameters()))
+    store["param_sums"] = np.array([float(p.detach().double().sum()) for p in net.parameters()])
+    out = _quiet(net, {'im1': im1.numpy(), 'im2': im2.numpy(), 'if_loss': True})
+    ld = out['loss_dict']
+    keys = ['photo_loss', 'smooth_loss', 'census_loss', 'msd_loss']
+    store["loss_keys"] = np.array(keys)
+    store["losses"] = np.array([float(ld[k]) for k in keys])
+    store["flow_f_out"] = _np(out['flow_f_out'])
+    store["flow_b_out"] = _np(out['flow_b_out'])
+    store["occ_fw"] = _np(out['occ_fw'])
+    store["im1_warp"] = _np(out['im1_warp'])
+    total = sum(ld[k] for k in keys)
+    total.backward()
+    store["grad_abs_sums"] = np.array([float(p.grad.detach().double().abs().sum()) if p.grad is not None else 0.0
+                                       for p in net.parameters()])
+    np.savez_compressed(os.path.join(OUT, "upflow_e2e.npz"), **store)
+    print("wrote upflow_e2e.npz; losses", dict(zip(keys, store["losses"])), "nparam", int(store["nparam"]))
+
+
+GROUPS = dict(rife_ops=rife_ops, upflow_ops=upflow_ops, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
+              upflow_e2e=upflow_e2e)
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"

@@ -80,3 +80,56 @@ def test_flow3d_vs_oracle_droplet():
         _, pi = m.update(imgs.to(DEV), gt.to(DEV), learning_rate=1e-4)
         for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G"):
             assert abs(float(pi[k]) - float(oi[k])) < 5e-4 * max(1.0, abs(float(oi[k]))), k
+
+
+def test_upflow_matches_reference_golden(golden):
+    """UPFlow_net (HIP correlation / warps / census / photo losses, MIOpen convs) against the
+    reference's forward + backward on identical weights (same seed) and inputs."""
+    from opticalflowscivis_amd.upflow.model.upflow import UPFlow_net
+    g = golden("upflow_e2e")
+    conf = UPFlow_net.config()
+    conf.update({'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+                 'norm_moments_across_images': False, 'photo_loss_census_weight': 1,
+                 'multi_scale_distillation_weight': 1})
+    torch.manual_seed(0)
+    net = conf()
+    np.testing.assert_allclose(_psums(net), g["param_sums"], rtol=0, atol=1e-9)
+    net = net.to(DEV)
+    out = net({'im1': torch.from_numpy(g["im1"]), 'im2': torch.from_numpy(g["im2"]), 'if_loss': True})
+    ref_f = torch.from_numpy(g["flow_f_out"])
+    scale = float(ref_f.abs().max())
+    # UPFlow is chaotic at fp32 level: WarpingLayer_no_div zeroes a feature pixel when its fp32 weight
+    # sum is < 1.0, which on ~1-2 % of in-bounds pixels is decided by the last ulp (SURVEY §7), at
+    # each of 4 pyramid levels.  The reference's OWN torch ops run on this GPU deviate from its CPU
+    # result by median 0.20 px / max 2.0 px at a flow scale of 68 px (measured, scripts/dbg_upflow.py);
+    # the HIP path lands in the same band (median 0.20 / max 2.7).  So the end-to-end check is a band,
+    # not an epsilon; the ops themselves are pinned tightly in test_gpu_warps / test_gpu_losses.
+    err = (out['flow_f_out'].detach().cpu() - ref_f).abs()
+    assert float(err.median()) < 0.01 * scale
+    assert float(err.flatten().quantile(0.99)) < 0.05 * scale
+    occ_ref = torch.from_numpy(g["occ_fw"])
+    assert float((out['occ_fw'].cpu() != occ_ref).float().mean()) < 1e-2
+    keys = [str(k) for k in g["loss_keys"]]
+    got = np.array([float(out['loss_dict'][k]) for k in keys])
+    np.testing.assert_allclose(got, g["losses"], rtol=5e-3)
+    sum(out['loss_dict'][k] for k in keys).backward()
+    gsum = np.array([float(p.grad.detach().double().abs().sum()) if p.grad is not None else 0.0
+                     for p in net.parameters()])
+    # gradient magnitude per parameter tensor: same band (these sums move with every flipped mask pixel)
+    rel = np.abs(gsum - g["grad_abs_sums"]) / (np.abs(g["grad_abs_sums"]) + 1e-3)
+    assert np.median(rel) < 0.05 and rel.max() < 0.5
+
+
+def test_upflow_c3_train_step_runs():
+    """BASELINE config C3 shape (150 x 450, census on) through one optimiser step, B=4."""
+    from opticalflowscivis_amd.upflow.scripts.simple_train import Trainer
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        conf = Trainer.Config(n_epoch=1, batchsize=4, batch_per_epoch=2, exp_dir=d)
+        conf.net_params = dict(conf.net_params, photo_loss_census_weight=1, multi_scale_distillation_weight=1)
+        torch.manual_seed(0)
+        tr = Trainer(conf, device=DEV)
+        before = _psums(tr.net)
+        tr.training()
+        after = _psums(tr.net)
+        assert np.isfinite(after).all() and not np.allclose(before, after)
