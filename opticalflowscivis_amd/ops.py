@@ -266,8 +266,8 @@ def rife2d_photometric(flow4, merged, img0, img1):
     have and are exact identities."""
     def term(flow2, frame):
         w = warp2d_photo(merged, flow2)
-        p = torch.pow(torch.pow(w - frame, 2) + 1.e-9 ** 2, 0.25)
-        return torch.sum(torch.sum(p, dim=1) / 3) / frame.size(0)
+        # charbonnier(x, 0.25, 1e-9) = (x^2 + 1e-18)^0.25, summed, / 3 / B: one fused penalty+reduction
+        return robust_loss(w, frame, None, PEN_CHARBONNIER, 0.25, 1.e-9 ** 2, form="sum") / 3 / frame.size(0)
 
     return (term(flow4[:, 2:4], img0) + term(flow4[:, :2], img1)) / 2
 
