@@ -113,3 +113,46 @@ def psnr(pred, gt):
     """PSNR on [0,1] data: -10 log10(mean((pred-gt)^2)) (Flow-3D/train.py:385)."""
     mse = torch.mean((pred.double() - gt.double()) ** 2)
     return float(-10.0 * math.log10(max(float(mse), 1e-20)))
+
+
+def rectangle2d_sequence(n_frames=64, seed=1234, grid=(128, 128), box=(60, 80), tile=10, vel=(-6, 6),
+                         max_seq=15):
+    """Seeded restatement of Datasets/create_rectangle_2d.py:81-199 (BASELINE config C1): a box of
+    `tile`-sized patches with values randint(30,256)/255 bouncing on a `grid`; the velocity is
+    re-drawn every `max_seq` steps or when a wall is hit.  Keeps the original's axis swap
+    (pos_x += vel_y, pos_y += vel_x, :165-167).  The original is unseeded and blocks on input();
+    here numpy's and random's streams are replaced by one seeded numpy Generator.
+    Returns (frames [T,H,W] float32 in [0,1], vel_x [T,H,W], vel_y [T,H,W])."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    gx, gy = grid
+    bx, by = box
+    b = np.ones((bx, by), dtype=np.float32)
+    for i in range(0, bx, tile):
+        for j in range(0, by, tile):
+            b[i:i + tile, j:j + tile] = rng.integers(30, 256) / 255.0
+    frames = np.zeros((n_frames, gx, gy), dtype=np.float32)
+    vxs = np.zeros_like(frames)
+    vys = np.zeros_like(frames)
+    px, py = int(rng.integers(0, gx - bx + 1)), int(rng.integers(0, gy - by + 1))
+    vx, vy = int(rng.integers(vel[0], vel[1] + 1)), int(rng.integers(vel[0], vel[1] + 1))
+    seq = max_seq
+    for t in range(n_frames):
+        if seq == 0:
+            vx, vy = int(rng.integers(vel[0], vel[1] + 1)), int(rng.integers(vel[0], vel[1] + 1))
+            seq = max_seq
+        px = min(max(px + vy, 0), gx - bx)
+        py = min(max(py + vx, 0), gy - by)
+        frames[t, px:px + bx, py:py + by] = b
+        vxs[t, px:px + bx, py:py + by] = vx
+        vys[t, px:px + bx, py:py + by] = vy
+        seq -= 1
+        if px == 0 or py == 0 or px == gx - bx or py == gy - by:
+            seq = 0
+    return torch.from_numpy(frames), torch.from_numpy(vxs), torch.from_numpy(vys)
+
+
+def rectangle2d_triplet(t=0, seed=1234):
+    """(img0, img1, gt) = frames (t, t+2, t+1) as [1,3,128,128] (C1: pair + middle frame)."""
+    f, _, _ = rectangle2d_sequence(t + 3, seed)
+    return torch.stack([f[t], f[t + 2], f[t + 1]], 0).unsqueeze(0)
