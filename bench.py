@@ -34,6 +34,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 BYTES_PER_VOXEL = {"fs_warp3d_pair_fwd": 2 * 20, "fs_warp3d_pair_bwd": 2 * 32}
 
 
+def pmc_traffic(kernel, S, B):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950,
+    WRITE_SIZE x1, as MI355X_MICROARCH.md prescribes); only valid for the workload they were taken on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_warp3d_pmc_traffic.json")) as f:
+            d = json.load(f)
+        if S == 256 and B == 2:
+            return d["kernels"][kernel]["hbm_bytes_corrected"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,7 +185,7 @@ def main():
             gbs = BYTES_PER_VOXEL.get(name, 0) * nvox / (avg * 1e-3) / 1e9
             kern[name] = {"launches": len(ms), "avg_ms": round(avg, 4), "algo_GBps": round(gbs, 1)}
         # dominant hand-written kernel = the one with the largest total time in the timed region
-        dom = max(ktimes, key=lambda k: sum(ktimes[k]))
+        dom = max((k for k in ktimes if k in BYTES_PER_VOXEL), key=lambda k: sum(ktimes[k]))
         out = {
             "metric": "volume-pairs/sec, Flow-3D unsupervised train step (fwd+loss+bwd+AdamW)",
             "value": world * B * args.steps / dt,
@@ -188,7 +201,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom + " (warp3d_%s_kernel)" %
                          ("bwd" if dom.endswith("bwd") else "fwd"),
                          "achieved": kern[dom]["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(kern[dom]["algo_GBps"] / HBM_PEAK_GBS, 4), "traffic": None},
+                         "frac": round(kern[dom]["algo_GBps"] / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(dom, S, B)},
             "kernels": kern,
             "loss_G": loss,
         }
