@@ -28,10 +28,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 
-# algorithmic HBM bytes per voxel of ONE warp (DESIGN.md "warp3d"):
-#   fwd: 12 flow + 4 gather + 4 store = 20;  bwd (grad_flow only; images carry no grad in
-#   training): 12 flow + 4 gather + 4 grad_out + 12 grad_flow = 32.  A pair launch does two warps.
-BYTES_PER_VOXEL = {"fs_warp3d_pair_fwd": 2 * 20, "fs_warp3d_pair_bwd": 2 * 32}
+# Algorithmic (compulsory) HBM bytes per launch are supplied by ops.py next to every C-ABI call
+# (DESIGN.md §4): e.g. one warp3d pair launch = 2 warps x 20 B/voxel forward (12 flow + 4 gather +
+# 4 store) or 2 x 32 B/voxel backward (12 flow + 4 gather + 4 grad_out + 12 grad_flow; the images
+# carry no gradient in training).
 
 
 def pmc_traffic(kernel, S, B):
@@ -178,14 +178,15 @@ def main():
     dt = float(t.item())
 
     if rank == 0:
-        nvox = B * S ** 3
         kern = {}
-        for name, ms in ktimes.items():
-            avg = sum(ms) / len(ms)
-            gbs = BYTES_PER_VOXEL.get(name, 0) * nvox / (avg * 1e-3) / 1e9
-            kern[name] = {"launches": len(ms), "avg_ms": round(avg, 4), "algo_GBps": round(gbs, 1)}
+        for name, recs in ktimes.items():
+            tot_ms = sum(r[0] for r in recs)
+            tot_b = sum(r[1] for r in recs)
+            kern[name] = {"launches": len(recs), "avg_ms": round(tot_ms / len(recs), 4),
+                          "ms_per_step": round(tot_ms / args.steps, 3),
+                          "algo_GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
         # dominant hand-written kernel = the one with the largest total time in the timed region
-        dom = max((k for k in ktimes if k in BYTES_PER_VOXEL), key=lambda k: sum(ktimes[k]))
+        dom = max(ktimes, key=lambda k: sum(r[0] for r in ktimes[k]))
         out = {
             "metric": "volume-pairs/sec, Flow-3D unsupervised train step (fwd+loss+bwd+AdamW)",
             "value": world * B * args.steps / dt,
@@ -198,8 +199,7 @@ def main():
                                    "3D trilinear warp HIP kernels" % (args.dataset, S, B),
                        "global_batch": world * B, "volume": [S, S, S],
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": dom + " (warp3d_%s_kernel)" %
-                         ("bwd" if dom.endswith("bwd") else "fwd"),
+            "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": kern[dom]["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(kern[dom]["algo_GBps"] / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(dom, S, B)},

@@ -195,8 +195,10 @@ int fs_distill_bwd(const float* merged_i, const float* merged_tea, const float* 
  * 1/`factor` (upsample = 0)), factor in {2, 4}.  grad_out [B,C,Dout,Hout,Wout] ->
  * grad_in [B,C,Din,Hin,Win], with out = in*factor (up) or in/factor (down, floor).
  * Gather-formulated adjoint (ATen scatters with atomics): no atomics, reproducible.
+ * ws: device scratch for the up-sampling case, B*C*(Dout*Hout*Win + Dout*Hin*Win) floats (the
+ * adjoint then runs as three separable 1-D passes); NULL selects the single-pass kernel.
  */
-int fs_interp3d_bwd(const float* grad_out, float* grad_in, int B, int C,
+int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws, int B, int C,
                     int Din, int Hin, int Win, int Dout, int Hout, int Wout,
                     int factor, int upsample, fs_stream_t stream);
 

@@ -83,10 +83,80 @@ __global__ __launch_bounds__(256) void interp3d_adjoint_kernel(const float* __re
   }
 }
 
+// ---- fast paths ---------------------------------------------------------------------------
+// Down-sampling by s with in == s * out: output o reads exactly the two inputs s*o + s/2 - 1 and
+// s*o + s/2 with weight 1/2 per axis, so a fine voxel has at most one contributor: pure streaming.
+__global__ __launch_bounds__(256) void interp3d_down_adjoint_exact(const float* __restrict__ gout,
+                                                                  float* __restrict__ gin, IP p) {
+  const long long nin = (long long)p.Di * p.Hi * p.Wi;
+  const long long nout = (long long)p.Do * p.Ho * p.Wo;
+  const long long total = p.nBC * nin;
+  const int lo = p.s / 2 - 1, hi = p.s / 2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long bc = e / nin;
+    const int r = (int)(e - bc * nin);
+    const int x = r % p.Wi, y = (r / p.Wi) % p.Hi, z = r / (p.Wi * p.Hi);
+    const int rx = x % p.s, ry = y % p.s, rz = z % p.s;
+    float v = 0.f;
+    if ((rx == lo || rx == hi) && (ry == lo || ry == hi) && (rz == lo || rz == hi))
+      v = 0.125f * gout[bc * nout + ((long long)(z / p.s) * p.Ho + (y / p.s)) * p.Wo + (x / p.s)];
+    gin[e] = v;
+  }
+}
+
+// Up-sampling adjoint as three separable 1-D passes (x, then y, then z): every fine gradient is
+// read from HBM once and the per-voxel gather count drops from NC^3 to NC per pass (the direct
+// kernel is bound by the 4-lanes-per-clock address path, not by HBM).
+//   g [outer, n_out, inner] -> out [outer, n_in, inner],  out[., i, .] = sum_o w(o, i) g[., o, .]
+template <int NC>
+__global__ __launch_bounds__(256) void interp_axis_adjoint_kernel(const float* __restrict__ g,
+                                                                  float* __restrict__ out,
+                                                                  long long outer, int n_out, int n_in,
+                                                                  int inner, int s, float rs) {
+  const long long total = outer * n_in * inner;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int in_i = (int)(e % inner);
+    const long long t = e / inner;
+    const int i = (int)(t % n_in);
+    const long long ou = t / n_in;
+    const int o0 = s * i - s / 2;
+    const float* col = g + (ou * n_out) * inner + in_i;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float w = axis_w(o0 + k, i, n_in, n_out, rs);
+      const int o = min(max(o0 + k, 0), n_out - 1);
+      acc = fmaf(w, col[(long long)o * inner], acc);
+    }
+    out[e] = acc;
+  }
+}
+
+unsigned grid_for(long long total) {
+  const long long want = (total + 255) / 256;
+  return (unsigned)(want < (1 << 20) ? want : (1 << 20));
+}
+
+template <int NC>
+void up_adjoint_separable(const float* gout, float* gin, float* ws, const IP& p, hipStream_t st) {
+  const long long nbc = p.nBC;
+  float* t1 = ws;                                              // [BC, Do, Ho, Wi]
+  float* t2 = ws + nbc * p.Do * p.Ho * p.Wi;                   // [BC, Do, Hi, Wi]
+  long long tot = nbc * p.Do * p.Ho * p.Wi;
+  hipLaunchKernelGGL(interp_axis_adjoint_kernel<NC>, dim3(grid_for(tot)), dim3(256), 0, st, gout, t1,
+                     nbc * p.Do * p.Ho, p.Wo, p.Wi, 1, p.s, p.rs);
+  tot = nbc * p.Do * p.Hi * p.Wi;
+  hipLaunchKernelGGL(interp_axis_adjoint_kernel<NC>, dim3(grid_for(tot)), dim3(256), 0, st, t1, t2,
+                     nbc * p.Do, p.Ho, p.Hi, p.Wi, p.s, p.rs);
+  tot = nbc * p.Di * p.Hi * p.Wi;
+  hipLaunchKernelGGL(interp_axis_adjoint_kernel<NC>, dim3(grid_for(tot)), dim3(256), 0, st, t2, gin, nbc,
+                     p.Do, p.Di, p.Hi * p.Wi, p.s, p.rs);
+}
+
 }  // namespace
 
-extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, int B, int C, int Din, int Hin,
-                               int Win, int Dout, int Hout, int Wout, int factor, int upsample,
+extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws, int B, int C, int Din,
+                               int Hin, int Win, int Dout, int Hout, int Wout, int factor, int upsample,
                                fs_stream_t stream) {
   FS_REQUIRE_PTR(grad_out); FS_REQUIRE_PTR(grad_in);
   if (B < 1 || C < 1 || Din < 1 || Hin < 1 || Win < 1 || Dout < 1 || Hout < 1 || Wout < 1)
@@ -107,15 +177,24 @@ extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, int B, int
     if (Dout != Din / factor || Hout != Hin / factor || Wout != Win / factor) return FS_ERR_SHAPE;
   }
   const long long total = p.nBC * Din * Hin * Win;
-  const long long want = (total + 255) / 256;
-  const unsigned nb = (unsigned)(want < (1 << 20) ? want : (1 << 20));
   hipStream_t st = (hipStream_t)stream;
-  if (!upsample)
-    hipLaunchKernelGGL(interp3d_adjoint_kernel<3>, dim3(nb), dim3(256), 0, st, grad_out, grad_in, p);
-  else if (factor == 2)
-    hipLaunchKernelGGL(interp3d_adjoint_kernel<4>, dim3(nb), dim3(256), 0, st, grad_out, grad_in, p);
-  else
-    hipLaunchKernelGGL(interp3d_adjoint_kernel<8>, dim3(nb), dim3(256), 0, st, grad_out, grad_in, p);
+  if (!upsample) {
+    if (Din == Dout * factor && Hin == Hout * factor && Win == Wout * factor)
+      hipLaunchKernelGGL(interp3d_down_adjoint_exact, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
+                         grad_in, p);
+    else
+      hipLaunchKernelGGL(interp3d_adjoint_kernel<3>, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
+                         grad_in, p);
+  } else if (ws != nullptr) {
+    if (factor == 2) up_adjoint_separable<4>(grad_out, grad_in, ws, p, st);
+    else up_adjoint_separable<8>(grad_out, grad_in, ws, p, st);
+  } else if (factor == 2) {
+    hipLaunchKernelGGL(interp3d_adjoint_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
+                       grad_in, p);
+  } else {
+    hipLaunchKernelGGL(interp3d_adjoint_kernel<8>, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
+                       grad_in, p);
+  }
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

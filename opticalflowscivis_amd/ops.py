@@ -54,14 +54,16 @@ def enable_kernel_timing(on=True):
 
 
 def kernel_timings():
-    """{entry point: [ms per launch]} for the launches recorded so far (synchronises)."""
+    """{entry point: [(ms, algorithmic HBM bytes) per launch]} recorded so far (synchronises)."""
     if _timing is None:
         return {}
     torch.cuda.synchronize()
-    return {k: [a.elapsed_time(b) for a, b in v] for k, v in _timing.items()}
+    return {k: [(a.elapsed_time(b), nb) for a, b, nb in v] for k, v in _timing.items()}
 
 
-def _call(name, *args):
+def _call(name, *args, algo_bytes=0):
+    """Launch a C-ABI entry point.  `algo_bytes` = compulsory HBM bytes of this launch,
+    only used by the optional timing records."""
     fn = getattr(_lib.lib(), name)
     if _timing is None:
         _lib.check(fn(*args), name)
@@ -72,7 +74,7 @@ def _call(name, *args):
     code = fn(*args)
     e1.record()
     _lib.check(code, name)
-    _timing.setdefault(name, []).append((e0, e1))
+    _timing.setdefault(name, []).append((e0, e1, algo_bytes))
 
 
 # --------------------------------------------------------------------------------------------
@@ -215,7 +217,7 @@ class _WarpPair(torch.autograd.Function):
                 D, H, W = flow.shape[2:]
                 _call("fs_warp3d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
                       out0.data_ptr(), out1.data_ptr(), B, C, _in_dhw(img0, flow), D, H, W,
-                      _stream(flow))
+                      _stream(flow), algo_bytes=4 * flow.numel() + 8 * out0.numel() * 2)
             else:
                 B, C, H, W = img0.shape
                 _call("fs_warp2d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
@@ -241,7 +243,8 @@ class _WarpPair(torch.autograd.Function):
                 D, H, W = flow.shape[2:]
                 _call("fs_warp3d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
                       g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), _ptr(gflow), B, C,
-                      _in_dhw(img0, flow), D, H, W, _stream(flow))
+                      _in_dhw(img0, flow), D, H, W, _stream(flow),
+                      algo_bytes=8 * flow.numel() + 8 * g0.numel() * 2 + (8 * img0.numel() if need_img else 0))
             else:
                 B, C, H, W = img0.shape
                 _call("fs_warp2d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
@@ -368,7 +371,8 @@ class _RobustLoss(torch.autograd.Function):
         ws = x.new_empty(2 * _REDUCE_BLOCKS)
         with torch.cuda.device(x.device):
             _call("fs_robust_sum", x.data_ptr(), _ptr(y), _ptr(w), sums.data_ptr(), ws.data_ptr(),
-                  B, C, S, H, W, border, mode, float(q), float(eps), _stream(x))
+                  B, C, S, H, W, border, mode, float(q), float(eps), _stream(x),
+                  algo_bytes=4 * x.numel() * (2 if y is not None else 1))
         S1, S2 = sums[0], sums[1]
         n = float(B * C * S)
         if form == "mean":
@@ -405,7 +409,8 @@ class _RobustLoss(torch.autograd.Function):
         gy = torch.empty_like(x) if need_y else None
         with torch.cuda.device(x.device):
             _call("fs_robust_sum_bwd", x.data_ptr(), _ptr(y), _ptr(w), coef.data_ptr(), _ptr(gx),
-                  _ptr(gy), B, C, S, H, W, border, mode, q, eps, _stream(x))
+                  _ptr(gy), B, C, S, H, W, border, mode, q, eps, _stream(x),
+                  algo_bytes=4 * x.numel() * ((2 if y is not None else 1) + int(need_x) + int(need_y)))
         return gx, gy, None, None, None, None, None, None
 
 
@@ -513,7 +518,7 @@ class _Merge(torch.autograd.Function):
         merged, sig = torch.empty_like(w0), torch.empty_like(m)
         with torch.cuda.device(w0.device):
             _call("fs_merge_fwd", w0.data_ptr(), w1.data_ptr(), m.data_ptr(), merged.data_ptr(),
-                  sig.data_ptr(), B, C, S, _stream(w0))
+                  sig.data_ptr(), B, C, S, _stream(w0), algo_bytes=4 * (3 * w0.numel() + 2 * m.numel()))
         ctx.save_for_backward(w0, w1, m)
         return merged, sig
 
@@ -531,7 +536,8 @@ class _Merge(torch.autograd.Function):
         gm = torch.empty_like(m) if nm else None
         with torch.cuda.device(w0.device):
             _call("fs_merge_bwd", w0.data_ptr(), w1.data_ptr(), m.data_ptr(), gmerged.data_ptr(),
-                  _ptr(gsig), _ptr(g0), _ptr(g1), _ptr(gm), B, C, S, _stream(w0))
+                  _ptr(gsig), _ptr(g0), _ptr(g1), _ptr(gm), B, C, S, _stream(w0),
+                  algo_bytes=4 * (5 * w0.numel() + 3 * m.numel()))
         return g0, g1, gm
 
 
@@ -558,7 +564,7 @@ class _Distill(torch.autograd.Function):
         with torch.cuda.device(merged_i.device):
             _call("fs_distill_fwd", merged_i.data_ptr(), merged_tea.data_ptr(), gt.data_ptr(),
                   flow_i.data_ptr(), flow_tea.data_ptr(), sums.data_ptr(), ws.data_ptr(), B, C, F_, S,
-                  _stream(merged_i))
+                  _stream(merged_i), algo_bytes=4 * (3 * merged_i.numel() + 2 * flow_i.numel()))
         ctx.save_for_backward(merged_i, merged_tea, gt, flow_i, flow_tea)
         return sums[0] / float(B * S)
 
@@ -574,7 +580,7 @@ class _Distill(torch.autograd.Function):
         with torch.cuda.device(merged_i.device):
             _call("fs_distill_bwd", merged_i.data_ptr(), merged_tea.data_ptr(), gt.data_ptr(),
                   flow_i.data_ptr(), flow_tea.data_ptr(), coef.data_ptr(), gf.data_ptr(), B, C, F_, S,
-                  _stream(merged_i))
+                  _stream(merged_i), algo_bytes=4 * (3 * merged_i.numel() + 3 * flow_i.numel()))
         return None, None, None, gf, None
 
 
@@ -603,9 +609,10 @@ class _Interp3D(torch.autograd.Function):
         gx = gy.new_empty(shape)
         B, C, Di, Hi, Wi = shape
         Do, Ho, Wo = gy.shape[2:]
+        ws = gy.new_empty(B * C * (Do * Ho * Wi + Do * Hi * Wi)) if up else None
         with torch.cuda.device(gy.device):
-            _call("fs_interp3d_bwd", gy.data_ptr(), gx.data_ptr(), B, C, Di, Hi, Wi, Do, Ho, Wo, factor,
-                  1 if up else 0, _stream(gy))
+            _call("fs_interp3d_bwd", gy.data_ptr(), gx.data_ptr(), _ptr(ws), B, C, Di, Hi, Wi, Do, Ho, Wo,
+                  factor, 1 if up else 0, _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()))
         return gx, None, None
 
 
@@ -646,7 +653,8 @@ class _PReLU(torch.autograd.Function):
         ws = x.new_empty(B * C * _PRELU_MAX_CHUNKS)
         with torch.cuda.device(x.device):
             _call("fs_prelu_bwd", x.data_ptr(), gy.data_ptr(), weight.data_ptr(), gx.data_ptr(),
-                  gw.data_ptr(), ws.data_ptr(), B, C, S, weight.numel(), _stream(x))
+                  gw.data_ptr(), ws.data_ptr(), B, C, S, weight.numel(), _stream(x),
+                  algo_bytes=12 * x.numel())
         return gx, gw
 
 
