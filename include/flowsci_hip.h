@@ -126,6 +126,16 @@ int fs_corr2d_bwd(const float* f1, const float* f2, const float* grad_out,
                   float* grad_f1, float* grad_f2,
                   int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
 
+/* 3-D correlation: NEW capability named by BASELINE.json (config 4); the reference has no 3-D cost
+ * volume, so this generalises the 2-D layer above (dz-major, then dy, dx; channel mean; zero pad):
+ *   f1, f2 [B,C,D,H,W] -> out [B,(2md+1)^3,D,H,W].  Pinned to the reference only through D = 1.
+ */
+int fs_corr3d_fwd(const float* f1, const float* f2, float* out,
+                  int B, int C, int D, int H, int W, int max_displacement, fs_stream_t stream);
+int fs_corr3d_bwd(const float* f1, const float* f2, const float* grad_out,
+                  float* grad_f1, float* grad_f2,
+                  int B, int C, int D, int H, int W, int max_displacement, fs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * a9/a10. Robust penalty + (masked) reduction -- the arithmetic of
  *   loss_functions.photo_loss_function   UPFlow/utils/loss.py:17-48   (tail of the census loss)

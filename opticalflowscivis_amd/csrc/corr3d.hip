@@ -1,0 +1,240 @@
+// corr3d.hip -- 3-D local-window correlation (cost volume) for gfx950.
+//
+// NEW CAPABILITY named by BASELINE.json (config 4: "3D correlation + trilinear warp HIP kernels");
+// the reference has NO 3-D correlation (its Flow-3D IFNet has no cost volume at all), so
+// the semantics are this build's generalisation of the 2-D layer (corr2d.hip / Corr_pyTorch):
+//
+//   out[b, ((dz+md)(2md+1) + (dy+md))(2md+1) + (dx+md), z, y, x]
+//        = (1/C) sum_c f1[b,c,z,y,x] * f2[b,c,z+dz,y+dy,x+dx],     zero outside, dz-major.
+//
+// pinned to the reference only in the degenerate D = 1 case (== corr2d on the dz = 0 plane); oracle:
+// oracle/corr.py::corr3d_closed.  The (2md+1)^3-channel output makes this a coarse-pyramid-level op
+// (md = 4: 729 channels).
+//
+// Design = corr2d per (z, dz) plane pair: forward, one workgroup = (8x32-pixel tile of slice z) x
+// (displacement plane dz), 2md+1 waves = dy rows, lane = 4 consecutive x, channels streamed through
+// LDS in chunks of 8.  Backward, thread = voxel, loops dz with its (2md+1)^2 upstream values of that
+// plane in registers and 8 channel accumulators; grad_f2 through the transposed-displacement
+// identity; no atomics.
+#include "common.hpp"
+
+namespace {
+
+constexpr int TY = 8, TX = 32, CC = 8;
+
+template <int MD>
+__global__ __launch_bounds__(64 * (2 * MD + 1)) void corr3d_fwd_kernel(
+    const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out, int C, int D,
+    int H, int W) {
+  constexpr int ND = 2 * MD + 1;
+  constexpr int SR = TY + 2 * MD, SCOLS = TX + 2 * MD, SW = (SCOLS + 3) / 4 * 4, NT = 64 * ND;
+  __shared__ __attribute__((aligned(16))) float s2[CC][SR][SW];
+  __shared__ __attribute__((aligned(16))) float s1[CC][TY][TX];
+
+  int bz = blockIdx.z;
+  const int dzi = bz % ND; bz /= ND;
+  const int z = bz % D;
+  const int b = bz / D;
+  const int z2 = z + dzi - MD;
+  const int y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
+  const int t = threadIdx.x, lane = t & 63, dy = t >> 6;
+  const int qy = lane >> 3, qx = (lane & 7) * 4;
+  const size_t HW = (size_t)H * W, vol = (size_t)D * HW;
+  const float* f1b = f1 + (size_t)b * C * vol + (size_t)z * HW;
+  const float* f2b = f2 + (size_t)b * C * vol + (size_t)(z2 < 0 ? 0 : (z2 >= D ? D - 1 : z2)) * HW;
+  const bool zin = (z2 >= 0 && z2 < D);
+
+  float acc[4][ND];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < ND; ++j) acc[i][j] = 0.f;
+
+  if (zin) {
+    for (int c0 = 0; c0 < C; c0 += CC) {
+      for (int i = t; i < CC * SR * SCOLS; i += NT) {
+        const int c = i / (SR * SCOLS), rem = i - c * (SR * SCOLS);
+        const int r = rem / SCOLS, col = rem - r * SCOLS;
+        const int gy = y0 + r - MD, gx = x0 + col - MD;
+        float v = 0.f;
+        if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
+          v = f2b[(size_t)(c0 + c) * vol + (size_t)gy * W + gx];
+        s2[c][r][col] = v;
+      }
+      for (int i = t; i < CC * TY * TX; i += NT) {
+        const int c = i / (TY * TX), rem = i - c * (TY * TX);
+        const int r = rem / TX, col = rem - r * TX;
+        const int gy = y0 + r, gx = x0 + col;
+        float v = 0.f;
+        if (c0 + c < C && gy < H && gx < W) v = f1b[(size_t)(c0 + c) * vol + (size_t)gy * W + gx];
+        s1[c][r][col] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(&s1[c][qy][qx]);
+        float row[4 + 2 * MD + 3];
+        const float* rp = &s2[c][qy + dy][qx];
+#pragma unroll
+        for (int k = 0; k < (4 + 2 * MD + 3) / 4; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
+          row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+        }
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) acc[i][j] = fmaf(av[i], row[i + j], acc[i][j]);
+      }
+      __syncthreads();
+    }
+  }
+  const int y = y0 + qy;
+  if (y >= H) return;
+  const float fC = (float)C;
+  // channel = (dzi*ND + dy)*ND + dx
+  float* ob = out + (((size_t)b * ND * ND * ND + ((size_t)dzi * ND + dy) * ND) * D + z) * HW + (size_t)y * W;
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = x0 + qx + i;
+      if (x < W) ob[(size_t)j * vol + x] = acc[i][j] / fC;
+    }
+}
+
+// grad[c, p] = (1/C) sum_d g(d, p) * other[c, p + d]; blockIdx.z < B*D: (gout, f2) -> grad_f1,
+// else (gout transposed on the fly, f1) -> grad_f2.
+template <int MD>
+__global__ __launch_bounds__(256) void corr3d_bwd_kernel(const float* __restrict__ f1,
+                                                         const float* __restrict__ f2,
+                                                         const float* __restrict__ gout,
+                                                         float* __restrict__ g1, float* __restrict__ g2,
+                                                         int B, int C, int D, int H, int W) {
+  constexpr int ND = 2 * MD + 1;
+  constexpr int SR = TY + 2 * MD, SW = TX + 2 * MD;
+  __shared__ float s[CC][SR][SW];
+  int bz = blockIdx.z;
+  const bool second = bz >= B * D;
+  if (second) bz -= B * D;
+  const int z = bz % D, b = bz / D;
+  float* grad = second ? g2 : g1;
+  if (grad == nullptr) return;
+  const float* other = second ? f1 : f2;
+  const int y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
+  const int t = threadIdx.x, py = t / TX, px = t % TX;
+  const int y = y0 + py, x = x0 + px;
+  const bool live = (y < H && x < W);
+  const size_t HW = (size_t)H * W, vol = (size_t)D * HW;
+  const float* gb = gout + (size_t)b * ND * ND * ND * vol;
+  const float* ob = other + (size_t)b * C * vol;
+  const float fC = (float)C;
+
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    float acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+    for (int k = 0; k < ND; ++k) {       // displacement plane dz = k - MD
+      const int zz = z + k - MD;
+      if (zz < 0 || zz >= D) continue;  // uniform per block
+      float g[ND][ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          float v = 0.f;
+          if (live) {
+            if (!second) {
+              v = gb[((size_t)((k * ND + j) * ND + i) * D + z) * HW + (size_t)y * W + x];
+            } else {  // gT[d, q] = g[-d, q + d]
+              const int yy = y + (j - MD), xx = x + (i - MD);
+              if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                v = gb[((size_t)(((ND - 1 - k) * ND + (ND - 1 - j)) * ND + (ND - 1 - i)) * D + zz) * HW +
+                       (size_t)yy * W + xx];
+            }
+          }
+          g[j][i] = v;
+        }
+      for (int i = t; i < CC * SR * SW; i += 256) {
+        const int c = i / (SR * SW), rem = i - c * (SR * SW);
+        const int r = rem / SW, col = rem - r * SW;
+        const int gy = y0 + r - MD, gx = x0 + col - MD;
+        float v = 0.f;
+        if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
+          v = ob[(size_t)(c0 + c) * vol + (size_t)zz * HW + (size_t)gy * W + gx];
+        s[c][r][col] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        float a = acc[c];
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int i = 0; i < ND; ++i) a = fmaf(g[j][i], s[c][py + j][px + i], a);
+        acc[c] = a;
+      }
+      __syncthreads();
+    }
+    if (live)
+#pragma unroll
+      for (int c = 0; c < CC; ++c)
+        if (c0 + c < C) grad[((size_t)b * C + c0 + c) * vol + (size_t)z * HW + (size_t)y * W + x] = acc[c] / fC;
+  }
+}
+
+int check_shape(int B, int C, int D, int H, int W, int md) {
+  if (B < 1 || C < 1 || D < 1 || H < 1 || W < 1) return FS_ERR_SHAPE;
+  if (md < 1 || md > 4) return FS_ERR_ARG;
+  const long long nd = 2 * md + 1;
+  if (2ll * B * D * nd > 65535 || fs::cdiv(H, TY) > 65535) return FS_ERR_SHAPE;
+  if (nd * nd * nd * D * H * W >= (1ll << 40)) return FS_ERR_SHAPE;
+  return FS_OK;
+}
+
+template <int MD>
+int launch(const float* f1, const float* f2, const float* gout, float* out, float* g1, float* g2, int B,
+           int C, int D, int H, int W, bool bwd, hipStream_t st) {
+  constexpr int ND = 2 * MD + 1;
+  if (!bwd) {
+    dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), B * D * ND);
+    hipLaunchKernelGGL(corr3d_fwd_kernel<MD>, grid, dim3(64 * ND), 0, st, f1, f2, out, C, D, H, W);
+  } else {
+    dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), 2 * B * D);
+    hipLaunchKernelGGL(corr3d_bwd_kernel<MD>, grid, dim3(256), 0, st, f1, f2, gout, g1, g2, B, C, D, H, W);
+  }
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int dispatch(const float* f1, const float* f2, const float* gout, float* out, float* g1, float* g2, int B,
+             int C, int D, int H, int W, int md, bool bwd, hipStream_t st) {
+  switch (md) {
+    case 1: return launch<1>(f1, f2, gout, out, g1, g2, B, C, D, H, W, bwd, st);
+    case 2: return launch<2>(f1, f2, gout, out, g1, g2, B, C, D, H, W, bwd, st);
+    case 3: return launch<3>(f1, f2, gout, out, g1, g2, B, C, D, H, W, bwd, st);
+    default: return launch<4>(f1, f2, gout, out, g1, g2, B, C, D, H, W, bwd, st);
+  }
+}
+
+}  // namespace
+
+extern "C" int fs_corr3d_fwd(const float* f1, const float* f2, float* out, int B, int C, int D, int H,
+                             int W, int max_displacement, fs_stream_t stream) {
+  FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(out);
+  const int rc = check_shape(B, C, D, H, W, max_displacement);
+  if (rc != FS_OK) return rc;
+  return dispatch(f1, f2, nullptr, out, nullptr, nullptr, B, C, D, H, W, max_displacement, false,
+                  (hipStream_t)stream);
+}
+
+extern "C" int fs_corr3d_bwd(const float* f1, const float* f2, const float* grad_out, float* grad_f1,
+                             float* grad_f2, int B, int C, int D, int H, int W, int max_displacement,
+                             fs_stream_t stream) {
+  FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(grad_out);
+  if (grad_f1 == nullptr && grad_f2 == nullptr) return FS_ERR_NULLPTR;
+  const int rc = check_shape(B, C, D, H, W, max_displacement);
+  if (rc != FS_OK) return rc;
+  return dispatch(f1, f2, grad_out, nullptr, grad_f1, grad_f2, B, C, D, H, W, max_displacement, true,
+                  (hipStream_t)stream);
+}

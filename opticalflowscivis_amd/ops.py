@@ -660,3 +660,43 @@ class _PReLU(torch.autograd.Function):
 
 def prelu(x, weight):
     return _PReLU.apply(x, weight)
+
+
+# --------------------------------------------------------------------------------------------
+# 3-D correlation (new capability; no reference implementation exists)
+# --------------------------------------------------------------------------------------------
+class _Corr3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, md):
+        f1 = _need_cuda_f32("f1", f1, 5)
+        f2 = _need_cuda_f32("f2", f2, 5)
+        if f1.shape != f2.shape or f1.device != f2.device:
+            raise ValueError("f1 %s and f2 %s must match" % (tuple(f1.shape), tuple(f2.shape)))
+        B, C, D, H, W = f1.shape
+        nd = 2 * md + 1
+        out = f1.new_empty(B, nd ** 3, D, H, W)
+        with torch.cuda.device(f1.device):
+            _call("fs_corr3d_fwd", f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, C, D, H, W, md,
+                  _stream(f1), algo_bytes=4 * (2 * f1.numel() + out.numel()))
+        ctx.save_for_backward(f1, f2)
+        ctx.md = md
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        f1, f2 = ctx.saved_tensors
+        g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        if g1 is None and g2 is None:
+            return None, None, None
+        gout = _need_cuda_f32("grad_output", gout, 5)
+        B, C, D, H, W = f1.shape
+        with torch.cuda.device(f1.device):
+            _call("fs_corr3d_bwd", f1.data_ptr(), f2.data_ptr(), gout.data_ptr(), _ptr(g1), _ptr(g2), B, C,
+                  D, H, W, ctx.md, _stream(f1))
+        return g1, g2, None
+
+
+def corr3d(f1, f2, max_displacement=4):
+    """Volume cost volume [B,(2md+1)^3,D,H,W]: channel-mean of f1 * shifted f2, zero padded, dz-major."""
+    return _Corr3D.apply(f1, f2, int(max_displacement))

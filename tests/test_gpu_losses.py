@@ -198,3 +198,25 @@ def test_prelu_backward_vs_aten(ops, shape, nw):
     gb, gw = torch.autograd.grad((ops.prelu(b, wb) * G.to(DEV)).sum(), [b, wb])
     assert torch.equal(gb.cpu(), ra)
     assert float((gw.cpu() - rw).abs().max()) < 1e-4 * max(1.0, float(rw.abs().max()))
+
+
+@pytest.mark.parametrize("shape,md", [((1, 8, 6, 12, 40), 2), ((2, 5, 4, 9, 33), 1), ((1, 3, 10, 10, 12), 4),
+                                      ((1, 4, 1, 7, 9), 3)])
+def test_corr3d_vs_oracle(ops, shape, md):
+    g = torch.Generator().manual_seed(md * 17 + shape[1])
+    f1, f2 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    nd = 2 * md + 1
+    a, b = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+    ref = ocorr.corr3d_closed(a, b, md)
+    G = torch.randn(ref.shape, generator=g)
+    r1, r2 = torch.autograd.grad((ref * G).sum(), [a, b])
+    c, d = f1.to(DEV).requires_grad_(), f2.to(DEV).requires_grad_()
+    out = ops.corr3d(c, d, md)
+    g1, g2 = torch.autograd.grad((out * G.to(DEV)).sum(), [c, d])
+    assert out.shape == ref.shape == (shape[0], nd ** 3) + shape[2:]
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5
+    assert float((g1.cpu() - r1).abs().max()) < 1e-4 * max(1.0, float(r1.abs().max()))
+    assert float((g2.cpu() - r2).abs().max()) < 1e-4 * max(1.0, float(r2.abs().max()))
+    if shape[2] == 1:  # the only case pinned to the reference: D = 1 == corr2d on the dz = 0 plane
+        c2 = ops.corr2d(f1[:, :, 0].to(DEV), f2[:, :, 0].to(DEV), md)
+        assert torch.equal(out[:, md * nd * nd:(md + 1) * nd * nd, 0], c2)
