@@ -7,6 +7,11 @@ The library is the product: there is no CPU or eager-PyTorch fallback.  `lib()` 
 import ctypes
 import os
 
+# torch MUST be imported before the library is dlopen()ed: PyTorch-ROCm ships its own libamdhip64 and
+# the first HIP runtime loaded into the process wins the soname.  If libflowsci_hip.so pulled in the
+# system runtime first, torch would bind to it and report no GPU.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libflowsci_hip.so")
 

@@ -1,7 +1,8 @@
 // api.hip -- version / error-string entry points of the C-ABI.
 #include "common.hpp"
 
-extern "C" int fs_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int fs_version(void) {
+  FS_ENTER(); return 100; /* 0.1.0 */ }
 
 extern "C" const char* fs_error_string(int code) {
   switch (code) {

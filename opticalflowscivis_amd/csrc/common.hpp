@@ -9,6 +9,11 @@
     if ((p) == nullptr) return FS_ERR_NULLPTR; \
   } while (0)
 
+// hipGetLastError() reports the last error of ANY earlier runtime call of this host thread --
+// e.g. the hipErrorNotReady PyTorch's allocator gets from hipEventQuery -- so every entry point
+// clears the slot first and FS_LAUNCH_CHECK then sees only its own launches.
+#define FS_ENTER() (void)hipGetLastError()
+
 #define FS_LAUNCH_CHECK()                                \
   do {                                                   \
     if (hipGetLastError() != hipSuccess) return FS_ERR_LAUNCH; \

@@ -212,6 +212,7 @@ int check_shape(int B, int C, int H, int W, int md) {
 
 extern "C" int fs_corr2d_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W,
                              int max_displacement, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(out);
   const int rc = check_shape(B, C, H, W, max_displacement);
   if (rc != FS_OK) return rc;
@@ -227,6 +228,7 @@ extern "C" int fs_corr2d_fwd(const float* f1, const float* f2, float* out, int B
 extern "C" int fs_corr2d_bwd(const float* f1, const float* f2, const float* grad_out, float* grad_f1,
                              float* grad_f2, int B, int C, int H, int W, int max_displacement,
                              fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(grad_out);
   if (grad_f1 == nullptr && grad_f2 == nullptr) return FS_ERR_NULLPTR;
   const int rc = check_shape(B, C, H, W, max_displacement);

@@ -221,6 +221,7 @@ int dispatch(const float* f1, const float* f2, const float* gout, float* out, fl
 
 extern "C" int fs_corr3d_fwd(const float* f1, const float* f2, float* out, int B, int C, int D, int H,
                              int W, int max_displacement, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(out);
   const int rc = check_shape(B, C, D, H, W, max_displacement);
   if (rc != FS_OK) return rc;
@@ -231,6 +232,7 @@ extern "C" int fs_corr3d_fwd(const float* f1, const float* f2, float* out, int B
 extern "C" int fs_corr3d_bwd(const float* f1, const float* f2, const float* grad_out, float* grad_f1,
                              float* grad_f2, int B, int C, int D, int H, int W, int max_displacement,
                              fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(grad_out);
   if (grad_f1 == nullptr && grad_f2 == nullptr) return FS_ERR_NULLPTR;
   const int rc = check_shape(B, C, D, H, W, max_displacement);

@@ -135,6 +135,7 @@ unsigned blocks_for(long long n, int cap) {
 
 extern "C" int fs_merge_fwd(const float* w0, const float* w1, const float* mask_logit, float* merged,
                             float* sigmoid_out, int B, int C, int S, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(w0); FS_REQUIRE_PTR(w1); FS_REQUIRE_PTR(mask_logit); FS_REQUIRE_PTR(merged);
   if (B < 1 || C < 1 || S < 1) return FS_ERR_SHAPE;
   const long long n = (long long)B * C * S;
@@ -148,6 +149,7 @@ extern "C" int fs_merge_bwd(const float* w0, const float* w1, const float* mask_
                             const float* grad_merged, const float* grad_sigmoid, float* grad_w0,
                             float* grad_w1, float* grad_mask_logit, int B, int C, int S,
                             fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(w0); FS_REQUIRE_PTR(w1); FS_REQUIRE_PTR(mask_logit); FS_REQUIRE_PTR(grad_merged);
   if (grad_w0 == nullptr && grad_w1 == nullptr && grad_mask_logit == nullptr) return FS_ERR_NULLPTR;
   if (B < 1 || C < 1 || S < 1) return FS_ERR_SHAPE;
@@ -162,6 +164,7 @@ extern "C" int fs_merge_bwd(const float* w0, const float* w1, const float* mask_
 extern "C" int fs_distill_fwd(const float* merged_i, const float* merged_tea, const float* gt,
                               const float* flow_i, const float* flow_tea, float* sums, float* ws, int B,
                               int C, int F, int S, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(merged_i); FS_REQUIRE_PTR(merged_tea); FS_REQUIRE_PTR(gt);
   FS_REQUIRE_PTR(flow_i); FS_REQUIRE_PTR(flow_tea); FS_REQUIRE_PTR(sums); FS_REQUIRE_PTR(ws);
   if (B < 1 || C < 1 || F < 1 || S < 1) return FS_ERR_SHAPE;
@@ -178,6 +181,7 @@ extern "C" int fs_distill_fwd(const float* merged_i, const float* merged_tea, co
 extern "C" int fs_distill_bwd(const float* merged_i, const float* merged_tea, const float* gt,
                               const float* flow_i, const float* flow_tea, const float* coef,
                               float* grad_flow_i, int B, int C, int F, int S, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(merged_i); FS_REQUIRE_PTR(merged_tea); FS_REQUIRE_PTR(gt);
   FS_REQUIRE_PTR(flow_i); FS_REQUIRE_PTR(flow_tea); FS_REQUIRE_PTR(coef); FS_REQUIRE_PTR(grad_flow_i);
   if (B < 1 || C < 1 || F < 1 || S < 1) return FS_ERR_SHAPE;

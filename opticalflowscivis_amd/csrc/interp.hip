@@ -158,6 +158,7 @@ void up_adjoint_separable(const float* gout, float* gin, float* ws, const IP& p,
 extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws, int B, int C, int Din,
                                int Hin, int Win, int Dout, int Hout, int Wout, int factor, int upsample,
                                fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(grad_out); FS_REQUIRE_PTR(grad_in);
   if (B < 1 || C < 1 || Din < 1 || Hin < 1 || Win < 1 || Dout < 1 || Hout < 1 || Wout < 1)
     return FS_ERR_SHAPE;

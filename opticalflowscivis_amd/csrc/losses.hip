@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void census_dist_bwd_kernel(const float* __res
 extern "C" int fs_robust_sum(const float* x, const float* y, const float* w, float* sums, float* ws,
                              int B, int C, int S, int H, int W, int border, int mode, float q,
                              float eps, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(sums); FS_REQUIRE_PTR(ws);
   RSP p;
   const int rc = make_rsp(p, B, C, S, H, W, border, mode, q, eps);
@@ -265,6 +266,7 @@ extern "C" int fs_robust_sum(const float* x, const float* y, const float* w, flo
 extern "C" int fs_robust_sum_bwd(const float* x, const float* y, const float* w, const float* coef,
                                  float* grad_x, float* grad_y, int B, int C, int S, int H, int W,
                                  int border, int mode, float q, float eps, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(coef);
   if (grad_x == nullptr && grad_y == nullptr) return FS_ERR_NULLPTR;
   if (grad_y != nullptr && y == nullptr) return FS_ERR_NULLPTR;
@@ -298,6 +300,7 @@ extern "C" int fs_robust_sum_bwd(const float* x, const float* y, const float* w,
 
 extern "C" int fs_census_dist_fwd(const float* img1, const float* img2, float* dist, int B, int H,
                                   int W, int max_distance, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(img2); FS_REQUIRE_PTR(dist);
   if (B < 1 || H < 1 || W < 1 || B > 65535 || fs::cdiv(H, CT) > 65535) return FS_ERR_SHAPE;
   if (max_distance != 3) return FS_ERR_ARG;  // the reference's only value (loss.py:51)
@@ -311,6 +314,7 @@ extern "C" int fs_census_dist_fwd(const float* img1, const float* img2, float* d
 extern "C" int fs_census_dist_bwd(const float* img1, const float* img2, const float* grad_dist,
                                   float* grad_img1, float* grad_img2, int B, int H, int W,
                                   int max_distance, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(img2); FS_REQUIRE_PTR(grad_dist);
   if (grad_img1 == nullptr && grad_img2 == nullptr) return FS_ERR_NULLPTR;
   if (B < 1 || H < 1 || W < 1 || B > 65535 || fs::cdiv(H, CT) > 65535) return FS_ERR_SHAPE;

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void prelu_ga_kernel(const float* __restrict__
 extern "C" int fs_prelu_bwd(const float* x, const float* grad_out, const float* weight, float* grad_x,
                             float* grad_weight, float* ws, int B, int C, int S, int num_weights,
                             fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(grad_out); FS_REQUIRE_PTR(weight);
   FS_REQUIRE_PTR(grad_x); FS_REQUIRE_PTR(grad_weight); FS_REQUIRE_PTR(ws);
   if (B < 1 || C < 1 || S < 1) return FS_ERR_SHAPE;

@@ -273,6 +273,7 @@ int check_mode(int mode, int with_mask, const float* start) {
 extern "C" int fs_warp2d_fwd(const float* in, const float* flow, const float* start, float* out,
                              int B, int C, int H, int W, int mode, int with_mask,
                              fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(out);
   int rc = check_mode(mode, with_mask, start);
   if (rc != FS_OK) return rc;
@@ -286,6 +287,7 @@ extern "C" int fs_warp2d_fwd(const float* in, const float* flow, const float* st
 extern "C" int fs_warp2d_bwd(const float* in, const float* flow, const float* start,
                              const float* grad_out, float* grad_in, float* grad_flow, int B, int C,
                              int H, int W, int mode, int with_mask, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(grad_out);
   if (grad_in == nullptr && grad_flow == nullptr) return FS_ERR_NULLPTR;
   int rc = check_mode(mode, with_mask, start);
@@ -300,6 +302,7 @@ extern "C" int fs_warp2d_bwd(const float* in, const float* flow, const float* st
 extern "C" int fs_warp2d_pair_fwd(const float* img0, const float* img1, const float* flow4,
                                   float* out0, float* out1, int B, int C, int H, int W, int mode,
                                   fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow4);
   FS_REQUIRE_PTR(out0); FS_REQUIRE_PTR(out1);
   int rc = check_mode(mode, 0, nullptr);
@@ -315,6 +318,7 @@ extern "C" int fs_warp2d_pair_bwd(const float* img0, const float* img1, const fl
                                   const float* grad_out0, const float* grad_out1, float* grad_img0,
                                   float* grad_img1, float* grad_flow4, int B, int C, int H, int W,
                                   int mode, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow4);
   FS_REQUIRE_PTR(grad_out0); FS_REQUIRE_PTR(grad_out1);
   if ((grad_img0 == nullptr) != (grad_img1 == nullptr)) return FS_ERR_NULLPTR;

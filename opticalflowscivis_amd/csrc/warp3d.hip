@@ -472,6 +472,7 @@ int launch_bwd(const W3Bwd& io, int npair, bool with_gin, const float* flow, flo
 
 extern "C" int fs_warp3d_fwd(const float* in, const float* flow, float* out, int B, int C,
                              const int* in_dhw, int D, int H, int W, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(out);
   W3P p;
   const int rc = make_params(p, B, C, in_dhw, D, H, W);
@@ -483,6 +484,7 @@ extern "C" int fs_warp3d_fwd(const float* in, const float* flow, float* out, int
 extern "C" int fs_warp3d_bwd(const float* in, const float* flow, const float* grad_out,
                              float* grad_in, float* grad_flow, int B, int C, const int* in_dhw,
                              int D, int H, int W, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(grad_out);
   if (grad_in == nullptr && grad_flow == nullptr) return FS_ERR_NULLPTR;
   W3P p;
@@ -495,6 +497,7 @@ extern "C" int fs_warp3d_bwd(const float* in, const float* flow, const float* gr
 extern "C" int fs_warp3d_pair_fwd(const float* img0, const float* img1, const float* flow6,
                                   float* out0, float* out1, int B, int C, const int* in_dhw,
                                   int D, int H, int W, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow6);
   FS_REQUIRE_PTR(out0); FS_REQUIRE_PTR(out1);
   W3P p;
@@ -508,6 +511,7 @@ extern "C" int fs_warp3d_pair_bwd(const float* img0, const float* img1, const fl
                                   const float* grad_out0, const float* grad_out1, float* grad_img0,
                                   float* grad_img1, float* grad_flow6, int B, int C,
                                   const int* in_dhw, int D, int H, int W, fs_stream_t stream) {
+  FS_ENTER();
   FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow6);
   FS_REQUIRE_PTR(grad_out0); FS_REQUIRE_PTR(grad_out1);
   if ((grad_img0 == nullptr) != (grad_img1 == nullptr)) return FS_ERR_NULLPTR;  // both or neither
