@@ -224,6 +224,19 @@ int fs_prelu_bwd(const float* x, const float* grad_out, const float* weight,
                  float* grad_x, float* grad_weight, float* ws,
                  int B, int C, int S, int num_weights, fs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Weight gradient of the IFNet-3D convolutions (callers of the hot path; MIOpen's own weight-gradient
+ * solvers have no gfx950 tuning) as an implicit GEMM on the fp32 matrix cores:
+ *   dw[g, c, kz,ky,kx] += sum_{b,o} g[b,g,o] * src[b,c, o*stride + k - pad]     (zero outside src)
+ * g [B,Cg,Do,Ho,Wo], src [B,Cs,Di,Hi,Wi], dw [Cg,Cs,k,k,k] (caller zero-fills; float atomics).
+ *   torch.nn.Conv3d:          g = grad_output, src = input        -> dw = weight.grad [Cout,Cin,k,k,k]
+ *   torch.nn.ConvTranspose3d: g = input,       src = grad_output  -> dw = weight.grad [Cin,Cout,k,k,k]
+ * (kernel, stride) in {(3,1), (4,2)} -- the IFBlock layers (Flow-3D/model/IFNet.py:33-78).
+ */
+int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B, int Cg, int Cs,
+                  int Do, int Ho, int Wo, int Di, int Hi, int Wi,
+                  int kernel, int stride, int pad, fs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

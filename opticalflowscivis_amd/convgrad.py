@@ -22,7 +22,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-_MODE = os.environ.get("FLOWSCI_CONV_WRW", "gemm")
+# mfma: hand-written implicit-GEMM kernel (csrc/convwrw.hip) where the layer shape is supported, else
+# gemm;  gemm: im2col + split-K GEMM with stock torch ops;  miopen: the stock autograd path.
+_MODE = os.environ.get("FLOWSCI_CONV_WRW", "mfma")
 _COL_BYTES_CAP = int(os.environ.get("FLOWSCI_CONV_COL_GB", "24")) << 30  # im2col scratch per chunk
 
 
@@ -46,6 +48,10 @@ def _wrw_from_patches(src, g, k, stride, padding):
     """dW[gc, sc, *k] = sum_{b, o} g[b, gc, o] * src_padded[b, sc, o*stride + koff]
     src [B,Cs,*in], g [B,Cg,*out] with out = floor((in + 2p - k)/stride) + 1 (extra src rows unused)."""
     nd = src.dim() - 2
+    if _MODE == "mfma" and src.is_cuda and nd == 3:
+        from . import ops
+        if ops.conv3d_wrw_supported(k, stride, padding):
+            return ops.conv3d_wrw(g, src, k[0], stride[0], padding[0])
     B, Cs = src.shape[:2]
     Cg = g.shape[1]
     out = g.shape[2:]
@@ -115,7 +121,7 @@ class _ConvFn(torch.autograd.Function):
 
 
 def _use_gemm(x):
-    return _MODE == "gemm" and x.is_cuda and torch.is_grad_enabled()
+    return _MODE in ("gemm", "mfma") and x.is_cuda and torch.is_grad_enabled()
 
 
 class Conv3d(nn.Conv3d):

@@ -54,16 +54,16 @@ def enable_kernel_timing(on=True):
 
 
 def kernel_timings():
-    """{entry point: [(ms, algorithmic HBM bytes) per launch]} recorded so far (synchronises)."""
+    """{entry point: [(ms, algorithmic HBM bytes, flops) per launch]} recorded so far (synchronises)."""
     if _timing is None:
         return {}
     torch.cuda.synchronize()
-    return {k: [(a.elapsed_time(b), nb) for a, b, nb in v] for k, v in _timing.items()}
+    return {k: [(a.elapsed_time(b), nb, fl) for a, b, nb, fl in v] for k, v in _timing.items()}
 
 
-def _call(name, *args, algo_bytes=0):
-    """Launch a C-ABI entry point.  `algo_bytes` = compulsory HBM bytes of this launch,
-    only used by the optional timing records."""
+def _call(name, *args, algo_bytes=0, algo_flops=0):
+    """Launch a C-ABI entry point.  `algo_bytes` / `algo_flops` = compulsory HBM bytes / useful flops of
+    this launch, only used by the optional timing records."""
     fn = getattr(_lib.lib(), name)
     if _timing is None:
         _lib.check(fn(*args), name)
@@ -74,7 +74,7 @@ def _call(name, *args, algo_bytes=0):
     code = fn(*args)
     e1.record()
     _lib.check(code, name)
-    _timing.setdefault(name, []).append((e0, e1, algo_bytes))
+    _timing.setdefault(name, []).append((e0, e1, algo_bytes, algo_flops))
 
 
 # --------------------------------------------------------------------------------------------
@@ -700,3 +700,29 @@ class _Corr3D(torch.autograd.Function):
 def corr3d(f1, f2, max_displacement=4):
     """Volume cost volume [B,(2md+1)^3,D,H,W]: channel-mean of f1 * shifted f2, zero padded, dz-major."""
     return _Corr3D.apply(f1, f2, int(max_displacement))
+
+
+# --------------------------------------------------------------------------------------------
+# IFNet-3D convolution weight gradient: implicit GEMM on the fp32 matrix cores
+# --------------------------------------------------------------------------------------------
+def conv3d_wrw_supported(k, stride, padding):
+    return (len(k) == 3 and k[0] == k[1] == k[2] and stride[0] == stride[1] == stride[2] and
+            padding[0] == padding[1] == padding[2] and (k[0], stride[0]) in ((3, 1), (4, 2)) and
+            0 <= padding[0] < k[0])
+
+
+def conv3d_wrw(g, src, k, stride, pad):
+    """dW[Cg, Cs, k,k,k] = sum_{b,o} g[b,:,o] (x) src[b,:,o*stride + koff - pad]  (fs_conv3d_wrw)."""
+    g = _need_cuda_f32("g", g, 5)
+    src = _need_cuda_f32("src", src, 5)
+    B, Cg = g.shape[:2]
+    Cs = src.shape[1]
+    if src.shape[0] != B:
+        raise ValueError("batch mismatch")
+    dw = g.new_zeros(Cg, Cs, k, k, k)
+    with torch.cuda.device(g.device):
+        _call("fs_conv3d_wrw", g.data_ptr(), src.data_ptr(), dw.data_ptr(), B, Cg, Cs, g.shape[2],
+              g.shape[3], g.shape[4], src.shape[2], src.shape[3], src.shape[4], int(k), int(stride),
+              int(pad), _stream(g), algo_bytes=4 * (g.numel() + src.numel()),
+              algo_flops=2 * g.numel() * Cs * int(k) ** 3)
+    return dw

@@ -220,3 +220,36 @@ def test_corr3d_vs_oracle(ops, shape, md):
     if shape[2] == 1:  # the only case pinned to the reference: D = 1 == corr2d on the dz = 0 plane
         c2 = ops.corr2d(f1[:, :, 0].to(DEV), f2[:, :, 0].to(DEV), md)
         assert torch.equal(out[:, md * nd * nd:(md + 1) * nd * nd, 0], c2)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(cin=11, cout=32, k=4, s=2, size=(12, 20, 72), tr=False),   # conv0 of a scale-1 block (odd Cin)
+    dict(cin=32, cout=64, k=4, s=2, size=(8, 10, 66), tr=False),
+    dict(cin=64, cout=64, k=3, s=1, size=(6, 9, 40), tr=False),     # Wo not a multiple of the 32-wide K-step
+    dict(cin=16, cout=128, k=3, s=1, size=(4, 5, 33), tr=False),    # Cg = 128: two M tiles
+    dict(cin=64, cout=32, k=4, s=2, size=(5, 6, 20), tr=True),      # deconv head, first layer
+    dict(cin=32, cout=6, k=4, s=2, size=(6, 7, 34), tr=True),       # deconv head, flow output
+    dict(cin=32, cout=1, k=4, s=2, size=(4, 9, 16), tr=True),       # mask output
+    dict(cin=3, cout=5, k=4, s=2, size=(7, 9, 13), tr=False),       # odd input extent: trailing rows unused
+])
+def test_conv3d_wrw_mfma_vs_autograd(ops, cfg):
+    import torch.nn.functional as F
+    from opticalflowscivis_amd import convgrad
+    g = torch.Generator().manual_seed(cfg["cin"] * 7 + cfg["cout"])
+    B = 2
+    x = torch.randn((B, cfg["cin"]) + cfg["size"], generator=g)
+    wshape = (cfg["cin"], cfg["cout"]) if cfg["tr"] else (cfg["cout"], cfg["cin"])
+    w = torch.randn(wshape + (cfg["k"],) * 3, generator=g) * 0.1
+    fn = F.conv_transpose3d if cfg["tr"] else F.conv3d
+    s3, p3 = (cfg["s"],) * 3, (1,) * 3
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = fn(xr, wr, None, s3, p3)
+    G = torch.randn(yr.shape, generator=g)
+    (gw_ref,) = torch.autograd.grad((yr * G.double()).sum(), [wr])
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    assert convgrad._MODE == "mfma"
+    y = convgrad._ConvFn.apply(xd, wd, None, s3, p3, cfg["tr"])
+    gx, gw = torch.autograd.grad((y * G.to(DEV)).sum(), [xd, wd])
+    scale = float(gw_ref.abs().max())
+    assert gw.shape == gw_ref.shape
+    assert float((gw.cpu().double() - gw_ref).abs().max()) < 2e-5 * scale
