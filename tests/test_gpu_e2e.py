@@ -133,3 +133,24 @@ def test_upflow_c3_train_step_runs():
         tr.training()
         after = _psums(tr.net)
         assert np.isfinite(after).all() and not np.allclose(before, after)
+
+
+def test_flow2d_c2_train_step_vs_oracle():
+    """BASELINE config C2: Flow-2D Droplet 160 x 224, batch 16, one unsupervised train step (2-D
+    warp-pair + photometric HIP kernels) against the CPU oracle on identical weights and data."""
+    from opticalflowscivis_amd.data import synthetic
+    from oracle.ifnet_ref import ModelRef
+    m = _product(2)
+    torch.manual_seed(1234)
+    o = ModelRef(2)
+    o.flownet.load_state_dict({k: v.cpu() for k, v in m.flownet.state_dict().items()})
+    data = synthetic.droplet2d_batch(16, 160, 224, seed=1234)
+    imgs, gt = data[:, :2], data[:, 2:3]
+    po, oi = o.update(imgs, gt, learning_rate=1e-4)
+    pp, pi = m.update(imgs.to(DEV), gt.to(DEV), "droplet2d", learning_rate=1e-4)
+    for k in ("loss_l1", "loss_tea", "loss_distill", "loss_photo", "loss_G"):
+        a, b = float(pi[k].detach()), float(oi[k].detach())
+        assert abs(a - b) < 1e-3 * max(1e-3, abs(b)), (k, a, b)
+    assert float((pi["flow"].detach().cpu() - oi["flow"][:, :2].detach()).abs().max()) < 1e-3
+    assert abs(synthetic.psnr(pp.detach().cpu(), gt) - synthetic.psnr(po.detach(), gt)) < PSNR_TOL_DB
+    np.testing.assert_allclose(_psums(m.flownet), _psums(o.flownet), rtol=1e-4, atol=5e-3)
