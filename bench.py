@@ -124,6 +124,12 @@ def cpu_baseline(size, steps=2):
 
 
 def main():
+    # stdout must carry exactly ONE JSON line, but RCCL prints a version banner to fd 1 when its
+    # communicator comes up.  Park the real stdout, send fd 1 to stderr for the run, and write the
+    # result to the parked descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,8 +142,12 @@ def main():
         sys.exit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # FLOWSCI_BENCH_FORCE_DDP=1: run the N > 1 code path (RCCL process group + DDP wrapper) with a
+    # single rank -- a rehearsal for boxes with one GPU; never set by the driver
+    ddp = world > 1 or os.environ.get("FLOWSCI_BENCH_FORCE_DDP") == "1"
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", world_size=world, rank=rank)  # RCCL on ROCm
 
     from opticalflowscivis_amd import ops
@@ -145,7 +155,7 @@ def main():
     from opticalflowscivis_amd.flow3d.model.RIFE import Model
 
     torch.manual_seed(1234)  # same initial weights on every rank (DDP would broadcast anyway)
-    model = Model(local_rank=local_rank if world > 1 else -1, device=dev)
+    model = Model(local_rank=local_rank if ddp else -1, device=dev)
     S, B = args.size, args.batch
     gen = synthetic.droplet3d_batch if args.dataset == "droplet3d" else synthetic.jets3d_batch
     data = gen(B, S, seed=1234 + rank, device=dev)  # resident in HBM before the timed region
@@ -154,7 +164,7 @@ def main():
     lr = 3e-4 * (10 / 2000.) * world / 4
 
     def barrier():
-        if world > 1:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -184,7 +194,7 @@ def main():
                                      for i in range(args.steps)),
             torch.cuda.max_memory_allocated() / 2 ** 30))
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if ddp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -219,8 +229,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if ddp:
         dist.destroy_process_group()
 
 
