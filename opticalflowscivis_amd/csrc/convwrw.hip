@@ -54,8 +54,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
   constexpr int ROWS = NC * K * K;
   constexpr int GLD = KW + 1;
   static_assert(RLP % 32 == K % 32, "source row pitch");
-  __shared__ float sG[32 * MT][GLD];
-  __shared__ float sS[ROWS][RLP];
+  // k = 3: double-buffered tiles, one barrier per K-step, prefetch interleaved with the MFMAs.
+  // k = 4 (25 prefetch registers per thread): single buffer, two barriers, prefetch issued up
+  // front -- the leaner structure keeps it under 256 VGPRs without spills.
+  constexpr bool DB = (K == 3);
+  constexpr bool INTER = (K == 3);
+  __shared__ float sG[DB ? 2 : 1][32 * MT][GLD];
+  __shared__ float sS[DB ? 2 : 1][ROWS][RLP];
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int c0 = blockIdx.y * NC;            // first source channel of this chunk
@@ -89,19 +94,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
   constexpr int ITS = (ROWS * RL + 255) / 256;     // source-row elements per thread and step
   float rG[ITG], rS[ITS];
 
-  // global -> registers for one K-step (zero where the tile leaves G / the padded source)
-  auto fetch = [&](long long st) {
-    long long q = st;
-    const int seg = (int)(q % p.segs); q /= p.segs;
-    const int oy = (int)(q % p.Ho); q /= p.Ho;
-    const int oz = (int)(q % p.Do);
-    const int b = (int)(q / p.Do);
-    const int ox0 = seg * KW;
+  // position of the step being FETCHED, advanced incrementally (seg fastest, then oy, oz, b)
+  const long long s0 = (long long)blockIdx.x * p.spw;
+  const long long s1 = min(s0 + p.spw, p.steps);
+  int f_seg, f_oy, f_oz, f_b;
+  {
+    long long q = s0;
+    f_seg = (int)(q % p.segs); q /= p.segs;
+    f_oy = (int)(q % p.Ho); q /= p.Ho;
+    f_oz = (int)(q % p.Do);
+    f_b = (int)(q / p.Do);
+  }
+  auto advance = [&]() {
+    if (++f_seg == p.segs) { f_seg = 0; if (++f_oy == p.Ho) { f_oy = 0; if (++f_oz == p.Do) { f_oz = 0; ++f_b; } } }
+  };
+
+  // global -> registers for a quarter of one K-step (zero where the tile leaves G / the padded
+  // source).  Called four times per step, spread over the MFMA loop, so that the address
+  // arithmetic issues in the shadow of the 64-cycle matrix instructions.
+  auto fetch = [&](int part) {
+    const int ox0 = f_seg * KW;
     // wave-uniform bases + 32-bit byte offsets: one address VGPR per load (saddr form)
-    const char* gb = reinterpret_cast<const char*>(G + ((size_t)b * p.Cg + g0) * gvol +
-                                                   ((size_t)oz * p.Ho + oy) * p.Wo + ox0);
+    const char* gb = reinterpret_cast<const char*>(G + ((size_t)f_b * p.Cg + g0) * gvol +
+                                                   ((size_t)f_oz * p.Ho + f_oy) * p.Wo + ox0);
 #pragma unroll
     for (int it = 0; it < ITG; ++it) {
+      if (part >= 0 && (it & 3) != part) continue;
       const int i = t + 256 * it;
       const int r = i / KW, col = i - r * KW;
       float v = 0.f;
@@ -110,13 +128,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
       rG[it] = v;
     }
     const int ix0 = ox0 * S - p.pad;
-    const char* sb = reinterpret_cast<const char*>(Src + ((size_t)b * p.Cs + c0) * svol);
+    const char* sb = reinterpret_cast<const char*>(Src + ((size_t)f_b * p.Cs + c0) * svol);
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
+      if (part >= 0 && (it & 3) != part) continue;
       const int i = t + 256 * it;
       const int r = i / RL, col = i - r * RL;
       const int c = r / (K * K), kz = (r / K) % K, ky = r % K;
-      const int iz = oz * S + kz - p.pad, iy = oy * S + ky - p.pad, ix = ix0 + col;
+      const int iz = f_oz * S + kz - p.pad, iy = f_oy * S + ky - p.pad, ix = ix0 + col;
       float v = 0.f;
       if (i < ROWS * RL && c0 + c < p.Cs && iz >= 0 && iz < p.Di && iy >= 0 && iy < p.Hi && ix >= 0 &&
           ix < p.Wi)
@@ -125,34 +144,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
       rS[it] = v;
     }
   };
-  auto park = [&]() {  // registers -> LDS
+  auto park = [&](int buf) {  // registers -> LDS buffer `buf`
 #pragma unroll
     for (int it = 0; it < ITG; ++it) {
       const int i = t + 256 * it;
-      if (i < 32 * MT * KW) sG[i / KW][i % KW] = rG[it];
+      if (i < 32 * MT * KW) sG[buf][i / KW][i % KW] = rG[it];
     }
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       const int i = t + 256 * it;
-      if (i < ROWS * RL) sS[i / RL][i % RL] = rS[it];
+      if (i < ROWS * RL) sS[buf][i / RL][i % RL] = rS[it];
     }
   };
 
-  const long long s0 = (long long)blockIdx.x * p.spw;
-  const long long s1 = min(s0 + p.spw, p.steps);
-  const float* sSf = &sS[0][0];
-  if (s0 < s1) fetch(s0);
+  if (s0 < s1) {
+    fetch(-1);  // whole step
+    advance();
+  }
   for (long long st = s0; st < s1; ++st) {
-    park();
+    const int buf = DB ? (int)((st - s0) & 1) : 0;
+    park(buf);
+    // double-buffered: ONE barrier per step (the other buffer was last read in the previous step's
+    // MFMA phase, which every wave has left before it can arrive here)
     __syncthreads();
-    if (st + 1 < s1) fetch(st + 1);  // in flight while the matrix cores work on this step
-    // ---- MFMA: 16 reduction pairs per step
-#pragma unroll 4
-    for (int kk = 0; kk < KW / 2; ++kk) {
+    const bool more = (st + 1 < s1);
+    const float* sSf = &sS[buf][0][0];
+    if (!INTER && more) fetch(-1);
+    auto mma = [&](int kk) {  // one pair of reduction elements through every (M, N) tile of this wave
       const int ox = 2 * kk + kh;
       float a[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = sG[m * 32 + (lane & 31)][ox];
+      for (int m = 0; m < MT; ++m) a[m] = sG[buf][m * 32 + (lane & 31)][ox];
 #pragma unroll
       for (int n = 0; n < NPW; ++n) {
         if ((wv + 4 * n) < NT32) {  // wave-uniform
@@ -162,8 +184,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv, acc[m][n], 0, 0, 0);
         }
       }
+    };
+    if (INTER) {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        if (more) fetch(part);  // next step's quarter: in flight under the matrix instructions
+#pragma unroll
+        for (int k4 = 0; k4 < KW / 8; ++k4) mma(part * (KW / 8) + k4);
+      }
+    } else {
+#pragma unroll 4
+      for (int kk = 0; kk < KW / 2; ++kk) mma(kk);
     }
-    __syncthreads();
+    if (more) advance();
+    if (!DB) __syncthreads();  // single buffer: MFMA reads done before the next park
   }
 
   // ---- epilogue: dW[g, c0*K3 + j] += acc  (row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31)
