@@ -170,31 +170,41 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
     const bool more = (st + 1 < s1);
     const float* sSf = &sS[buf][0][0];
     if (!INTER && more) fetch(-1);
-    auto mma = [&](int kk) {  // one pair of reduction elements through every (M, N) tile of this wave
+    // operands of reduction pair kk: one A float per M tile, one B float per N tile of this wave.
+    // They are read from LDS ONE PAIR AHEAD of the MFMAs that use them (register rotation): issued
+    // right before use, every pair would expose an LDS round trip (~100 cycles per 256 MFMA cycles).
+    auto lds_ops = [&](int kk, float (&a)[MT], float (&bq)[NPW]) {
       const int ox = 2 * kk + kh;
-      float a[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) a[m] = sG[buf][m * 32 + (lane & 31)][ox];
 #pragma unroll
+      for (int n = 0; n < NPW; ++n) bq[n] = sSf[boff[n] + ox * S];
+    };
+    auto mma = [&](const float (&a)[MT], const float (&bq)[NPW]) {
+#pragma unroll
       for (int n = 0; n < NPW; ++n) {
         if ((wv + 4 * n) < NT32) {  // wave-uniform
-          const float bv = sSf[boff[n] + ox * S];
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[n], acc[m][n], 0, 0, 0);
         }
       }
     };
-    if (INTER) {
+    float a0[MT], b0[NPW], a1[MT], b1[NPW];
+    lds_ops(0, a0, b0);
 #pragma unroll
-      for (int part = 0; part < 4; ++part) {
-        if (more) fetch(part);  // next step's quarter: in flight under the matrix instructions
+    for (int part = 0; part < 4; ++part) {
+      if (INTER && more) fetch(part);  // next step's quarter: in flight under the matrix instructions
 #pragma unroll
-        for (int k4 = 0; k4 < KW / 8; ++k4) mma(part * (KW / 8) + k4);
+      for (int k4 = 0; k4 < KW / 8; k4 += 2) {
+        const int kk = part * (KW / 8) + k4;
+        lds_ops(kk + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of the MFMAs they do not feed
+        mma(a0, b0);
+        if (kk + 2 < KW / 2) lds_ops(kk + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
       }
-    } else {
-#pragma unroll 4
-      for (int kk = 0; kk < KW / 2; ++kk) mma(kk);
     }
     if (more) advance();
     if (!DB) __syncthreads();  // single buffer: MFMA reads done before the next park
