@@ -157,9 +157,11 @@ __global__ __launch_bounds__(256) void census_dist_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const float u1 = g1[py + j][px + i] - c1, u2 = g2[py + j][px + i] - c2;  // :65
-      const float t1 = u1 / sqrtf(0.81f + u1 * u1), t2 = u2 / sqrtf(0.81f + u2 * u2);  // :66
+      // :66 t = u / sqrt(0.81 + u^2) and :71 d / (0.1 + d) with v_rsq / v_rcp (1 ulp) instead of the
+      // IEEE divide + sqrt sequences: the kernel is VALU-bound (49 x 2 divides + sqrts per pixel)
+      const float t1 = u1 * rsqrtf(0.81f + u1 * u1), t2 = u2 * rsqrtf(0.81f + u2 * u2);
       const float d = (t1 - t2) * (t1 - t2);  // :70
-      acc += d / (0.1f + d);  // :71
+      acc += d * __builtin_amdgcn_rcpf(0.1f + d);
     }
   dist[(size_t)b * HW + (size_t)y * W + x] = acc;
 }
@@ -170,7 +172,7 @@ __device__ __forceinline__ void census_pair_grad(float u1, float u2, float k, fl
   const float r1 = rsqrtf(0.81f + u1 * u1), r2 = rsqrtf(0.81f + u2 * u2);
   const float e = u1 * r1 - u2 * r2;
   const float den = 0.1f + e * e;
-  const float dD = k * 0.2f * e / (den * den);
+  const float dD = k * 0.2f * e * __builtin_amdgcn_rcpf(den * den);  // v_rcp: the kernel is VALU-bound
   h1 = dD * (0.81f * r1 * r1 * r1);
   h2 = -dD * (0.81f * r2 * r2 * r2);
 }

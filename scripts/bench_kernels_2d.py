@@ -1,0 +1,61 @@
+"""Per-kernel timing of the 2-D hot-path rows at the BASELINE C2 / C3 shapes (GPU box only):
+algorithmic GB/s of corr2d, census, robust reductions and the 2-D warps."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from opticalflowscivis_amd import ops
+
+
+def t(fn, n=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def row(name, ms, nbytes, flops=0):
+    extra = "  %.1f TFLOP/s" % (flops / ms / 1e9) if flops else ""
+    print("%-46s %8.4f ms  %7.1f GB/s algorithmic%s" % (name, ms, nbytes / ms / 1e6, extra), flush=True)
+
+
+dev = "cuda:0"
+B = 32
+# a3/a4: UPFlow pyramid levels at C3 (150x450 input)
+for C, h, w in [(196, 3, 8), (128, 5, 15), (96, 10, 29), (64, 19, 57), (32, 38, 113)]:
+    f1 = torch.randn(B, C, h, w, device=dev, requires_grad=True)
+    f2 = torch.randn(B, C, h, w, device=dev, requires_grad=True)
+    out = ops.corr2d(f1, f2, 4)
+    G = torch.randn_like(out)
+    fb = 4 * (2 * C + 81) * h * w * B
+    row("corr2d fwd  C=%3d %3dx%3d B=32" % (C, h, w), t(lambda: ops.corr2d(f1, f2, 4)), fb, 2 * 81 * C * h * w * B)
+    row("corr2d bwd  C=%3d %3dx%3d B=32" % (C, h, w),
+        t(lambda: torch.autograd.grad(out, [f1, f2], G, retain_graph=True)), 4 * (4 * C + 81) * h * w * B,
+        4 * 81 * C * h * w * B)
+# a8: census on the C3 image pair
+im1 = torch.rand(B, 3, 150, 450, device=dev, requires_grad=True)
+im2 = torch.rand(B, 3, 150, 450, device=dev, requires_grad=True)
+occ = (torch.rand(B, 1, 150, 450, device=dev) > 0.3).float()
+npx = B * 150 * 450
+d = ops.census_dist(im1, im2)
+Gd = torch.randn_like(d)
+row("census_dist fwd 32x3x150x450", t(lambda: ops.census_dist(im1, im2)), 28 * npx)
+row("census_dist bwd", t(lambda: torch.autograd.grad(d, [im1, im2], Gd, retain_graph=True)), (28 + 24) * npx)
+row("census loss fwd (dist + robust_sum, occ)", t(lambda: ops.census_loss(im1, im2, occ, 0.4, False, True)), 36 * npx)
+# a9: photometric loss
+row("photo_loss abs_robust fwd (occ)", t(lambda: ops.photo_loss_multi_type(im1, im2, occ, 'abs_robust', 0.4, True)),
+    (24 + 4) * npx)
+# a5/a6/a7: feature / image warps
+flow = torch.randn(B, 2, 150, 450, device=dev) * 2
+row("warp2d dilated fwd 32x3x150x450", t(lambda: ops.warp2d_dilated(im1.detach(), flow)), (8 + 12 + 12) * npx)
+f = torch.randn(B, 32, 38, 113, device=dev)
+fl = torch.randn(B, 2, 38, 113, device=dev)
+row("warp2d pwc+mask fwd 32x32x38x113", t(lambda: ops.warp2d_pwc(f, fl, True)), (8 + 8 * 32) * B * 38 * 113)
+# a1: Flow-2D pair warp at C2
+i0, i1 = torch.rand(16, 1, 160, 224, device=dev), torch.rand(16, 1, 160, 224, device=dev)
+f4 = torch.randn(16, 4, 160, 224, device=dev)
+row("warp2d pair fwd 16x1x160x224 (C2)", t(lambda: ops.warp_pair(i0, i1, f4)), 2 * 16 * 16 * 160 * 224)
