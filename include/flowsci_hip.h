@@ -162,6 +162,19 @@ int fs_robust_sum_bwd(const float* x, const float* y, const float* w, const floa
                       int B, int C, int S, int H, int W, int border, int mode, float q, float eps,
                       fs_stream_t stream);
 
+/* a9, 'SSIM' branch: network_tools.weighted_ssim (UPFlow/model/upflow.py:141-196, c1 = inf,
+ * c2 = 9e-6, weight_epsilon = 0.01, 3x3 valid average pools) fused with the reduction of
+ * photo_loss_multi_type (:285-289):  sums[0] = sum ld * (use_occ ? avgpool(weight) : 1),
+ * sums[1] = sum avgpool(weight);  x, y [B,C,H,W], weight [B,1,H,W], H, W >= 3.
+ * loss = sums[0]/(sums[1]+1e-6) (use_occ) or sums[0]/(B*C*(H-2)*(W-2)).  ws as for fs_robust_sum.
+ * bwd: grad_x / grad_y (nullable) = coef[0] * d sums[0] / d x, y  (the weight carries no gradient).
+ */
+int fs_wssim_fwd(const float* x, const float* y, const float* weight, float* sums, float* ws,
+                 int B, int C, int H, int W, int use_occ, fs_stream_t stream);
+int fs_wssim_bwd(const float* x, const float* y, const float* weight, const float* coef,
+                 float* grad_x, float* grad_y, int B, int C, int H, int W, int use_occ,
+                 fs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * a8. Census (soft ternary) distance -- loss_functions.census_loss_torch,
  * UPFlow/utils/loss.py:51-72: grey = .2989R+.5870G+.1140B; 7x7 zero-padded neighbourhood

@@ -46,6 +46,8 @@ SIGNATURES = {
     "fs_corr3d_fwd": [_f32p] * 3 + [_int] * 6 + [_stream],
     "fs_corr3d_bwd": [_f32p] * 5 + [_int] * 6 + [_stream],
     "fs_conv3d_wrw": [_f32p] * 3 + [_int] * 12 + [_stream],
+    "fs_wssim_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
+    "fs_wssim_bwd": [_f32p] * 6 + [_int] * 5 + [_stream],
     "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _stream],
     "fs_warp2d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                       _stream],

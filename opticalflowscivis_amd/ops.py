@@ -437,8 +437,10 @@ def photo_loss_function(diff, mask, q, charbonnier_or_abs_robust, if_use_occ, av
 
 def photo_loss_multi_type(x, y, occ_mask, photo_loss_type='abs_robust', photo_loss_delta=0.4,
                           photo_loss_use_occ=False):
-    """UPFlow/model/upflow.py:267-289 for the abs_robust / charbonnier / L1 types (SSIM lives in
-    the upflow mirror module)."""
+    """UPFlow/model/upflow.py:267-289: abs_robust / charbonnier / L1 through fs_robust_sum, SSIM through
+    fs_wssim."""
+    if photo_loss_type == 'SSIM':
+        return weighted_ssim_loss(x, y, occ_mask, photo_loss_use_occ)
     mode, q, eps = {"abs_robust": (PEN_ABS_ROBUST, photo_loss_delta, 0.0),
                     "charbonnier": (PEN_CHARBONNIER, photo_loss_delta, 1e-6),
                     "L1": (PEN_L1_EPS, 1.0, 0.0)}[photo_loss_type]
@@ -726,3 +728,51 @@ def conv3d_wrw(g, src, k, stride, pad):
               int(pad), _stream(g), algo_bytes=4 * (g.numel() + src.numel()),
               algo_flops=2 * g.numel() * Cs * int(k) ** 3)
     return dw
+
+
+# --------------------------------------------------------------------------------------------
+# a9 'SSIM' branch: weighted SSIM + masked reduction, fused (upflow.py:141-196, 285-289)
+# --------------------------------------------------------------------------------------------
+class _WSSIMLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, weight, use_occ):
+        x = _need_cuda_f32("x", x, 4)
+        y = _need_cuda_f32("y", y, 4)
+        weight = _need_cuda_f32("occ_mask", weight, 4)
+        B, C, H, W = x.shape
+        if y.shape != x.shape or tuple(weight.shape) != (B, 1, H, W):
+            raise ValueError("weighted SSIM operands mismatch: %s %s %s" %
+                             (tuple(x.shape), tuple(y.shape), tuple(weight.shape)))
+        sums = x.new_empty(2)
+        ws = x.new_empty(2 * _REDUCE_BLOCKS)
+        with torch.cuda.device(x.device):
+            _call("fs_wssim_fwd", x.data_ptr(), y.data_ptr(), weight.data_ptr(), sums.data_ptr(),
+                  ws.data_ptr(), B, C, H, W, int(bool(use_occ)), _stream(x),
+                  algo_bytes=4 * (2 * x.numel() + weight.numel()))
+        if use_occ:
+            dS1 = 1.0 / (sums[1] + 1e-6)
+        else:
+            dS1 = sums.new_tensor(1.0 / float(B * C * (H - 2) * (W - 2)))
+        ctx.save_for_backward(x, y, weight, dS1)
+        ctx.use_occ = int(bool(use_occ))
+        return sums[0] * dS1
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, weight, dS1 = ctx.saved_tensors
+        nx, ny = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (nx or ny):
+            return None, None, None, None
+        B, C, H, W = x.shape
+        coef = (gout * dS1).reshape(1).contiguous()
+        gx = torch.empty_like(x) if nx else None
+        gy = torch.empty_like(y) if ny else None
+        with torch.cuda.device(x.device):
+            _call("fs_wssim_bwd", x.data_ptr(), y.data_ptr(), weight.data_ptr(), coef.data_ptr(), _ptr(gx),
+                  _ptr(gy), B, C, H, W, ctx.use_occ, _stream(x))
+        return gx, gy, None, None
+
+
+def weighted_ssim_loss(x, y, occ_mask, photo_loss_use_occ):
+    """photo_loss_multi_type(..., photo_loss_type='SSIM') in one fused pass."""
+    return _WSSIMLoss.apply(x, y, occ_mask, bool(photo_loss_use_occ))

@@ -6,7 +6,7 @@ estimator, context network, unsupervised losses) with the per-frame-pair hot pat
                                                                  ignored: there is no PyTorch fallback)
   * occlusion-check warps    -> tools.torch_warp               (fs_warp2d, PWC mode)
   * photometric warps        -> boundary_dilated_warp.warp_im  (fs_warp2d, DILATED mode)
-  * photo / msd losses       -> network_tools.photo_loss_multi_type (fs_robust_sum)
+  * photo / msd losses       -> network_tools.photo_loss_multi_type (fs_robust_sum; fs_wssim for 'SSIM')
   * census loss              -> loss_functions.census_loss_torch    (fs_census_dist + fs_robust_sum)
 
 Convolutions are stock torch.nn (MIOpen).  Module tree and construction order follow the
@@ -51,7 +51,8 @@ class network_tools:
 
     @classmethod
     def weighted_ssim(cls, x, y, weight, c1=float('inf'), c2=9e-6, weight_epsilon=0.01):
-        """upflow.py:141-196 (3x3 average-pool moments; stock ops -- not on the fused path yet)."""
+        """upflow.py:141-196, per-pixel maps with stock ops (API completeness); the loss itself goes
+        through the fused kernel, see photo_loss_multi_type."""
         if c1 == float('inf') and c2 == float('inf'):
             raise ValueError('Both c1 and c2 are infinite, SSIM loss is zero. This is likely unintended.')
         pool = lambda z: F.avg_pool2d(z, (3, 3), (1, 1))
@@ -106,13 +107,8 @@ class network_tools:
     @classmethod
     def photo_loss_multi_type(cls, x, y, occ_mask, photo_loss_type='abs_robust', photo_loss_delta=0.4,
                               photo_loss_use_occ=False):
-        """upflow.py:267-289 (a9).  abs_robust / charbonnier / L1: one fused HIP pass."""
-        if photo_loss_type == 'SSIM':
-            loss_diff, occ_weight = cls.weighted_ssim(x, y, occ_mask)
-            if photo_loss_use_occ:
-                return torch.sum(loss_diff * occ_weight) / (torch.sum(occ_weight) + 1e-6)
-            return torch.mean(loss_diff)
-        if photo_loss_type not in ('abs_robust', 'charbonnier', 'L1'):
+        """upflow.py:267-289 (a9): every type is one fused HIP pass (fs_robust_sum / fs_wssim)."""
+        if photo_loss_type not in ('abs_robust', 'charbonnier', 'L1', 'SSIM'):
             raise ValueError('wrong photo_loss type: %s' % photo_loss_type)
         return ops.photo_loss_multi_type(x, y, occ_mask, photo_loss_type, photo_loss_delta,
                                          photo_loss_use_occ)

@@ -112,7 +112,7 @@ def test_census_vs_oracle_c3_shape(ops):
 def test_photo_losses_golden(ops, golden):
     g = golden("upflow_ops")
     occ = T(g["cen_occ"])
-    for typ in ["abs_robust", "charbonnier", "L1"]:
+    for typ in ["abs_robust", "charbonnier", "L1", "SSIM"]:
         for useocc in (False, True):
             tag = "%s_%d" % (typ, int(useocc))
             im1, im2 = T(g["cen_im1"], True), T(g["cen_im2"], True)
