@@ -210,3 +210,39 @@ def test_operand_validation(ops):
         ops.warp3d(x.cpu(), torch.zeros(1, 3, 8, 8, 8))
     with pytest.raises(ValueError):
         ops.warp2d(torch.rand(1, 1, 8, 8, device=DEV), torch.zeros(1, 2, 8, 9, device=DEV))
+
+
+def test_wild_flows_do_not_fault(ops):
+    """NaN / Inf / 1e30 flow vectors must stay inside the tensors (a faulting kernel can reset the
+    node): every warp, forward and backward, must complete; finite flows next to them stay exact."""
+    g = torch.Generator().manual_seed(0)
+    bad = torch.tensor([float("nan"), float("inf"), -float("inf"), 1e30, -1e30, 3e9, -3e9, 0.0])
+
+    def poison(f):
+        f = f.clone()
+        flat = f.view(-1)
+        idx = torch.randperm(flat.numel(), generator=g)[:64]
+        flat[idx] = bad.repeat(8)
+        return f
+
+    x3 = torch.rand(1, 2, 9, 70, 40, generator=g).to(DEV).requires_grad_()
+    f3 = poison(torch.randn(1, 3, 9, 70, 40, generator=g)).to(DEV).requires_grad_()
+    out = ops.warp3d(x3, f3)
+    out.nan_to_num().sum().backward()
+    i0 = torch.rand(1, 1, 9, 70, 40, generator=g).to(DEV)
+    f6 = poison(torch.randn(1, 6, 9, 70, 40, generator=g)).to(DEV).requires_grad_()
+    a, b = ops.warp_pair(i0, i0, f6)
+    (a.nan_to_num().sum() + b.nan_to_num().sum()).backward()
+    x2 = torch.rand(2, 3, 33, 47, generator=g).to(DEV).requires_grad_()
+    for fn in (ops.warp2d, lambda p, q: ops.warp2d_pwc(p, q, True), lambda p, q: ops.warp2d_pwc(p, q, False),
+               ops.warp2d_photo, ops.warp2d_dilated):
+        f2 = poison(torch.randn(2, 2, 33, 47, generator=g)).to(DEV).requires_grad_()
+        o = fn(x2, f2)
+        o.nan_to_num().sum().backward()
+    torch.cuda.synchronize()
+    # voxels with finite flow are unaffected by poisoned neighbours
+    f_ok = torch.randn(1, 3, 9, 70, 40, generator=g)
+    f_bad = poison(f_ok)
+    same = (f_ok == f_bad).all(dim=1, keepdim=True).to(DEV)
+    o1, o2 = ops.warp3d(x3.detach()[:, :1], f_ok.to(DEV)), ops.warp3d(x3.detach()[:, :1], f_bad.to(DEV))
+    assert torch.equal(o1[same], o2[same])
