@@ -109,6 +109,22 @@ int fs_warp2d_pair_bwd(const float* img0, const float* img1, const float* flow4,
                        int B, int C, int H, int W, int mode, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * f2. Forward-backward occlusion check + outgoing mask, fused.
+ *   UPFlow/utils/tools.py:560-590 (occ_check_model.__call__ dispatch), :592-630
+ *   (_forward_backward_occ_check with length_sq_v0 = sum_c |x_c| and two torch_warp calls),
+ *   :683-709 (torch_outgoing_occ_check), :711-719 (torch_get_obj_occ_check).
+ *   flow_f, flow_b [B,2,H,W] -> occ_f, occ_b [B,1,H,W] in {0,1} (0 = occluded / ignore).
+ *   alpha1, alpha2_over_scale: occ_thresh = alpha1 * (|flow_f|_1 + |flow_b|_1) + alpha2/scale.
+ *   mode FS_OCC_ALL: the consistency masks; FS_OCC_OUT: the outgoing masks only;
+ *   FS_OCC_OBJ: (consistent == 1) or (outgoing == 0) -- the reference's 'obj' setting.
+ *   No gradient: the reference's masks are bool -> float.
+ */
+enum { FS_OCC_ALL = 0, FS_OCC_OBJ = 1, FS_OCC_OUT = 2 };
+int fs_occ_check2d(const float* flow_f, const float* flow_b, float* occ_f, float* occ_b,
+                   int B, int H, int W, float alpha1, float alpha2_over_scale, int mode,
+                   fs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * a3/a4. Local-window correlation (cost volume) -- replaces the `correlation_cuda` torch
  * extension bound at UPFlow/model/correlation_package/correlation.py:4,26-27,42-43
  * (sources absent from the reference tree; semantics pinned by Corr_pyTorch,
@@ -224,6 +240,28 @@ int fs_distill_bwd(const float* merged_i, const float* merged_tea, const float* 
 int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws, int B, int C,
                     int Din, int Hin, int Win, int Dout, int Hout, int Wout,
                     int factor, int upsample, fs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * f3. Laplacian-pyramid L1 loss of Flow-2D: Flow-2D/model/laplacian.py:10-88
+ * (gauss_kernel :10-19, downsample :21-22, upsample :24-36, conv_gauss :38-47,
+ * laplacian_pyramid :49-74, LapLoss.forward :81-88).
+ *   loss = sum_{l < levels} mean | pyr_l(input) - pyr_l(target) |  computed as ONE pyramid of
+ *   (input - target) -- every pyramid step is linear.
+ * input, target [N,H,W] (N = B*C; the 5x5 filter is depthwise), target may be NULL (= zeros).
+ * Every level needs extent >= 3 (reflect padding by 2; torch raises there too) -> FS_ERR_SHAPE.
+ * fs_laploss2d_sizes: host-only; element counts of the three caller-owned fp32 buffers.
+ *   sgn  : sign(pyr_l) / numel_l for every level, written by fwd, read by bwd (save it);
+ *   ws   : scratch (fwd: ws_fwd_floats, bwd: ws_bwd_floats), contents need not survive.
+ * fwd : loss[0] = the loss (loss[1] is scratch; pass 2 floats).
+ * bwd : grad_loss = device pointer to d(objective)/d(loss) (1 float);
+ *       grad_diff [N,H,W] = d/d(input) = -d/d(target).  Gathers only, deterministic.
+ */
+int fs_laploss2d_sizes(int N, int H, int W, int levels, long long* sgn_floats,
+                       long long* ws_fwd_floats, long long* ws_bwd_floats);
+int fs_laploss2d_fwd(const float* input, const float* target, float* sgn, float* ws, float* loss,
+                     int N, int H, int W, int levels, fs_stream_t stream);
+int fs_laploss2d_bwd(const float* sgn, const float* grad_loss, float* ws, float* grad_diff,
+                     int N, int H, int W, int levels, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward of torch.nn.PReLU(num_parameters = C or 1) as used after every IFNet convolution

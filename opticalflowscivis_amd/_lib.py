@@ -20,6 +20,7 @@ _int = ctypes.c_int
 _float = ctypes.c_float
 _stream = ctypes.c_void_p
 _intp = ctypes.POINTER(ctypes.c_int)  # host array of ints (or None)
+_i64p = ctypes.POINTER(ctypes.c_longlong)  # host out-parameter
 
 # name -> argtypes; restype is int unless listed in _RESTYPES
 SIGNATURES = {
@@ -31,6 +32,10 @@ SIGNATURES = {
     "fs_warp3d_pair_bwd": [_f32p] * 8 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_warp2d_pair_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_warp2d_pair_bwd": [_f32p] * 8 + [_int] * 5 + [_stream],
+    "fs_occ_check2d": [_f32p] * 4 + [_int] * 3 + [_float, _float, _int, _stream],
+    "fs_laploss2d_sizes": [_int] * 4 + [_i64p] * 3,
+    "fs_laploss2d_fwd": [_f32p] * 5 + [_int] * 4 + [_stream],
+    "fs_laploss2d_bwd": [_f32p] * 4 + [_int] * 4 + [_stream],
     "fs_corr2d_fwd": [_f32p] * 3 + [_int] * 5 + [_stream],
     "fs_corr2d_bwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_robust_sum": [_f32p] * 5 + [_int] * 7 + [_float, _float, _stream],

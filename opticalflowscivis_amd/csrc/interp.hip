@@ -104,6 +104,37 @@ __global__ __launch_bounds__(256) void interp3d_down_adjoint_exact(const float* 
   }
 }
 
+// Same, four consecutive x per thread (Wi % 4 == 0): the row test and the index arithmetic are paid
+// once per float4 store -- the scalar version is bound by its integer divisions, not by HBM.
+__global__ __launch_bounds__(256) void interp3d_down_adjoint_exact_v4(const float* __restrict__ gout,
+                                                                     float4* __restrict__ gin, IP p) {
+  const int W4 = p.Wi >> 2;
+  const long long rows = p.nBC * p.Di * p.Hi;
+  const long long total = rows * W4;
+  const int lo = p.s / 2 - 1, hi = p.s / 2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long row = e / W4;
+    const int x4 = (int)(e - row * W4);
+    const int y = (int)(row % p.Hi);
+    const long long t = row / p.Hi;
+    const int z = (int)(t % p.Di);
+    const long long bc = t / p.Di;
+    const int ry = y % p.s, rz = z % p.s;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((ry == lo || ry == hi) && (rz == lo || rz == hi)) {
+      const float* g = gout + ((bc * p.Do + z / p.s) * p.Ho + y / p.s) * p.Wo;
+      if (p.s == 2) {
+        const float g0 = 0.125f * g[2 * x4], g1 = 0.125f * g[2 * x4 + 1];
+        v = make_float4(g0, g0, g1, g1);
+      } else {  // s == 4: residues 1 and 2 of each group of four
+        const float g0 = 0.125f * g[x4];
+        v = make_float4(0.f, g0, g0, 0.f);
+      }
+    }
+    gin[e] = v;
+  }
+}
+
 // Up-sampling adjoint as three separable 1-D passes (x, then y, then z): every fine gradient is
 // read from HBM once and the per-voxel gather count drops from NC^3 to NC per pass (the direct
 // kernel is bound by the 4-lanes-per-clock address path, not by HBM).
@@ -180,7 +211,11 @@ extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws,
   const long long total = p.nBC * Din * Hin * Win;
   hipStream_t st = (hipStream_t)stream;
   if (!upsample) {
-    if (Din == Dout * factor && Hin == Hout * factor && Win == Wout * factor)
+    const bool exact = Din == Dout * factor && Hin == Hout * factor && Win == Wout * factor;
+    if (exact && (Win & 3) == 0 && ((uintptr_t)grad_in & 15) == 0)
+      hipLaunchKernelGGL(interp3d_down_adjoint_exact_v4, dim3(grid_for(total / 4)), dim3(256), 0, st, grad_out,
+                         (float4*)grad_in, p);
+    else if (exact)
       hipLaunchKernelGGL(interp3d_down_adjoint_exact, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
                          grad_in, p);
     else

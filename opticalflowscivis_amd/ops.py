@@ -176,6 +176,26 @@ def warp2d_pwc(x, flow, with_mask):
     return _Warp2D.apply(x, flow, None, WARP2D_PWC, 1 if with_mask else 0)
 
 
+def occ_check2d(flow_f, flow_b, alpha1, alpha2, scale=1, obj_out_all="obj"):
+    """§8f.2: UPFlow/utils/tools.py:560-719 `occ_check_model.__call__` as one launch -- both
+    torch_warp calls, the L1 magnitudes, the threshold test, the outgoing masks and their
+    combination.  Returns (occ_fw, occ_bw) [B,1,H,W] float {0,1}; no gradient (bool in the
+    reference)."""
+    mode = {"all": 0, "obj": 1, "out": 2}[obj_out_all]
+    flow_f = _need_cuda_f32("flow_f", flow_f.detach(), 4)
+    flow_b = _need_cuda_f32("flow_b", flow_b.detach(), 4)
+    if flow_f.shape != flow_b.shape or flow_f.shape[1] != 2:
+        raise ValueError("flows must both be [B,2,H,W], got %s / %s" % (tuple(flow_f.shape), tuple(flow_b.shape)))
+    B, _, H, W = flow_f.shape
+    occ_f = torch.empty((B, 1, H, W), device=flow_f.device, dtype=torch.float32)
+    occ_b = torch.empty_like(occ_f)
+    with torch.cuda.device(flow_f.device):
+        _call("fs_occ_check2d", flow_f.data_ptr(), flow_b.data_ptr(), occ_f.data_ptr(), occ_b.data_ptr(),
+              B, H, W, float(alpha1), float(alpha2 / scale), mode, _stream(flow_f),
+              algo_bytes=24 * B * H * W)
+    return occ_f, occ_b
+
+
 def warp2d_photo(frame, flow):
     """a11: the `backwrd_warp` closure of Flow-2D/model/RIFE.py:244-262."""
     return _Warp2D.apply(frame, flow, None, WARP2D_PHOTO, 0)
@@ -595,6 +615,58 @@ def distill_term(merged_i, merged_teacher, gt, flow_i, flow_teacher):
 # --------------------------------------------------------------------------------------------
 # §8f.1: trilinear resize of IFBlock with a gather-formulated HIP backward
 # --------------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------------
+# §8f.3: Flow-2D/model/laplacian.py:49-88 LapLoss as one pyramid of (input - target)
+# --------------------------------------------------------------------------------------------
+def _lap_sizes(N, H, W, levels):
+    import ctypes
+    a, b, c = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+    code = _lib.lib().fs_laploss2d_sizes(N, H, W, levels, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    if code != 0:
+        raise ValueError("LapLoss needs every pyramid level >= 3 px per side (reflect padding by 2) and "
+                         "1 <= levels <= 8; got [%d,%d,%d], %d levels" % (N, H, W, levels))
+    return a.value, b.value, c.value
+
+
+class _LapLoss2D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, target, levels):
+        inp = _need_cuda_f32("input", inp, 4)
+        target = _need_cuda_f32("target", target, 4)
+        if inp.shape != target.shape:
+            raise ValueError("input %s and target %s differ in shape" % (tuple(inp.shape), tuple(target.shape)))
+        B, C, H, W = inp.shape
+        n_sgn, n_fwd, n_bwd = _lap_sizes(B * C, H, W, levels)
+        sgn = inp.new_empty(n_sgn)
+        ws = inp.new_empty(n_fwd)
+        loss = inp.new_empty(2)
+        with torch.cuda.device(inp.device):
+            _call("fs_laploss2d_fwd", inp.data_ptr(), target.data_ptr(), sgn.data_ptr(), ws.data_ptr(),
+                  loss.data_ptr(), B * C, H, W, levels, _stream(inp), algo_bytes=8 * inp.numel())
+        ctx.save_for_backward(sgn)
+        ctx.cfg = (B, C, H, W, levels, n_bwd)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (sgn,) = ctx.saved_tensors
+        B, C, H, W, levels, n_bwd = ctx.cfg
+        gl = gloss.detach().to(torch.float32).reshape(1).contiguous()
+        ws = sgn.new_empty(n_bwd)
+        gd = sgn.new_empty((B, C, H, W))
+        with torch.cuda.device(sgn.device):
+            _call("fs_laploss2d_bwd", sgn.data_ptr(), gl.data_ptr(), ws.data_ptr(), gd.data_ptr(), B * C, H, W,
+                  levels, _stream(sgn), algo_bytes=8 * gd.numel())
+        gi = gd if ctx.needs_input_grad[0] else None
+        gt = -gd if ctx.needs_input_grad[1] else None
+        return gi, gt, None
+
+
+def laploss2d(inp, target, max_levels=5):
+    """LapLoss(max_levels)(input, target) of Flow-2D/model/laplacian.py:76-88 (scalar)."""
+    return _LapLoss2D.apply(inp, target, int(max_levels))
+
+
 class _Interp3D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, factor, up):

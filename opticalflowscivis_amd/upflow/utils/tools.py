@@ -55,9 +55,10 @@ class tools:
             return ops.warp2d_dilated(I_nchw, flow_nchw, start)
 
     class occ_check_model:
-        """Forward-backward consistency occlusion masks (UPFlow/utils/tools.py:543-719).  The two
-        flow warps go through the HIP kernel; the rest is a handful of elementwise ops on
-        [B,1,H,W] masks (fusion candidate)."""
+        """Forward-backward consistency occlusion masks (UPFlow/utils/tools.py:543-719).
+        `__call__` is ONE HIP launch (ops.occ_check2d): both flow warps, the
+        magnitudes, the threshold test and the outgoing masks.  The per-step methods below keep
+        the reference's names for callers that use them directly."""
 
         def __init__(self, occ_type='for_back_check', occ_alpha_1=1.0, occ_alpha_2=0.05,
                      sum_abs_or_squar=True, obj_out_all='all'):
@@ -70,6 +71,9 @@ class tools:
         def __call__(self, flow_f, flow_b, scale=1):
             if self.occ_type != 'for_back_check':
                 raise ValueError('not implemented')  # as in the reference (:567)
+            if flow_f.is_cuda:
+                return ops.occ_check2d(flow_f, flow_b, self.occ_alpha_1, self.occ_alpha_2, scale,
+                                       self.obj_out_all)
             if self.obj_out_all == 'out':
                 return self.torch_outgoing_occ_check(flow_f), self.torch_outgoing_occ_check(flow_b)
             occ_1, occ_2 = self._forward_backward_occ_check(flow_f, flow_b, scale)

@@ -206,3 +206,48 @@ def warp2d_dilated_ref(I, flow, start=None):
     wc = ((x - x0f) * (y1f - y)).unsqueeze(1)
     wd = ((x - x0f) * (y - y0f)).unsqueeze(1)
     return wa * Ia + wb * Ib + wc * Ic + wd * Id
+
+
+# --------------------------------------------------------------------------------------------
+# §8f.2  UPFlow/utils/tools.py:543-719 occ_check_model (forward-backward check + outgoing mask)
+# --------------------------------------------------------------------------------------------
+def occ_fb_lhs_thresh(flow_fw, flow_bw, alpha1, alpha2, scale=1):
+    """tools.py:592-622: the two tested quantities and the threshold (before the `<`)."""
+    def mag(x):  # length_sq_v0 (:596-601)
+        return torch.sum(torch.pow(x ** 2, 0.5), dim=1, keepdim=True)
+    mag_sq = mag(flow_fw) + mag(flow_bw)                                  # :615
+    flow_bw_warped = warp2d_pwc_ref(flow_bw, flow_fw, with_mask=False)    # :616 tools.torch_warp
+    flow_fw_warped = warp2d_pwc_ref(flow_fw, flow_bw, with_mask=False)    # :617
+    thresh = alpha1 * mag_sq + alpha2 / scale                             # :620
+    return mag(flow_fw + flow_bw_warped), mag(flow_bw + flow_fw_warped), thresh
+
+
+def occ_outgoing_ref(flow):
+    """tools.py:683-709."""
+    B, C, H, W = flow.size()
+    xx = torch.arange(0, W).view(1, -1).repeat(H, 1).view(1, 1, H, W).repeat(B, 1, 1, 1).float()
+    yy = torch.arange(0, H).view(-1, 1).repeat(1, W).view(1, 1, H, W).repeat(B, 1, 1, 1).float()
+    pos_x, pos_y = xx + flow[:, 0:1], yy + flow[:, 1:2]
+    m = torch.ones_like(pos_x)
+    m[pos_x > W - 1] = 0
+    m[pos_x < 0] = 0
+    m[pos_y > H - 1] = 0
+    m[pos_y < 0] = 0
+    return m.float()
+
+
+def occ_check_ref(flow_f, flow_b, alpha1, alpha2, scale=1, obj_out_all='obj'):
+    """tools.py:560-590 dispatch; returns (occ_fw, occ_bw), 0 = occluded."""
+    if obj_out_all == 'out':
+        return occ_outgoing_ref(flow_f), occ_outgoing_ref(flow_b)
+    lf, lb, th = occ_fb_lhs_thresh(flow_f, flow_b, alpha1, alpha2, scale)
+    occ_1, occ_2 = (lf < th).float(), (lb < th).float()                  # :621-622
+    if obj_out_all == 'all':
+        return occ_1, occ_2
+
+    def obj(occ, out):  # :711-719
+        o = torch.zeros_like(occ)
+        o[occ == 1] = 1
+        o[out == 0] = 1
+        return o
+    return obj(occ_1, occ_outgoing_ref(flow_f)), obj(occ_2, occ_outgoing_ref(flow_b))

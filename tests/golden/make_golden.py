@@ -9,6 +9,8 @@ Usage (each group imports a different reference package layout, so one process p
     python tests/golden/make_golden.py flow3d_e2e   # Flow-3D Model.update / inference
     python tests/golden/make_golden.py flow2d_e2e   # Flow-2D Model.update / inference
     python tests/golden/make_golden.py upflow_e2e   # UPFlow_net forward losses / flows / grads
+    python tests/golden/make_golden.py rife_next    # Flow-2D LapLoss
+    python tests/golden/make_golden.py upflow_next  # occ_check_model, normalize_features
     python tests/golden/make_golden.py all          # runs the groups above as subprocesses
 
 Third-party modules the reference imports at module scope but that are absent from this
@@ -320,7 +322,71 @@ def upflow_e2e():
     print("wrote upflow_e2e.npz; losses", dict(zip(keys, store["losses"])), "nparam", int(store["nparam"]))
 
 
-GROUPS = dict(rife_ops=rife_ops, upflow_ops=upflow_ops, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
+# ------------------------------------------------------------------------------------------
+def rife_next():
+    """the Flow-2D Laplacian-pyramid loss (Flow-2D/model/laplacian.py)."""
+    lap = _load_file("ref_lap2d", REF + "/Flow-2D/model/laplacian.py")
+    lap.device = torch.device("cpu")
+    gen = torch.Generator().manual_seed(3131)
+    store = {}
+    for tag, (B, C, H, W), levels in [("even", (2, 1, 48, 64), 5), ("odd", (1, 1, 37, 51), 5),
+                                      ("l3", (2, 1, 13, 18), 3), ("c2", (1, 2, 24, 40), 4)]:
+        a = torch.rand(B, C, H, W, generator=gen).requires_grad_()
+        b = (a.detach() + 0.2 * torch.randn(B, C, H, W, generator=gen)).clamp(0, 1).requires_grad_()
+        crit = lap.LapLoss(max_levels=levels, channels=C)
+        loss = crit(a, b)
+        ga, gb = torch.autograd.grad(loss, [a, b])
+        for k, v in dict(a=a, b=b, loss=loss, ga=ga, gb=gb).items():
+            store["lap_%s_%s" % (tag, k)] = _np(v)
+        store["lap_%s_levels" % tag] = np.int64(levels)
+    np.savez_compressed(os.path.join(OUT, "rife_next.npz"), **store)
+    print("wrote rife_next.npz", len(store), "arrays")
+
+
+# ------------------------------------------------------------------------------------------
+def upflow_next():
+    """SURVEY §8f rows on the UPFlow side: occlusion check (f2), normalize_features (f4)."""
+    _install_stubs()
+    sys.path[:0] = [REF + "/UPFlow"]
+    from utils.tools import tools
+    import model.upflow as U
+    U.device = torch.device("cpu")
+    gen = torch.Generator().manual_seed(4242)
+    store = {}
+    B, H, W = 2, 24, 40
+    # a roughly consistent pair (flow_b ~ -flow_f) plus noise, plus a stripe leaving the frame
+    ff = 3.0 * torch.randn(B, 2, 1, 1, generator=gen) + 0.8 * torch.randn(B, 2, H, W, generator=gen)
+    fb = -ff + 0.6 * torch.randn(B, 2, H, W, generator=gen)
+    ff[:, 0, :, -6:] += 9.0
+    fb[:, 1, :4] -= 7.0
+    store.update(occ_ff=_np(ff), occ_fb=_np(fb))
+    for mode in ("all", "obj", "out"):
+        for scale in (1, 4):
+            m = tools.occ_check_model(occ_type='for_back_check', occ_alpha_1=0.1, occ_alpha_2=0.5,
+                                      obj_out_all=mode)
+            of, ob = m(flow_f=ff, flow_b=fb, scale=scale)
+            store["occ_%s_s%d_f" % (mode, scale)] = _np(of)
+            store["occ_%s_s%d_b" % (mode, scale)] = _np(ob)
+    # normalize_features: the four flag combinations, gradients included
+    f1 = (1.5 * torch.randn(2, 5, 9, 13, generator=gen) + 0.7).requires_grad_()
+    f2 = (0.5 * torch.randn(2, 5, 9, 13, generator=gen) - 0.2).requires_grad_()
+    store.update(nf_f1=_np(f1), nf_f2=_np(f2))
+    for ch in (False, True):
+        for im in (False, True):
+            o1, o2 = U.network_tools.normalize_features((f1, f2), normalize=True, center=True,
+                                                        moments_across_channels=ch,
+                                                        moments_across_images=im)
+            G1 = torch.randn(o1.shape, generator=torch.Generator().manual_seed(11))
+            G2 = torch.randn(o2.shape, generator=torch.Generator().manual_seed(12))
+            g1, g2 = torch.autograd.grad((o1 * G1).sum() + (o2 * G2).sum(), [f1, f2])
+            tag = "nf_c%d_i%d_" % (int(ch), int(im))
+            for k, v in dict(o1=o1, o2=o2, G1=G1, G2=G2, g1=g1, g2=g2).items():
+                store[tag + k] = _np(v)
+    np.savez_compressed(os.path.join(OUT, "upflow_next.npz"), **store)
+    print("wrote upflow_next.npz", len(store), "arrays")
+
+
+GROUPS = dict(rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
               upflow_e2e=upflow_e2e)
 
 if __name__ == "__main__":

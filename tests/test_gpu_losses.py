@@ -169,7 +169,8 @@ def test_merge_distill_l1_vs_oracle(ops, shape):
 
 
 @pytest.mark.parametrize("shape,sf", [((2, 3, 8, 12, 16), 4.0), ((1, 6, 10, 6, 8), 2.0), ((2, 5, 16, 24, 32), 0.25),
-                                      ((1, 2, 12, 20, 8), 0.5), ((1, 1, 9, 11, 14), 0.5), ((1, 2, 13, 10, 9), 0.25)])
+                                      ((1, 2, 12, 20, 8), 0.5), ((1, 1, 9, 11, 14), 0.5), ((1, 2, 13, 10, 9), 0.25),
+                                      ((1, 2, 8, 8, 6), 0.5), ((1, 3, 8, 4, 12), 0.25)])
 def test_interpolate3d_backward_vs_aten(ops, shape, sf):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(shape, generator=g)
@@ -253,3 +254,47 @@ def test_conv3d_wrw_mfma_vs_autograd(ops, cfg):
     scale = float(gw_ref.abs().max())
     assert gw.shape == gw_ref.shape
     assert float((gw.cpu().double() - gw_ref).abs().max()) < 2e-5 * scale
+
+
+def test_laploss2d_golden(ops, golden):
+    """§8f.3: fs_laploss2d against the value and gradients the reference's LapLoss produced."""
+    g = golden("rife_next")
+    for tag in ("even", "odd", "l3", "c2"):
+        a, b = T(g["lap_%s_a" % tag], True), T(g["lap_%s_b" % tag], True)
+        loss = ops.laploss2d(a, b, int(g["lap_%s_levels" % tag]))
+        ref = float(g["lap_%s_loss" % tag])
+        assert abs(float(loss) - ref) < 2e-6 * abs(ref), (tag, float(loss), ref)
+        ga, gb = torch.autograd.grad(loss, [a, b])
+        # |pyr| is non-differentiable at 0: a pixel whose difference-pyramid entry is ~1e-8 may take
+        # the other sign (one pyramid of a-b here, two pyramids there); bound their number
+        for got, want in ((ga, g["lap_%s_ga" % tag]), (gb, g["lap_%s_gb" % tag])):
+            want = torch.from_numpy(want)
+            err = (got.cpu() - want).abs()
+            scale = float(want.abs().max())
+            assert float((err > 1e-4 * scale).float().mean()) < 2e-3, tag
+            assert float(err.max()) < 2.5 * scale
+        assert torch.equal(ga, -gb)
+
+
+def test_laploss2d_vs_oracle_c2_shape(ops):
+    """C2 shape [16,1,160,224], 5 levels: value + gradients vs the CPU restatement; shape errors."""
+    from oracle import ifnet_ref
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(16, 1, 160, 224, generator=g)
+    b = (a + 0.1 * torch.randn(16, 1, 160, 224, generator=g)).clamp(0, 1)
+    ac, bc = a.clone().requires_grad_(), b.clone()
+    lo = ifnet_ref.lap_loss(ac, bc, 5)
+    (go,) = torch.autograd.grad(lo, [ac])
+    ad = a.to(DEV).requires_grad_()
+    lh = ops.laploss2d(ad, b.to(DEV), 5)
+    (gh,) = torch.autograd.grad(3.0 * lh, [ad])  # the incoming gradient is honoured
+    assert abs(float(lh) - float(lo)) < 2e-6 * float(lo)
+    err = (gh.cpu() / 3.0 - go).abs()
+    assert float((err > 1e-4 * float(go.abs().max())).float().mean()) < 1e-3
+    # identical inputs: zero loss, zero gradient (sign(0) = 0 as in ATen)
+    z = ops.laploss2d(ad, ad.detach().clone(), 5)
+    assert float(z) == 0.0
+    with pytest.raises(ValueError):
+        ops.laploss2d(torch.rand(1, 1, 16, 16, device=DEV), torch.rand(1, 1, 16, 16, device=DEV), 5)  # 16,8,4,2: <3
+    with pytest.raises(ValueError):
+        ops.laploss2d(torch.rand(1, 1, 16, 16, device=DEV), torch.rand(1, 1, 16, 17, device=DEV), 2)

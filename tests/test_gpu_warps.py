@@ -246,3 +246,53 @@ def test_wild_flows_do_not_fault(ops):
     same = (f_ok == f_bad).all(dim=1, keepdim=True).to(DEV)
     o1, o2 = ops.warp3d(x3.detach()[:, :1], f_ok.to(DEV)), ops.warp3d(x3.detach()[:, :1], f_bad.to(DEV))
     assert torch.equal(o1[same], o2[same])
+
+
+def _occ_compare(ops, ff, fb, a1, a2, scale, mode, eps=2e-4):
+    """HIP masks vs oracle masks: identical except where the tested quantity is within `eps` of the
+    threshold (the comparison is discontinuous; fp32 evaluation order decides those pixels)."""
+    of, ob = ops.occ_check2d(ff.to(DEV), fb.to(DEV), a1, a2, scale, mode)
+    rf, rb = owarps.occ_check_ref(ff, fb, a1, a2, scale, mode)
+    assert of.shape == rf.shape and set(np.unique(of.cpu().numpy())) <= {0.0, 1.0}
+    if mode == "out":
+        assert torch.equal(of.cpu(), rf) and torch.equal(ob.cpu(), rb)
+        return 0.0
+    lf, lb, th = owarps.occ_fb_lhs_thresh(ff, fb, a1, a2, scale)
+    bad = 0
+    for o, r, l in ((of, rf, lf), (ob, rb, lb)):
+        diff = o.cpu() != r
+        assert bool(((l - th).abs()[diff] < eps).all()), "mask differs away from the threshold"
+        bad += int(diff.sum())
+    return bad / (2.0 * rf.numel())
+
+
+def test_occ_check_golden(ops, golden):
+    """§8f.2: fs_occ_check2d against the masks the reference itself produced."""
+    g = golden("upflow_next")
+    ff, fb = torch.from_numpy(g["occ_ff"]), torch.from_numpy(g["occ_fb"])
+    for mode in ("all", "obj", "out"):
+        for scale in (1, 4):
+            of, ob = ops.occ_check2d(ff.to(DEV), fb.to(DEV), 0.1, 0.5, scale, mode)
+            nf = int((of.cpu() != torch.from_numpy(g["occ_%s_s%d_f" % (mode, scale)])).sum())
+            nb = int((ob.cpu() != torch.from_numpy(g["occ_%s_s%d_b" % (mode, scale)])).sum())
+            assert nf + nb <= 2, (mode, scale, nf, nb)  # 3840 pixels; threshold ties only
+            assert _occ_compare(ops, ff, fb, 0.1, 0.5, scale, mode) < 1e-3
+
+
+def test_occ_check_vs_oracle_c3_shape(ops):
+    """C3 shape [32,2,150,450] with the UPFlow defaults (alpha 0.1 / 0.5, 'obj')."""
+    g = torch.Generator().manual_seed(5)
+    ff = 2.0 * torch.randn(32, 2, 1, 1, generator=g) + torch.randn(32, 2, 150, 450, generator=g)
+    fb = -ff + 0.5 * torch.randn(32, 2, 150, 450, generator=g)
+    for mode in ("obj", "all", "out"):
+        assert _occ_compare(ops, ff, fb, 0.1, 0.5, 1, mode) < 1e-4
+    # consistent flows (b = -f, constant) are visible everywhere except where they leave the frame
+    c = torch.tensor([3.0, -2.0]).view(1, 2, 1, 1).expand(1, 2, 40, 60).contiguous()
+    of, ob = ops.occ_check2d(c.to(DEV), (-c).to(DEV), 0.1, 0.5, 1, "all")
+    assert float(of[:, :, 4:-4, 4:-4].min()) == 1.0 and float(ob[:, :, 4:-4, 4:-4].min()) == 1.0
+    with pytest.raises(ValueError):
+        ops.occ_check2d(c.to(DEV), c[:, :1].to(DEV), 0.1, 0.5)
+    # wild flows stay inside the tensors
+    w = c.clone(); w[0, 0, 3, 3] = float("nan"); w[0, 1, 5, 5] = float("inf"); w[0, 0, 7, 7] = -1e30
+    ops.occ_check2d(w.to(DEV), (-w).to(DEV), 0.1, 0.5, 1, "obj")
+    torch.cuda.synchronize()

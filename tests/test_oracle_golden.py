@@ -1,5 +1,6 @@
 """The oracle (oracle/) against golden vectors captured from the reference itself
 (tests/golden/make_golden.py).  CPU only.  This is what pins the oracle."""
+import numpy as np
 import torch
 
 from oracle import corr as ocorr
@@ -133,3 +134,31 @@ def test_census_and_photo_losses(golden):
             g1, g2 = torch.autograd.grad(loss, [im1, im2])
             close(g1, g["photo_%s_g1" % tag], 1e-8, 1e-4)
             close(g2, g["photo_%s_g2" % tag], 1e-8, 1e-4)
+
+
+def test_occ_check(golden):
+    """§8f.2: the oracle's occ_check_model against the reference's masks (bit-exact: same torch ops)."""
+    g = golden("upflow_next")
+    ff, fb = T(g["occ_ff"]), T(g["occ_fb"])
+    for mode in ("all", "obj", "out"):
+        for scale in (1, 4):
+            of, ob = owarps.occ_check_ref(ff, fb, 0.1, 0.5, scale, mode)
+            assert torch.equal(of, T(g["occ_%s_s%d_f" % (mode, scale)])), (mode, scale)
+            assert torch.equal(ob, T(g["occ_%s_s%d_b" % (mode, scale)])), (mode, scale)
+    # the fixture exercises both values of every mask
+    for k in ("occ_all_s1_f", "occ_obj_s1_b", "occ_out_s1_f", "occ_out_s1_b"):
+        m = float(np.mean(g[k]))
+        assert 0.05 < m < 0.95, (k, m)
+
+
+def test_lap_loss(golden):
+    """§8f.3: the oracle's LapLoss restatement against the reference's value and gradients."""
+    from oracle import ifnet_ref
+    g = golden("rife_next")
+    for tag in ("even", "odd", "l3", "c2"):
+        a, b = T(g["lap_%s_a" % tag], True), T(g["lap_%s_b" % tag], True)
+        loss = ifnet_ref.lap_loss(a, b, int(g["lap_%s_levels" % tag]))
+        close(loss, g["lap_%s_loss" % tag], 1e-7, 1e-6)
+        ga, gb = torch.autograd.grad(loss, [a, b])
+        close(ga, g["lap_%s_ga" % tag], 1e-9, 1e-5)
+        close(gb, g["lap_%s_gb" % tag], 1e-9, 1e-5)
