@@ -264,6 +264,24 @@ int fs_laploss2d_bwd(const float* sgn, const float* grad_loss, float* ws, float*
                      int N, int H, int W, int levels, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Forward pass of the IFNet-3D convolutions as an implicit GEMM on the fp32 matrix cores
+ * (companion of fs_conv3d_wrw; `conv()` / IFBlock.conv0 / convblock in Flow-3D/model/IFNet.py:13-29,
+ * 31-76: Conv3d(k=3,s=1,p=1) and Conv3d(k=4,s=2,p=1), NCDHW fp32).
+ *   y[b,co,o] = bias[co] + sum_{ci,k} W[co,ci,k] * x[b,ci, o*stride + k - pad]   (zero padding)
+ * x [B,Cin,Di,Hi,Wi] -> y [B,Cout,Do,Ho,Wo], Do = (Di + 2 pad - kernel)/stride + 1 (checked).
+ * (kernel,stride) in {(3,1),(4,2)}.  bias may be NULL.
+ * wmode 0: w is [Cout][Cin][k^3] (Conv3d forward; also the INPUT GRADIENT of a ConvTranspose3d, whose
+ *          weight tensor [Cin_t][Cout_t][k^3] already reads as [out][in] of that convolution);
+ * wmode 1: w is [Cin][Cout][k^3] and is applied flipped (tap k^3-1-k): the INPUT GRADIENT of a
+ *          stride-1 "same" Conv3d is this convolution of grad_out with the layer's own weight.
+ * ws: device scratch of fs_conv3d_fwd_ws_floats(Cin, Cout, kernel) floats (re-laid-out weights).
+ */
+long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel);
+int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws,
+                  int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                  int kernel, int stride, int pad, int wmode, fs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Backward of torch.nn.PReLU(num_parameters = C or 1) as used after every IFNet convolution
  * (`conv()` in Flow-2D/model/IFNet.py and Flow-3D/model/IFNet.py):  y = x > 0 ? x : a[c] x.
  *   grad_x[e] = x > 0 ? g : a[c] g ;  grad_weight[c] = sum_{b,spatial} (x > 0 ? 0 : x g).

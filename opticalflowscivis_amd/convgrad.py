@@ -85,12 +85,35 @@ def _wrw_from_patches(src, g, k, stride, padding):
     return dW.view((Cg, Cs) + tuple(k))
 
 
+_MIN_WORKGROUPS = int(os.environ.get("FLOWSCI_CONV_FWD_MIN_WG", "128"))
+
+
+def _hip_fwd_ok(x, cout, out_dhw, k, stride, padding):
+    """Route this convolution through fs_conv3d_fwd?  Supported (k,s) pairs, fp32 on the GPU, and
+    enough output bricks to fill the chip (small trunk layers stay on MIOpen, which wins there)."""
+    if _MODE != "mfma" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5:
+        return False
+    from . import ops
+    if not ops.conv3d_wrw_supported(k, stride, padding):
+        return False
+    return ops.conv3d_fwd_workgroups(x.shape[0], cout, out_dhw, k[0]) >= _MIN_WORKGROUPS
+
+
+def _conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, transposed):
         nd = x.dim() - 2
         if transposed:
             y = (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
+        elif nd == 3 and _hip_fwd_ok(x, w.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
+                                                     zip(x.shape[2:], w.shape[2:], stride, padding)],
+                                     tuple(w.shape[2:]), stride, padding):
+            from . import ops
+            y = ops.conv3d_fwd(x, w, b, w.shape[2], stride[0], padding[0], 0)
         else:
             y = (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, padding)
         ctx.save_for_backward(x, w)
@@ -111,8 +134,19 @@ class _ConvFn(torch.autograd.Function):
                 # with the flipped, channel-transposed filter -> MIOpen's forward kernel (CK, 2.0 ms per
                 # 64->64 layer at 64^3) instead of its backward-data solvers (2.7 ms CK / >4 ms GEMM+Col2Im,
                 # whichever its un-tuned find step happens to pick)
-                wf = w.transpose(0, 1).flip(*range(2, 2 + nd)).contiguous()
-                gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, stride, padding)
+                if nd == 3 and _hip_fwd_ok(gy, w.shape[1], x.shape[2:], k, stride, padding):
+                    from . import ops  # flip + transpose happen in the kernel's weight re-layout
+                    gx = ops.conv3d_fwd(gy, w, None, k[0], 1, padding[0], 1)
+                else:
+                    wf = w.transpose(0, 1).flip(*range(2, 2 + nd)).contiguous()
+                    gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, stride, padding)
+            elif (transposed and nd == 3 and _hip_fwd_ok(gy, w.shape[0], x.shape[2:], k, stride, padding) and
+                  all(_conv_out(n, kk, s, p) == m for n, kk, s, p, m in
+                      zip(gy.shape[2:], k, stride, padding, x.shape[2:]))):
+                # input gradient of a transposed convolution = the strided convolution of grad_out with
+                # the same weight tensor read as [out = Cin_t][in = Cout_t]
+                from . import ops
+                gx = ops.conv3d_fwd(gy, w, None, k[0], stride[0], padding[0], 0)
             else:  # MIOpen backward-data
                 gx = torch.ops.aten.convolution_backward(
                     gy, x, w, None, list(stride), list(padding), [1] * nd, transposed, [0] * nd, 1,
@@ -136,6 +170,13 @@ def _use_gemm(x):
 class Conv3d(nn.Conv3d):
     def forward(self, x):
         if not _use_gemm(x):
+            st, pd, k = _tuple(self.stride, 3), _tuple(self.padding, 3), tuple(self.weight.shape[2:])
+            if x.dim() == 5 and self.padding_mode == "zeros" and self.groups == 1 and _tuple(self.dilation, 3) == (1, 1, 1) \
+                    and _hip_fwd_ok(x, self.weight.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
+                                                              zip(x.shape[2:], k, st, pd)], k, st, pd):
+                from . import ops  # inference: same kernel, no autograd node
+                return ops.conv3d_fwd(x, self.weight.detach(), None if self.bias is None else self.bias.detach(),
+                                      k[0], st[0], pd[0], 0)
             return super().forward(x)
         return _ConvFn.apply(x, self.weight, self.bias, _tuple(self.stride, 3), _tuple(self.padding, 3), False)
 

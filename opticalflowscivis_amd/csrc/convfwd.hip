@@ -1,0 +1,254 @@
+// convfwd.hip -- forward pass of the IFNet-3D convolutions (and, with flipped / transposed weights,
+// the input gradient of its stride-1 layers and of its transposed convolutions) as an implicit GEMM
+// on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) for gfx950, NCDHW in, NCDHW out.
+//
+// Not one of the §8(a) rows: a companion of convwrw.hip.  MIOpen (ROCm 7.2, no gfx950 tuning db)
+// runs these layers through CK's NDHWC kernels behind layout transposes (~58 TFLOP/s + 14 ms of
+// batched_transpose per 256^3 step), and the strided / transposed ones through GEMM + Col2Im
+// (~27 TFLOP/s) -- profiles/r01_bench_256_kernel_stats.csv.
+//
+//   Y[b, co, oz,oy,ox] = bias[co] + sum_{ci,kz,ky,kx} W[co, ci, kz,ky,kx] * X[b, ci, oz*s+kz-p, ...]
+//
+//   M = Cout (32 / 64 per workgroup),  N = output voxels,  K = Cin * k^3.
+//
+// Decomposition.  A workgroup (4 waves) owns a TZ x (TY*32/TW) x TW brick of output voxels for 32*MT
+// output channels.  The reduction runs over chunks of CI input channels: per chunk the input brick
+// with its halo ((TZ-1)s+k x (TYR-1)s+k x (TW-1)s+k, zero padded) and the CI*k^3 x 32*MT weight slab
+// are staged in LDS, then each wave issues MT*NT MFMAs per reduction pair for its NT 32-voxel
+// column tiles.  The two reduction elements of a 32x32x2 MFMA are the same tap of input channels cl
+// and cl + CI/2, so both operand addresses are "per-lane base + compile-time immediate": im2col is
+// only an LDS addressing pattern.  LDS reads run one pair ahead of the MFMAs (register rotation).
+// Two workgroups per CU (<= 80 KB LDS each): one stages while the other feeds the matrix cores.
+//
+// Weights arrive re-laid-out as Wt[ci][tap][co] (co contiguous, zero padded to the tile sizes) by
+// wprep_kernel, which also applies the flip + transpose that turns the stride-1 input gradient
+// into a forward convolution.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FP {
+  int B, Cin, Cout, CoutP;
+  int Di, Hi, Wi, Do, Ho, Wo;
+  int pad;
+  int tz, ty, tx;  // tiles per axis
+  long long tiles;
+};
+
+// Wt[ci][tap][co] (ci < CinP, co < CoutP; zero outside the real channels)
+//   mode 0: W[co][ci][tap]                       (Conv3d forward; ConvTranspose3d input gradient)
+//   mode 1: W[ci][co][K3-1-tap]                  (stride-1 "same" Conv3d input gradient)
+__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
+                                                    int Cin, int K3, int CinP, int CoutP, int mode) {
+  const int total = CinP * K3 * CoutP;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int co = e % CoutP;
+    const int t = e / CoutP;
+    const int tap = t % K3, ci = t / K3;
+    float v = 0.f;
+    if (co < Cout && ci < Cin)
+      v = mode ? w[((size_t)ci * Cout + co) * K3 + (K3 - 1 - tap)] : w[((size_t)co * Cin + ci) * K3 + tap];
+    wt[e] = v;
+  }
+}
+
+template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
+__global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restrict__ X,
+                                                         const float* __restrict__ Wt,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ Y, FP p) {
+  constexpr int K3 = K * K * K;
+  constexpr int R = 32 / TW;    // output rows (y) inside one 32-column MFMA tile
+  constexpr int TYR = TY * R;   // output rows (y) of the brick
+  static_assert(TZ * TY == 4 * NT && TY % NT == 0 && (CI % 2) == 0 && (TW == 32 || TW == 16), "tile shape");
+  constexpr int ZT = (TZ - 1) * S + K, YT = (TYR - 1) * S + K, XT = (TW - 1) * S + K;
+  constexpr int PS = YT * XT, CHS = ZT * PS;  // plane / channel pitch of the staged brick
+  constexpr int CP = 32 * MT;
+  constexpr int NP = (CI / 2) * K3;           // reduction pairs per chunk
+  constexpr int NX = CI * CHS, NW = CI * K3 * CP;
+  __shared__ float sX[NX];
+  __shared__ __attribute__((aligned(16))) float sW[NW];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+
+  // brick of this workgroup.  Consecutive workgroup ids land on different XCDs (round robin over
+  // 8); give each XCD a contiguous range of bricks so that halo re-reads hit its own L2.
+  long long tile = blockIdx.x;
+  {
+    const long long per = p.tiles / 8;
+    if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int txi = (int)(tile % p.tx); tile /= p.tx;
+  const int tyi = (int)(tile % p.ty); tile /= p.ty;
+  const int tzi = (int)(tile % p.tz);
+  const int b = (int)(tile / p.tz);
+  const int oz0 = tzi * TZ, oy0 = tyi * TYR, ox0 = txi * TW;
+  const int co0 = blockIdx.y * CP;
+
+  const int ly = col / TW, lx = col % TW;
+  const int rr0 = wv * NT;                // first row slot of this wave (all NT share one z)
+  const int wz = rr0 / TY, wy = rr0 % TY;
+  const float* bB = sX + kh * (CI / 2) * CHS + (wz * S) * PS + ((wy * R + ly) * S) * XT + lx * S;
+  const float* aB = sW + kh * (CI / 2) * K3 * CP + col;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
+  const int gz0 = oz0 * S - p.pad, gy0 = oy0 * S - p.pad, gx0 = ox0 * S - p.pad;
+  constexpr int ITX = (NX + 255) / 256;
+  constexpr int ITW = (NW / 4 + 255) / 256;
+
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+    // ---- stage the input brick (zero outside the volume / beyond Cin) and the weight slab
+    const float* xb = X + ((size_t)b * p.Cin + c0) * xvol;
+#pragma unroll 4
+    for (int it = 0; it < ITX; ++it) {
+      const int i = t + 256 * it;
+      if (i < NX) {
+        const int c = i / CHS, r1 = i - c * CHS;
+        const int z = r1 / PS, r2 = r1 - z * PS;
+        const int y = r2 / XT, x = r2 - y * XT;
+        const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
+        float v = 0.f;
+        if (c0 + c < p.Cin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
+          v = xb[(size_t)c * xvol + ((size_t)gz * p.Hi + gy) * p.Wi + gx];
+        sX[i] = v;
+      }
+    }
+    const float* wb = Wt + (size_t)c0 * K3 * p.CoutP + co0;
+#pragma unroll
+    for (int it = 0; it < ITW; ++it) {
+      const int i4 = t + 256 * it;
+      if (i4 < NW / 4) {
+        const int row = i4 / (CP / 4), j4 = i4 - row * (CP / 4);
+        const float4 v = *reinterpret_cast<const float4*>(wb + (size_t)row * p.CoutP + 4 * j4);
+        *reinterpret_cast<float4*>(sW + row * CP + 4 * j4) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA phase: pair j = (cl, tap); lanes 32..63 feed channel cl + CI/2
+    auto lds_ops = [&](int j, float (&a)[MT], float (&bq)[NT]) {
+      const int cl = j / K3, tap = j - cl * K3;
+      const int kz = tap / (K * K), ky = (tap / K) % K, kx = tap % K;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = aB[(cl * K3 + tap) * CP + m * 32];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bq[n] = bB[cl * CHS + kz * PS + (ky + n * R * S) * XT + kx];
+    };
+    auto mma = [&](const float (&a)[MT], const float (&bq)[NT]) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[n], acc[m][n], 0, 0, 0);
+    };
+    float a0[MT], b0[NT], a1[MT], b1[NT];
+    lds_ops(0, a0, b0);
+#pragma unroll
+    for (int j = 0; j < NP; j += 2) {
+      if (j + 1 < NP) lds_ops(j + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      if (j + 2 < NP) lds_ops(j + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < NP) mma(a1, b1);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: row (channel) = (r&3) + 8*(r>>2) + 4*kh, column (voxel) = lane & 31
+  const int oz = oz0 + wz;
+  const int ox = ox0 + lx;
+  if (oz < p.Do && ox < p.Wo) {
+    const size_t yvol = (size_t)p.Do * p.Ho * p.Wo;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int oy = oy0 + (wy + n) * R + ly;
+      if (oy >= p.Ho) continue;
+      float* yb = Y + (size_t)b * p.Cout * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (co < p.Cout) yb[(size_t)co * yvol] = acc[m][n][r] + (bias ? bias[co] : 0.f);
+        }
+    }
+  }
+}
+
+template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
+int launch(const float* X, const float* Wt, const float* bias, float* Y, FP& p, hipStream_t st) {
+  constexpr int TYR = TY * (32 / TW);
+  p.tz = fs::cdiv(p.Do, TZ); p.ty = fs::cdiv(p.Ho, TYR); p.tx = fs::cdiv(p.Wo, TW);
+  p.tiles = (long long)p.B * p.tz * p.ty * p.tx;
+  const int mgroups = p.CoutP / (32 * MT);
+  if (p.tiles >= (1ll << 31) || mgroups > 65535) return FS_ERR_SHAPE;
+  hipLaunchKernelGGL((conv3d_fwd_kernel<K, S, CI, MT, NT, TZ, TY, TW>), dim3((unsigned)p.tiles, mgroups),
+                     dim3(256), 0, st, X, Wt, bias, Y, p);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// channel padding of the re-laid-out weights for a layer
+void wt_dims(int Cin, int Cout, int kernel, int* CinP, int* CoutP) {
+  const int ci = (kernel == 3) ? 4 : 2;
+  *CinP = (Cin + ci - 1) / ci * ci;
+  *CoutP = (Cout <= 32 && kernel == 4) ? 32 : (Cout + 63) / 64 * 64;
+}
+
+}  // namespace
+
+extern "C" long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel) {
+  if (Cin < 1 || Cout < 1 || (kernel != 3 && kernel != 4)) return -1;
+  int cinp, coutp;
+  wt_dims(Cin, Cout, kernel, &cinp, &coutp);
+  return (long long)cinp * kernel * kernel * kernel * coutp;
+}
+
+extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B,
+                             int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kernel,
+                             int stride, int pad, int wmode, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y); FS_REQUIRE_PTR(ws);
+  if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1 || Do < 1 || Ho < 1 || Wo < 1)
+    return FS_ERR_SHAPE;
+  if (!((kernel == 3 && stride == 1) || (kernel == 4 && stride == 2)) || pad < 0 || pad >= kernel ||
+      (wmode != 0 && wmode != 1))
+    return FS_ERR_ARG;
+  // the output grid must be the convolution's: floor((in + 2p - k) / s) + 1
+  if (Do != (Di + 2 * pad - kernel) / stride + 1 || Ho != (Hi + 2 * pad - kernel) / stride + 1 ||
+      Wo != (Wi + 2 * pad - kernel) / stride + 1)
+    return FS_ERR_SHAPE;
+  if ((long long)Di * Hi * Wi >= (1ll << 31) || (long long)Do * Ho * Wo >= (1ll << 31)) return FS_ERR_SHAPE;
+  FP p;
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Do; p.Ho = Ho; p.Wo = Wo;
+  p.pad = pad;
+  int cinp;
+  wt_dims(Cin, Cout, kernel, &cinp, &p.CoutP);
+  hipStream_t st = (hipStream_t)stream;
+  const int K3 = kernel * kernel * kernel;
+  const int total = cinp * K3 * p.CoutP;
+  hipLaunchKernelGGL(wprep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, ws, Cout, Cin, K3, cinp,
+                     p.CoutP, wmode);
+  if (kernel == 3) {
+    if (Wo > 16) return launch<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
+    return launch<3, 1, 4, 2, 4, 2, 8, 16>(x, ws, bias, y, p, st);
+  }
+  if (p.CoutP == 32) {
+    if (Wo > 16) return launch<4, 2, 2, 1, 2, 1, 8, 32>(x, ws, bias, y, p, st);
+    return launch<4, 2, 2, 1, 2, 1, 8, 16>(x, ws, bias, y, p, st);
+  }
+  if (Wo > 16) return launch<4, 2, 2, 2, 2, 1, 8, 32>(x, ws, bias, y, p, st);
+  return launch<4, 2, 2, 2, 2, 1, 8, 16>(x, ws, bias, y, p, st);
+}

@@ -802,6 +802,42 @@ def conv3d_wrw(g, src, k, stride, pad):
     return dw
 
 
+def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
+    """Workgroups fs_conv3d_fwd launches for this layer (mirrors its tile choice, csrc/convfwd.hip)."""
+    Do, Ho, Wo = out_dhw
+    tw = 32 if Wo > 16 else 16
+    tyr = 8 * (32 // tw)
+    tz = 2 if k == 3 else 1
+    mg = 1 if (k == 4 and Cout <= 32) else -(-Cout // 64)
+    return B * (-(-Do // tz)) * (-(-Ho // tyr)) * (-(-Wo // tw)) * mg
+
+
+def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0):
+    """fs_conv3d_fwd: y = conv3d(x, W, bias, stride, pad) with W = w (wmode 0, [Cout,Cin,k,k,k]) or the
+    flipped transpose of w (wmode 1, w [Cin,Cout,k,k,k]: input gradient of a stride-1 same conv)."""
+    x = _need_cuda_f32("x", x, 5)
+    w = _need_cuda_f32("w", w, 5)
+    B, Cin = x.shape[:2]
+    Cout = w.shape[1] if wmode else w.shape[0]
+    if (w.shape[0] if wmode else w.shape[1]) != Cin or tuple(w.shape[2:]) != (k, k, k):
+        raise ValueError("weight %s does not fit input %s (wmode %d)" % (tuple(w.shape), tuple(x.shape), wmode))
+    if bias is not None:
+        bias = _need_cuda_f32("bias", bias, 1)
+        if bias.numel() != Cout:
+            raise ValueError("bias must have %d elements" % Cout)
+    Di, Hi, Wi = x.shape[2:]
+    Do, Ho, Wo = [(n + 2 * pad - k) // stride + 1 for n in (Di, Hi, Wi)]
+    if min(Do, Ho, Wo) < 1:
+        raise ValueError("convolution output is empty for input %s" % (tuple(x.shape),))
+    y = x.new_empty((B, Cout, Do, Ho, Wo))
+    ws = x.new_empty(int(_lib.lib().fs_conv3d_fwd_ws_floats(Cin, Cout, int(k))))
+    with torch.cuda.device(x.device):
+        _call("fs_conv3d_fwd", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin, Cout,
+              Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode), _stream(x),
+              algo_bytes=4 * (x.numel() + y.numel()), algo_flops=2 * y.numel() * Cin * int(k) ** 3)
+    return y
+
+
 # --------------------------------------------------------------------------------------------
 # a9 'SSIM' branch: weighted SSIM + masked reduction, fused (upflow.py:141-196, 285-289)
 # --------------------------------------------------------------------------------------------

@@ -298,3 +298,51 @@ def test_laploss2d_vs_oracle_c2_shape(ops):
         ops.laploss2d(torch.rand(1, 1, 16, 16, device=DEV), torch.rand(1, 1, 16, 16, device=DEV), 5)  # 16,8,4,2: <3
     with pytest.raises(ValueError):
         ops.laploss2d(torch.rand(1, 1, 16, 16, device=DEV), torch.rand(1, 1, 16, 17, device=DEV), 2)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(cin=64, cout=64, k=3, s=1, size=(6, 18, 40), tr=False),    # trunk layer, 32-wide bricks
+    dict(cin=7, cout=70, k=3, s=1, size=(5, 9, 13), tr=False),      # ragged: Cin % 4, Cout % 64, 16-wide bricks
+    dict(cin=128, cout=128, k=3, s=1, size=(4, 8, 16), tr=False),   # two output-channel groups
+    dict(cin=11, cout=32, k=4, s=2, size=(8, 20, 70), tr=False),    # block conv0a (32 output channels)
+    dict(cin=32, cout=64, k=4, s=2, size=(6, 12, 30), tr=False),    # block conv0b
+    dict(cin=3, cout=5, k=4, s=2, size=(7, 9, 13), tr=False),       # odd input extent
+    dict(cin=64, cout=32, k=4, s=2, size=(3, 6, 18), tr=True),      # deconv head: input gradient = strided conv
+    dict(cin=32, cout=6, k=4, s=2, size=(4, 7, 20), tr=True),
+])
+def test_conv3d_fwd_mfma_vs_fp64(ops, cfg, monkeypatch):
+    """fs_conv3d_fwd (forward, stride-1 input gradient via flipped weights, transposed-conv input
+    gradient) against an fp64 CPU convolution; the autograd wiring of convgrad with it forced on."""
+    import torch.nn.functional as F
+    from opticalflowscivis_amd import convgrad
+    monkeypatch.setattr(convgrad, "_MIN_WORKGROUPS", 0)
+    g = torch.Generator().manual_seed(cfg["cin"] * 13 + cfg["cout"])
+    B = 2
+    x = torch.randn((B, cfg["cin"]) + cfg["size"], generator=g)
+    wshape = (cfg["cin"], cfg["cout"]) if cfg["tr"] else (cfg["cout"], cfg["cin"])
+    w = torch.randn(wshape + (cfg["k"],) * 3, generator=g) * 0.1
+    bias = torch.randn(cfg["cout"], generator=g)
+    fn = F.conv_transpose3d if cfg["tr"] else F.conv3d
+    s3, p3 = (cfg["s"],) * 3, (1,) * 3
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), bias.double().requires_grad_()
+    yr = fn(xr, wr, br, s3, p3)
+    G = torch.randn(yr.shape, generator=g)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad((yr * G.double()).sum(), [xr, wr, br])
+    xd, wd, bd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), bias.to(DEV).requires_grad_()
+    ops.enable_kernel_timing(True)
+    y = convgrad._ConvFn.apply(xd, wd, bd, s3, p3, cfg["tr"])
+    gx, gw, gb = torch.autograd.grad((y * G.to(DEV)).sum(), [xd, wd, bd])
+    torch.cuda.synchronize()
+    names = set(ops.kernel_timings().keys())
+    ops.enable_kernel_timing(False)
+    assert "fs_conv3d_fwd" in names, names  # the HIP path ran (forward for convs, input gradient for all)
+    for got, ref in ((y, yr), (gx, gx_ref), (gw, gw_ref), (gb, gb_ref)):
+        scale = float(ref.abs().max())
+        assert got.shape == ref.shape
+        assert float((got.detach().cpu().double() - ref.detach()).abs().max()) < 3e-5 * scale
+    if not cfg["tr"]:
+        # inference path (no autograd node) gives the same bits as the training forward
+        m = convgrad.Conv3d(cfg["cin"], cfg["cout"], cfg["k"], cfg["s"], 1).to(DEV)
+        with torch.no_grad():
+            m.weight.copy_(wd); m.bias.copy_(bd)
+            assert torch.equal(m(xd), y)
