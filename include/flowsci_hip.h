@@ -282,6 +282,23 @@ int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, f
                   int kernel, int stride, int pad, int wmode, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * ConvTranspose3d(k=4, s=2, p=1) forward -- the IFNet-3D heads (`conv1` / `conv2` of IFBlock,
+ * Flow-3D/model/IFNet.py:62-75) -- which is also the INPUT GRADIENT of Conv3d(k=4, s=2, p=1)
+ * (IFBlock.conv0, Flow-3D/model/IFNet.py:34-37) applied to grad_out.
+ *   y[b,co,o] = bias[co] + sum_{ci,k : (o + 1 - k) even} x[b,ci,(o + 1 - k)/2] * w[ci,co,k]
+ * x [B,Cin,Di,Hi,Wi], w [Cin][Cout][4*4*4] (a ConvTranspose3d weight as stored; a Conv3d weight
+ * [Cout_conv][Cin_conv][64] reads the same way for its input gradient), bias may be NULL,
+ * y [B,Cout,Dout,Hout,Wout] with out = 2*in per axis (or 2*in + 1: input gradient of a convolution
+ * whose odd input extent left its last plane unused -- that plane receives zeros).
+ * Cout <= 32 (FS_ERR_ARG otherwise).  ws: fs_conv3d_tr_ws_floats(Cin, Cout) floats of device scratch
+ * (0 for Cout <= 12: those run on the vector ALUs with scalar-loaded weights).
+ */
+long long fs_conv3d_tr_ws_floats(int Cin, int Cout);
+int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws,
+                 int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
+                 fs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Backward of torch.nn.PReLU(num_parameters = C or 1) as used after every IFNet convolution
  * (`conv()` in Flow-2D/model/IFNet.py and Flow-3D/model/IFNet.py):  y = x > 0 ? x : a[c] x.
  *   grad_x[e] = x > 0 ? g : a[c] g ;  grad_weight[c] = sum_{b,spatial} (x > 0 ? 0 : x g).

@@ -38,6 +38,8 @@ SIGNATURES = {
     "fs_laploss2d_bwd": [_f32p] * 4 + [_int] * 4 + [_stream],
     "fs_conv3d_fwd_ws_floats": [_int] * 3,
     "fs_conv3d_fwd": [_f32p] * 5 + [_int] * 13 + [_stream],
+    "fs_conv3d_tr_ws_floats": [_int] * 2,
+    "fs_conv3d_tr": [_f32p] * 5 + [_int] * 9 + [_stream],
     "fs_corr2d_fwd": [_f32p] * 3 + [_int] * 5 + [_stream],
     "fs_corr2d_bwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_robust_sum": [_f32p] * 5 + [_int] * 7 + [_float, _float, _stream],
@@ -59,7 +61,8 @@ SIGNATURES = {
     "fs_warp2d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                       _stream],
 }
-_RESTYPES = {"fs_error_string": ctypes.c_char_p, "fs_conv3d_fwd_ws_floats": ctypes.c_longlong}
+_RESTYPES = {"fs_error_string": ctypes.c_char_p, "fs_conv3d_fwd_ws_floats": ctypes.c_longlong,
+             "fs_conv3d_tr_ws_floats": ctypes.c_longlong}
 
 
 class FlowsciLibraryError(RuntimeError):

@@ -86,6 +86,7 @@ def _wrw_from_patches(src, g, k, stride, padding):
 
 
 _MIN_WORKGROUPS = int(os.environ.get("FLOWSCI_CONV_FWD_MIN_WG", "128"))
+_MIN_TR_POSITIONS = int(os.environ.get("FLOWSCI_CONV_TR_MIN_POS", "16384"))  # input voxels (all samples)
 
 
 def _hip_fwd_ok(x, cout, out_dhw, k, stride, padding):
@@ -99,6 +100,16 @@ def _hip_fwd_ok(x, cout, out_dhw, k, stride, padding):
     return ops.conv3d_fwd_workgroups(x.shape[0], cout, out_dhw, k[0]) >= _MIN_WORKGROUPS
 
 
+def _hip_tr_ok(x, cout, k, stride, padding):
+    """Route a ConvTranspose3d(4,2,1) forward / Conv3d(4,2,1) input gradient through fs_conv3d_tr?"""
+    if _MODE != "mfma" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5:
+        return False
+    from . import ops
+    if not ops.conv3d_tr_supported(cout, k, stride, padding):
+        return False
+    return x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4] >= _MIN_TR_POSITIONS
+
+
 def _conv_out(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
@@ -107,7 +118,10 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, transposed):
         nd = x.dim() - 2
-        if transposed:
+        if transposed and nd == 3 and _hip_tr_ok(x, w.shape[1], tuple(w.shape[2:]), stride, padding):
+            from . import ops
+            y = ops.conv3d_tr(x, w, b)
+        elif transposed:
             y = (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
         elif nd == 3 and _hip_fwd_ok(x, w.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
                                                      zip(x.shape[2:], w.shape[2:], stride, padding)],
@@ -147,6 +161,12 @@ class _ConvFn(torch.autograd.Function):
                 # the same weight tensor read as [out = Cin_t][in = Cout_t]
                 from . import ops
                 gx = ops.conv3d_fwd(gy, w, None, k[0], stride[0], padding[0], 0)
+            elif (not transposed and nd == 3 and _hip_tr_ok(gy, w.shape[1], k, stride, padding) and
+                  all(n in (2 * m, 2 * m + 1) for n, m in zip(x.shape[2:], gy.shape[2:]))):
+                # input gradient of Conv3d(4, 2, 1) = the transposed convolution of grad_out with the
+                # layer's weight [Cout][Cin][64] read as [in][out][64]
+                from . import ops
+                gx = ops.conv3d_tr(gy, w, None, x.shape[2:])
             else:  # MIOpen backward-data
                 gx = torch.ops.aten.convolution_backward(
                     gy, x, w, None, list(stride), list(padding), [1] * nd, transposed, [0] * nd, 1,
@@ -184,6 +204,11 @@ class Conv3d(nn.Conv3d):
 class ConvTranspose3d(nn.ConvTranspose3d):
     def forward(self, x):
         if not _use_gemm(x):
+            st, pd, k = _tuple(self.stride, 3), _tuple(self.padding, 3), tuple(self.weight.shape[2:])
+            if x.dim() == 5 and self.groups == 1 and _tuple(self.dilation, 3) == (1, 1, 1) and \
+                    _tuple(self.output_padding, 3) == (0, 0, 0) and _hip_tr_ok(x, self.weight.shape[1], k, st, pd):
+                from . import ops  # inference: same kernel, no autograd node
+                return ops.conv3d_tr(x, self.weight.detach(), None if self.bias is None else self.bias.detach())
             return super().forward(x)
         return _ConvFn.apply(x, self.weight, self.bias, _tuple(self.stride, 3), _tuple(self.padding, 3), True)
 

@@ -1,0 +1,288 @@
+// convtr.hip -- ConvTranspose3d(k=4, s=2, p=1) forward of the IFNet-3D heads, which is also the input
+// gradient of the Conv3d(k=4, s=2, p=1) layers (IFBlock.conv0), for gfx950.
+//
+// Companion of convfwd.hip / convwrw.hip (not a §8(a) row).  MIOpen runs every one of these through
+// GEMM + Col2Im3dU, one sample at a time: 64 ms of the 231 ms 256^3 step.
+//
+//   y[b, co, z,y,x] = bias[co] + sum_{ci} sum_{k : (z + 1 - kz) even, ...} x[b, ci, (z+1-kz)/2, ...] * W[ci, co, kz,ky,kx]
+//
+// Sub-pixel form: an output voxel of parity (pz,py,px) at z = 2q + pz sees exactly two taps per axis,
+//   parity 0: (input q, k = 1), (input q-1, k = 3)        parity 1: (input q+1, k = 0), (input q, k = 2)
+// so the layer is 8 independent 2x2x2 convolutions over the INPUT grid sharing one 3x3x3 input
+// neighbourhood.  One thread / one MFMA column owns one input-grid position q and produces all 8
+// output voxels 2q + {0,1}^3: stores are float2 (both x parities) and fully coalesced.
+//
+//   convtr_mfma_kernel (12 < Cout <= 32): implicit GEMM on v_mfma_f32_32x32x2_f32, M = 32 output
+//       channels, N = 32 consecutive qx, 8 accumulator tiles (one per parity class) per wave; per chunk
+//       of 4 input channels the 3x3x3-haloed input brick and the [4][64][32] weight slab sit in LDS.
+//   convtr_valu_kernel<CO> (Cout <= 12: the flow / mask heads, the gradient w.r.t. the 11/12-channel
+//       block input): padding 6 channels to a 32-row MFMA tile wastes 80 % of the matrix core, and the
+//       fp32 vector ALUs have the same peak as the fp32 matrix cores on this part.  One thread per q,
+//       8*CO accumulators, weights are wave-uniform -> scalar loads feeding v_fmac's SGPR operand.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TP {
+  int B, Cin, Cout;
+  int Di, Hi, Wi;        // input extent
+  int Dout, Hout, Wout;  // output extent (2*in or 2*in + 1 per axis)
+  int Dq, Hq, Wq;        // input-grid positions that own outputs: ceil(out / 2)
+  int tz, ty, tx;
+  long long tiles;
+};
+
+// tap a (0/1) of output parity p along one axis: input offset d and kernel index k
+__device__ __forceinline__ constexpr int tap_d(int p, int a) { return p == 0 ? (a == 0 ? 0 : -1) : (a == 0 ? 1 : 0); }
+__device__ __forceinline__ constexpr int tap_k(int p, int a) { return p == 0 ? (a == 0 ? 1 : 3) : (a == 0 ? 0 : 2); }
+
+// Wt[ci][tap 0..63][co 0..31] <- W[ci][co][tap]  (zero for co >= Cout, ci >= Cin)
+__global__ __launch_bounds__(256) void wprep_tr_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin,
+                                                       int Cout, int CinP) {
+  const int total = CinP * 64 * 32;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int co = e & 31, tap = (e >> 5) & 63, ci = e >> 11;
+    wt[e] = (co < Cout && ci < Cin) ? w[((size_t)ci * Cout + co) * 64 + tap] : 0.f;
+  }
+}
+
+// all 8 outputs of position q for channel co; float2 stores when the rows are 8-byte aligned
+__device__ __forceinline__ void store8(float* __restrict__ yc, const float (&v)[8], int qz, int qy, int qx,
+                                       const TP& p) {
+#pragma unroll
+  for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      const int z = 2 * qz + pz, y = 2 * qy + py, x = 2 * qx;
+      if (z >= p.Dout || y >= p.Hout || x >= p.Wout) continue;
+      float* row = yc + ((size_t)z * p.Hout + y) * p.Wout + x;
+      const float v0 = v[(pz * 2 + py) * 2], v1 = v[(pz * 2 + py) * 2 + 1];
+      if ((p.Wout & 1) == 0) {
+        *reinterpret_cast<float2*>(row) = make_float2(v0, v1);
+      } else {
+        row[0] = v0;
+        if (x + 1 < p.Wout) row[1] = v1;
+      }
+    }
+}
+
+template <int TZ, int TY>
+__global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __restrict__ X,
+                                                          const float* __restrict__ Wt,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ Y, TP p) {
+  static_assert(TZ * TY == 4, "one 32-position row per wave");
+  constexpr int CI = 4;
+  constexpr int ZT = TZ + 2, YT = TY + 2, XT = 34;
+  constexpr int PS = YT * XT, CHS = ZT * PS;
+  constexpr int NX = CI * CHS, NW = CI * 64 * 32;
+  __shared__ float sX[NX];
+  __shared__ __attribute__((aligned(16))) float sW[NW];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  long long tile = blockIdx.x;
+  {
+    const long long per = p.tiles / 8;  // contiguous brick range per XCD (see convfwd.hip)
+    if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int txi = (int)(tile % p.tx); tile /= p.tx;
+  const int tyi = (int)(tile % p.ty); tile /= p.ty;
+  const int tzi = (int)(tile % p.tz);
+  const int b = (int)(tile / p.tz);
+  const int qz0 = tzi * TZ, qy0 = tyi * TY, qx0 = txi * 32;
+  const int wz = wv / TY, wy = wv % TY;
+
+  const float* bB = sX + kh * 2 * CHS + (wz + 1) * PS + (wy + 1) * XT + (col + 1);
+  const float* aB = sW + kh * 2 * 64 * 32 + col;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
+  constexpr int ITX = (NX + 255) / 256, ITW = NW / 4 / 256;
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+    const float* xb = X + ((size_t)b * p.Cin + c0) * xvol;
+#pragma unroll 3
+    for (int it = 0; it < ITX; ++it) {
+      const int i = t + 256 * it;
+      if (i < NX) {
+        const int c = i / CHS, r1 = i - c * CHS;
+        const int z = r1 / PS, r2 = r1 - z * PS;
+        const int y = r2 / XT, x = r2 - y * XT;
+        const int gz = qz0 - 1 + z, gy = qy0 - 1 + y, gx = qx0 - 1 + x;
+        float v = 0.f;
+        if (c0 + c < p.Cin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
+          v = xb[(size_t)c * xvol + ((size_t)gz * p.Hi + gy) * p.Wi + gx];
+        sX[i] = v;
+      }
+    }
+    const float4* wb = reinterpret_cast<const float4*>(Wt + (size_t)c0 * 64 * 32);
+#pragma unroll
+    for (int it = 0; it < ITW; ++it) reinterpret_cast<float4*>(sW)[t + 256 * it] = wb[t + 256 * it];
+    __syncthreads();
+
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      float xn[27];  // the 3x3x3 input neighbourhood of this lane's position (channel cl / cl+2 by kh)
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            xn[(dz * 3 + dy) * 3 + dx] = bB[cl * CHS + (dz - 1) * PS + (dy - 1) * XT + (dx - 1)];
+#pragma unroll
+      for (int cls = 0; cls < 8; ++cls) {
+        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+#pragma unroll
+        for (int tp = 0; tp < 8; ++tp) {
+          const int a = tp >> 2, bb = (tp >> 1) & 1, c = tp & 1;
+          const int kidx = (tap_k(pz, a) * 4 + tap_k(py, bb)) * 4 + tap_k(px, c);
+          const int didx = ((tap_d(pz, a) + 1) * 3 + (tap_d(py, bb) + 1)) * 3 + (tap_d(px, c) + 1);
+          const float av = aB[(cl * 64 + kidx) * 32];
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xn[didx], acc[cls], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int qz = qz0 + wz, qy = qy0 + wy, qx = qx0 + col;
+  if (qz < p.Dq && qy < p.Hq && qx < p.Wq) {
+    const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (co >= p.Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = acc[c][r] + bv;
+      store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p);
+    }
+  }
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void convtr_valu_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ Y,
+                                                          TP p) {
+  const long long nq = (long long)p.B * p.Dq * p.Hq * p.Wq;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nq) return;
+  const int qx = (int)(e % p.Wq);
+  long long r = e / p.Wq;
+  const int qy = (int)(r % p.Hq); r /= p.Hq;
+  const int qz = (int)(r % p.Dq);
+  const int b = (int)(r / p.Dq);
+
+  // offsets of the 3x3x3 neighbourhood inside one input channel; -1 = outside (reads as zero)
+  int off[27];
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int z = qz + dz - 1, y = qy + dy - 1, x = qx + dx - 1;
+        const bool ok = z >= 0 && z < p.Di && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
+        off[(dz * 3 + dy) * 3 + dx] = ok ? (z * p.Hi + y) * p.Wi + x : -1;
+      }
+
+  float acc[CO][8];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    const float bv = (bias && co < p.Cout) ? bias[co] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[co][c] = bv;
+  }
+  const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
+  const float* xc = X + (size_t)b * p.Cin * xvol;
+  for (int ci = 0; ci < p.Cin; ++ci, xc += xvol) {
+    float xn[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) xn[i] = off[i] >= 0 ? xc[off[i]] : 0.f;
+    const float* wc = W + (size_t)ci * p.Cout * 64;  // wave-uniform: scalar loads
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      if (co < p.Cout) {
+#pragma unroll
+        for (int cls = 0; cls < 8; ++cls) {
+          const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+#pragma unroll
+          for (int tp = 0; tp < 8; ++tp) {
+            const int a = tp >> 2, bb = (tp >> 1) & 1, c = tp & 1;
+            const int kidx = (tap_k(pz, a) * 4 + tap_k(py, bb)) * 4 + tap_k(px, c);
+            const int didx = ((tap_d(pz, a) + 1) * 3 + (tap_d(py, bb) + 1)) * 3 + (tap_d(px, c) + 1);
+            acc[co][cls] = fmaf(xn[didx], wc[co * 64 + kidx], acc[co][cls]);
+          }
+        }
+      }
+    }
+  }
+  const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
+#pragma unroll
+  for (int co = 0; co < CO; ++co)
+    if (co < p.Cout) store8(Y + ((size_t)b * p.Cout + co) * yvol, acc[co], qz, qy, qx, p);
+}
+
+template <int CO>
+void launch_valu(const float* x, const float* w, const float* bias, float* y, const TP& p, hipStream_t st) {
+  const long long nq = (long long)p.B * p.Dq * p.Hq * p.Wq;
+  hipLaunchKernelGGL(convtr_valu_kernel<CO>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, x, w, bias, y,
+                     p);
+}
+
+}  // namespace
+
+extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
+  if (Cin < 1 || Cout < 1 || Cout > 32) return -1;
+  if (Cout <= 12) return 0;
+  return (long long)((Cin + 3) / 4 * 4) * 64 * 32;
+}
+
+extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws, int B,
+                            int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
+                            fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y);
+  if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1) return FS_ERR_SHAPE;
+  if (Cout > 32) return FS_ERR_ARG;
+  // transposed convolution: out = 2 in; input gradient of Conv3d(4,2,1): in_x = 2 out or 2 out + 1
+  if ((Dout != 2 * Di && Dout != 2 * Di + 1) || (Hout != 2 * Hi && Hout != 2 * Hi + 1) ||
+      (Wout != 2 * Wi && Wout != 2 * Wi + 1))
+    return FS_ERR_SHAPE;
+  if ((long long)Di * Hi * Wi >= (1ll << 31) || (long long)Dout * Hout * Wout >= (1ll << 31))
+    return FS_ERR_SHAPE;
+  TP p;
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+  p.Dout = Dout; p.Hout = Hout; p.Wout = Wout;
+  p.Dq = (Dout + 1) / 2; p.Hq = (Hout + 1) / 2; p.Wq = (Wout + 1) / 2;
+  hipStream_t st = (hipStream_t)stream;
+  if ((long long)B * p.Dq * p.Hq * p.Wq >= (1ll << 31) * 256) return FS_ERR_SHAPE;
+  if (Cout <= 12) {
+    if (Cout == 1) launch_valu<1>(x, w, bias, y, p, st);
+    else if (Cout <= 2) launch_valu<2>(x, w, bias, y, p, st);
+    else if (Cout <= 4) launch_valu<4>(x, w, bias, y, p, st);
+    else if (Cout <= 6) launch_valu<6>(x, w, bias, y, p, st);
+    else if (Cout <= 8) launch_valu<8>(x, w, bias, y, p, st);
+    else launch_valu<12>(x, w, bias, y, p, st);
+    FS_LAUNCH_CHECK();
+    return FS_OK;
+  }
+  FS_REQUIRE_PTR(ws);
+  const int cinp = (Cin + 3) / 4 * 4;
+  hipLaunchKernelGGL(wprep_tr_kernel, dim3((cinp * 64 * 32 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout, cinp);
+  p.tz = fs::cdiv(p.Dq, 2); p.ty = fs::cdiv(p.Hq, 2); p.tx = fs::cdiv(p.Wq, 32);
+  p.tiles = (long long)B * p.tz * p.ty * p.tx;
+  if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
+  hipLaunchKernelGGL((convtr_mfma_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}

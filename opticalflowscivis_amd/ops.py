@@ -838,6 +838,37 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0):
     return y
 
 
+def conv3d_tr_supported(cout, k, stride, padding):
+    return (tuple(k) == (4, 4, 4) and tuple(stride) == (2, 2, 2) and tuple(padding) == (1, 1, 1) and cout <= 32)
+
+
+def conv3d_tr(x, w, bias, out_dhw=None):
+    """fs_conv3d_tr: ConvTranspose3d(4, 2, 1)(x) with weight w [Cin,Cout,4,4,4]; with out_dhw = the
+    input extent of a Conv3d(4, 2, 1) layer and w = that layer's weight, its input gradient."""
+    x = _need_cuda_f32("x", x, 5)
+    w = _need_cuda_f32("w", w, 5)
+    B, Cin = x.shape[:2]
+    Cout = w.shape[1]
+    if w.shape[0] != Cin or tuple(w.shape[2:]) != (4, 4, 4):
+        raise ValueError("weight %s does not fit input %s" % (tuple(w.shape), tuple(x.shape)))
+    if bias is not None:
+        bias = _need_cuda_f32("bias", bias, 1)
+        if bias.numel() != Cout:
+            raise ValueError("bias must have %d elements" % Cout)
+    Di, Hi, Wi = x.shape[2:]
+    Do, Ho, Wo = (2 * Di, 2 * Hi, 2 * Wi) if out_dhw is None else tuple(int(v) for v in out_dhw)
+    y = x.new_empty((B, Cout, Do, Ho, Wo))
+    nws = int(_lib.lib().fs_conv3d_tr_ws_floats(Cin, Cout))
+    if nws < 0:
+        raise ValueError("fs_conv3d_tr supports at most 32 output channels, got %d" % Cout)
+    ws = x.new_empty(max(nws, 1))
+    with torch.cuda.device(x.device):
+        _call("fs_conv3d_tr", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin, Cout,
+              Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=4 * (x.numel() + y.numel()),
+              algo_flops=2 * x.numel() * Cout * 64)
+    return y
+
+
 # --------------------------------------------------------------------------------------------
 # a9 'SSIM' branch: weighted SSIM + masked reduction, fused (upflow.py:141-196, 285-289)
 # --------------------------------------------------------------------------------------------

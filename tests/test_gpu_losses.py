@@ -309,6 +309,9 @@ def test_laploss2d_vs_oracle_c2_shape(ops):
     dict(cin=3, cout=5, k=4, s=2, size=(7, 9, 13), tr=False),       # odd input extent
     dict(cin=64, cout=32, k=4, s=2, size=(3, 6, 18), tr=True),      # deconv head: input gradient = strided conv
     dict(cin=32, cout=6, k=4, s=2, size=(4, 7, 20), tr=True),
+    dict(cin=32, cout=1, k=4, s=2, size=(3, 5, 33), tr=True),       # mask head (vector-ALU kernel)
+    dict(cin=6, cout=20, k=4, s=2, size=(3, 5, 37), tr=True),       # ragged channels on the MFMA kernel
+    dict(cin=12, cout=32, k=4, s=2, size=(9, 11, 15), tr=False),    # odd extents: gradient of unused planes = 0
 ])
 def test_conv3d_fwd_mfma_vs_fp64(ops, cfg, monkeypatch):
     """fs_conv3d_fwd (forward, stride-1 input gradient via flipped weights, transposed-conv input
@@ -316,6 +319,7 @@ def test_conv3d_fwd_mfma_vs_fp64(ops, cfg, monkeypatch):
     import torch.nn.functional as F
     from opticalflowscivis_amd import convgrad
     monkeypatch.setattr(convgrad, "_MIN_WORKGROUPS", 0)
+    monkeypatch.setattr(convgrad, "_MIN_TR_POSITIONS", 0)
     g = torch.Generator().manual_seed(cfg["cin"] * 13 + cfg["cout"])
     B = 2
     x = torch.randn((B, cfg["cin"]) + cfg["size"], generator=g)
@@ -335,7 +339,10 @@ def test_conv3d_fwd_mfma_vs_fp64(ops, cfg, monkeypatch):
     torch.cuda.synchronize()
     names = set(ops.kernel_timings().keys())
     ops.enable_kernel_timing(False)
-    assert "fs_conv3d_fwd" in names, names  # the HIP path ran (forward for convs, input gradient for all)
+    # the HIP paths ran: forward + input gradient, one of them through each kernel family for k = 4
+    assert "fs_conv3d_fwd" in names, names
+    if cfg["k"] == 4:
+        assert "fs_conv3d_tr" in names, names
     for got, ref in ((y, yr), (gx, gx_ref), (gw, gw_ref), (gb, gb_ref)):
         scale = float(ref.abs().max())
         assert got.shape == ref.shape
@@ -343,6 +350,11 @@ def test_conv3d_fwd_mfma_vs_fp64(ops, cfg, monkeypatch):
     if not cfg["tr"]:
         # inference path (no autograd node) gives the same bits as the training forward
         m = convgrad.Conv3d(cfg["cin"], cfg["cout"], cfg["k"], cfg["s"], 1).to(DEV)
+        with torch.no_grad():
+            m.weight.copy_(wd); m.bias.copy_(bd)
+            assert torch.equal(m(xd), y)
+    else:
+        m = convgrad.ConvTranspose3d(cfg["cin"], cfg["cout"], 4, 2, 1).to(DEV)
         with torch.no_grad():
             m.weight.copy_(wd); m.bias.copy_(bd)
             assert torch.equal(m(xd), y)
