@@ -36,9 +36,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (same guide: v_mfma_f
 
 
 def roofline(dom, k, S, B):
-    """Roofline record of the dominant hand-written kernel: the fp32 implicit-GEMM weight gradient is
-    priced against the dense fp32 MFMA peak, every other kernel against HBM."""
-    if "TFLOPps" in k and dom == "fs_conv3d_wrw":
+    """Roofline record of the dominant hand-written kernel: the fp32 implicit-GEMM convolutions (forward /
+    input gradient, weight gradient, transposed) are priced against the dense fp32 MFMA peak, every
+    other kernel against HBM."""
+    if "TFLOPps" in k and dom in ("fs_conv3d_wrw", "fs_conv3d_fwd", "fs_conv3d_tr"):
         return {"bound": "mfma", "kernel": dom, "achieved": k["TFLOPps"], "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(k["TFLOPps"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}
     return {"bound": "hbm", "kernel": dom, "achieved": k["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -107,34 +107,65 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   constexpr int ITX = (NX + 255) / 256;
   constexpr int ITW = (NW / 4 + 255) / 256;
 
-  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
-    // ---- stage the input brick (zero outside the volume / beyond Cin) and the weight slab
-    const float* xb = X + ((size_t)b * p.Cin + c0) * xvol;
-#pragma unroll 4
+  // Byte offset of every brick element this thread stages, relative to the chunk's first channel
+  // (~0u = outside the volume -> zero).  They do not depend on the chunk, so the per-chunk staging is
+  // loads only: wave-uniform base + 32-bit lane offset, one address VGPR per load.
+  unsigned xoff[ITX];
+#pragma unroll
+  for (int it = 0; it < ITX; ++it) {
+    const int i = t + 256 * it;
+    const int c = i / CHS, r1 = i - c * CHS;
+    const int z = r1 / PS, r2 = r1 - z * PS;
+    const int y = r2 / XT, x = r2 - y * XT;
+    const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
+    const bool ok = i < NX && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+    xoff[it] = ok ? ((unsigned)c * (unsigned)xvol + ((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u : ~0u;
+  }
+  // PF (k = 4: short MFMA phases, large bricks): the next chunk is fetched into registers before the
+  // MFMA phase and lands under it.  k = 3 stages straight into LDS (its MFMA phase is 3x longer and
+  // its 128 accumulators leave no room for 50 prefetch registers).
+  constexpr bool PF = true, PFW = (K == 4);
+  float rX[PF ? ITX : 1];
+  float4 rW[PFW ? ITW : 1];
+  auto load_x = [&](int c0, int it) -> float {
+    const char* xb = reinterpret_cast<const char*>(X + ((size_t)b * p.Cin + c0) * xvol);
+    const bool chan_ok = (c0 + CI <= p.Cin) || (c0 + (t + 256 * it) / CHS < p.Cin);
+    return (xoff[it] != ~0u && chan_ok) ? *reinterpret_cast<const float*>(xb + xoff[it]) : 0.f;
+  };
+  auto load_w = [&](int c0, int it) -> float4 {
+    const int i4 = t + 256 * it;
+    const int row = i4 / (CP / 4), j4 = i4 - row * (CP / 4);
+    const float* wb = Wt + (size_t)c0 * K3 * p.CoutP + co0;
+    return (i4 < NW / 4) ? *reinterpret_cast<const float4*>(wb + (size_t)row * p.CoutP + 4 * j4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < ITX; ++it) rX[PF ? it : 0] = load_x(c0, it);
+#pragma unroll
+    for (int it = 0; it < ITW; ++it)
+      if (PFW) rW[PFW ? it : 0] = load_w(c0, it);
+  };
+  auto park = [&](int c0) {  // PF: registers -> LDS;  !PF: global -> LDS
+#pragma unroll
     for (int it = 0; it < ITX; ++it) {
       const int i = t + 256 * it;
-      if (i < NX) {
-        const int c = i / CHS, r1 = i - c * CHS;
-        const int z = r1 / PS, r2 = r1 - z * PS;
-        const int y = r2 / XT, x = r2 - y * XT;
-        const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
-        float v = 0.f;
-        if (c0 + c < p.Cin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
-          v = xb[(size_t)c * xvol + ((size_t)gz * p.Hi + gy) * p.Wi + gx];
-        sX[i] = v;
-      }
+      const float v = PF ? rX[PF ? it : 0] : load_x(c0, it);
+      if (i < NX) sX[i] = v;
     }
-    const float* wb = Wt + (size_t)c0 * K3 * p.CoutP + co0;
 #pragma unroll
     for (int it = 0; it < ITW; ++it) {
       const int i4 = t + 256 * it;
-      if (i4 < NW / 4) {
-        const int row = i4 / (CP / 4), j4 = i4 - row * (CP / 4);
-        const float4 v = *reinterpret_cast<const float4*>(wb + (size_t)row * p.CoutP + 4 * j4);
-        *reinterpret_cast<float4*>(sW + row * CP + 4 * j4) = v;
-      }
+      const float4 v = PFW ? rW[PFW ? it : 0] : load_w(c0, it);
+      if (i4 < NW / 4) reinterpret_cast<float4*>(sW)[i4] = v;
     }
+  };
+
+  if (PF) fetch(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+    park(c0);
     __syncthreads();
+    if (PF && c0 + CI < p.Cin) fetch(c0 + CI);
 
     // ---- MFMA phase: pair j = (cl, tap); lanes 32..63 feed channel cl + CI/2
     auto lds_ops = [&](int j, float (&a)[MT], float (&bq)[NT]) {
@@ -231,6 +262,8 @@ extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, 
       Wo != (Wi + 2 * pad - kernel) / stride + 1)
     return FS_ERR_SHAPE;
   if ((long long)Di * Hi * Wi >= (1ll << 31) || (long long)Do * Ho * Wo >= (1ll << 31)) return FS_ERR_SHAPE;
+  // 32-bit byte offsets inside one staged channel chunk (4 channels for k = 3, 2 for k = 4)
+  if ((long long)(kernel == 3 ? 4 : 2) * Di * Hi * Wi * 4 >= (1ll << 32)) return FS_ERR_SHAPE;
   FP p;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Do; p.Ho = Ho; p.Wo = Wo;
   p.pad = pad;
