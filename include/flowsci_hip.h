@@ -291,7 +291,7 @@ int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, f
  * y [B,Cout,Dout,Hout,Wout] with out = 2*in per axis (or 2*in + 1: input gradient of a convolution
  * whose odd input extent left its last plane unused -- that plane receives zeros).
  * Cout <= 32 (FS_ERR_ARG otherwise).  ws: fs_conv3d_tr_ws_floats(Cin, Cout) floats of device scratch
- * (0 for Cout <= 12: those run on the vector ALUs with scalar-loaded weights).
+ * (0 for Cout <= 6: those run on the vector ALUs with scalar-loaded weights).
  */
 long long fs_conv3d_tr_ws_floats(int Cin, int Cout);
 int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws,

@@ -15,10 +15,12 @@
 //   convtr_mfma_kernel (12 < Cout <= 32): implicit GEMM on v_mfma_f32_32x32x2_f32, M = 32 output
 //       channels, N = 32 consecutive qx, 8 accumulator tiles (one per parity class) per wave; per chunk
 //       of 4 input channels the 3x3x3-haloed input brick and the [4][64][32] weight slab sit in LDS.
-//   convtr_valu_kernel<CO> (Cout <= 12: the flow / mask heads, the gradient w.r.t. the 11/12-channel
-//       block input): padding 6 channels to a 32-row MFMA tile wastes 80 % of the matrix core, and the
-//       fp32 vector ALUs have the same peak as the fp32 matrix cores on this part.  One thread per q,
-//       8*CO accumulators, weights are wave-uniform -> scalar loads feeding v_fmac's SGPR operand.
+//   convtr_mfma16_kernel (7..16 output channels: the gradient w.r.t. the 11/12-channel block input):
+//       the same on v_mfma_f32_16x16x4_f32 (16 channels x 16 positions, the 4 chunk channels per MFMA).
+//   convtr_valu_kernel<CO> (Cout <= 6: the flow / mask heads): padding 6 channels to a 16/32-row MFMA
+//       tile wastes most of the matrix core, and the fp32 vector ALUs have the same peak as the fp32
+//       matrix cores on this part.  One thread per q, 8*CO accumulators, weights are wave-uniform ->
+//       scalar loads feeding v_fmac's SGPR operand.
 #include "common.hpp"
 
 namespace {
@@ -106,26 +108,43 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __rest
 
   const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
   constexpr int ITX = (NX + 255) / 256, ITW = NW / 4 / 256;
-  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
-    const float* xb = X + ((size_t)b * p.Cin + c0) * xvol;
-#pragma unroll 3
+  // chunk-invariant byte offsets of the brick elements this thread stages (~0u = outside -> zero);
+  // the next chunk is fetched into registers before the MFMA phase and lands under it (convfwd.hip)
+  unsigned xoff[ITX];
+#pragma unroll
+  for (int it = 0; it < ITX; ++it) {
+    const int i = t + 256 * it;
+    const int c = i / CHS, r1 = i - c * CHS;
+    const int z = r1 / PS, r2 = r1 - z * PS;
+    const int y = r2 / XT, x = r2 - y * XT;
+    const int gz = qz0 - 1 + z, gy = qy0 - 1 + y, gx = qx0 - 1 + x;
+    const bool ok = i < NX && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+    xoff[it] = ok ? ((unsigned)c * (unsigned)xvol + ((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u : ~0u;
+  }
+  float rX[ITX];
+  float4 rW[ITW];
+  auto fetch = [&](int c0) {
+    const char* xb = reinterpret_cast<const char*>(X + ((size_t)b * p.Cin + c0) * xvol);
+#pragma unroll
     for (int it = 0; it < ITX; ++it) {
-      const int i = t + 256 * it;
-      if (i < NX) {
-        const int c = i / CHS, r1 = i - c * CHS;
-        const int z = r1 / PS, r2 = r1 - z * PS;
-        const int y = r2 / XT, x = r2 - y * XT;
-        const int gz = qz0 - 1 + z, gy = qy0 - 1 + y, gx = qx0 - 1 + x;
-        float v = 0.f;
-        if (c0 + c < p.Cin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
-          v = xb[(size_t)c * xvol + ((size_t)gz * p.Hi + gy) * p.Wi + gx];
-        sX[i] = v;
-      }
+      const bool chan_ok = (c0 + CI <= p.Cin) || (c0 + (t + 256 * it) / CHS < p.Cin);
+      rX[it] = (xoff[it] != ~0u && chan_ok) ? *reinterpret_cast<const float*>(xb + xoff[it]) : 0.f;
     }
     const float4* wb = reinterpret_cast<const float4*>(Wt + (size_t)c0 * 64 * 32);
 #pragma unroll
-    for (int it = 0; it < ITW; ++it) reinterpret_cast<float4*>(sW)[t + 256 * it] = wb[t + 256 * it];
+    for (int it = 0; it < ITW; ++it) rW[it] = wb[t + 256 * it];
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+#pragma unroll
+    for (int it = 0; it < ITX; ++it) {
+      const int i = t + 256 * it;
+      if (i < NX) sX[i] = rX[it];
+    }
+#pragma unroll
+    for (int it = 0; it < ITW; ++it) reinterpret_cast<float4*>(sW)[t + 256 * it] = rW[it];
     __syncthreads();
+    if (c0 + CI < p.Cin) fetch(c0 + CI);
 
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl) {
@@ -165,6 +184,146 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __rest
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = acc[c][r] + bv;
       store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p);
+    }
+  }
+}
+
+// ---- 7..16 output channels: v_mfma_f32_16x16x4_f32 ------------------------------------------------
+// M = 16 output channels, N = 16 consecutive qx, and the 4 reduction elements of one MFMA are the
+// four input channels of the chunk at one tap: a (class, tap) pair is ONE instruction per chunk and
+// column tile, an accumulator tile is 4 VGPRs.  A wave owns one brick row = two 16-position tiles.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void wprep_tr16_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                         int Cin, int Cout, int CinP) {
+  const int total = CinP * 64 * 16;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int co = e & 15, tap = (e >> 4) & 63, ci = e >> 10;
+    wt[e] = (co < Cout && ci < Cin) ? w[((size_t)ci * Cout + co) * 64 + tap] : 0.f;
+  }
+}
+
+template <int TZ, int TY>
+__global__ __launch_bounds__(256, 2) void convtr_mfma16_kernel(const float* __restrict__ X,
+                                                            const float* __restrict__ Wt,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ Y, TP p) {
+  static_assert(TZ * TY == 4, "one 32-position row per wave");
+  constexpr int CI = 4;
+  constexpr int ZT = TZ + 2, YT = TY + 2, XT = 34;
+  constexpr int PS = YT * XT, CHS = ZT * PS;
+  constexpr int NX = CI * CHS, NW = CI * 64 * 16;
+  __shared__ float sX[NX];
+  __shared__ __attribute__((aligned(16))) float sW[NW];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  long long tile = blockIdx.x;
+  {
+    const long long per = p.tiles / 8;
+    if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int txi = (int)(tile % p.tx); tile /= p.tx;
+  const int tyi = (int)(tile % p.ty); tile /= p.ty;
+  const int tzi = (int)(tile % p.tz);
+  const int b = (int)(tile / p.tz);
+  const int qz0 = tzi * TZ, qy0 = tyi * TY, qx0 = txi * 32;
+  const int wz = wv / TY, wy = wv % TY;
+
+  const float* bB = sX + kq * CHS + (wz + 1) * PS + (wy + 1) * XT + (col + 1);
+  const float* aB = sW + kq * 64 * 16 + col;
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[n][c][r] = 0.f;
+
+  const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
+  constexpr int ITX = (NX + 255) / 256, ITW = NW / 4 / 256;
+  unsigned xoff[ITX];
+#pragma unroll
+  for (int it = 0; it < ITX; ++it) {
+    const int i = t + 256 * it;
+    const int c = i / CHS, r1 = i - c * CHS;
+    const int z = r1 / PS, r2 = r1 - z * PS;
+    const int y = r2 / XT, x = r2 - y * XT;
+    const int gz = qz0 - 1 + z, gy = qy0 - 1 + y, gx = qx0 - 1 + x;
+    const bool ok = i < NX && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+    xoff[it] = ok ? ((unsigned)c * (unsigned)xvol + ((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u : ~0u;
+  }
+  float rX[ITX];
+  float4 rW[ITW];
+  auto fetch = [&](int c0) {
+    const char* xb = reinterpret_cast<const char*>(X + ((size_t)b * p.Cin + c0) * xvol);
+#pragma unroll
+    for (int it = 0; it < ITX; ++it) {
+      const bool chan_ok = (c0 + CI <= p.Cin) || (c0 + (t + 256 * it) / CHS < p.Cin);
+      rX[it] = (xoff[it] != ~0u && chan_ok) ? *reinterpret_cast<const float*>(xb + xoff[it]) : 0.f;
+    }
+    const float4* wb = reinterpret_cast<const float4*>(Wt + (size_t)c0 * 64 * 16);
+#pragma unroll
+    for (int it = 0; it < ITW; ++it) rW[it] = wb[t + 256 * it];
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+#pragma unroll
+    for (int it = 0; it < ITX; ++it) {
+      const int i = t + 256 * it;
+      if (i < NX) sX[i] = rX[it];
+    }
+#pragma unroll
+    for (int it = 0; it < ITW; ++it) reinterpret_cast<float4*>(sW)[t + 256 * it] = rW[it];
+    __syncthreads();
+    if (c0 + CI < p.Cin) fetch(c0 + CI);
+
+    float xn[2][27];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            xn[n][(dz * 3 + dy) * 3 + dx] = bB[16 * n + (dz - 1) * PS + (dy - 1) * XT + (dx - 1)];
+#pragma unroll
+    for (int cls = 0; cls < 8; ++cls) {
+      const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp) {
+        const int a = tp >> 2, bb = (tp >> 1) & 1, c = tp & 1;
+        const int kidx = (tap_k(pz, a) * 4 + tap_k(py, bb)) * 4 + tap_k(px, c);
+        const int didx = ((tap_d(pz, a) + 1) * 3 + (tap_d(py, bb) + 1)) * 3 + (tap_d(px, c) + 1);
+        const float av = aB[kidx * 16];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[n][cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xn[n][didx], acc[n][cls], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // D row (channel) = 4 * (lane >> 4) + r, column (position) = lane & 15
+  const int qz = qz0 + wz, qy = qy0 + wy;
+  if (qz < p.Dq && qy < p.Hq) {
+    const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int qx = qx0 + 16 * n + col;
+      if (qx >= p.Wq) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * kq + r;
+        if (co >= p.Cout) continue;
+        const float bv = bias ? bias[co] : 0.f;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = acc[n][c][r] + bv;
+        store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p);
+      }
     }
   }
 }
@@ -243,8 +402,8 @@ void launch_valu(const float* x, const float* w, const float* bias, float* y, co
 
 extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   if (Cin < 1 || Cout < 1 || Cout > 32) return -1;
-  if (Cout <= 12) return 0;
-  return (long long)((Cin + 3) / 4 * 4) * 64 * 32;
+  if (Cout <= 6) return 0;
+  return (long long)((Cin + 3) / 4 * 4) * 64 * (Cout <= 16 ? 16 : 32);
 }
 
 extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws, int B,
@@ -260,29 +419,36 @@ extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, f
     return FS_ERR_SHAPE;
   if ((long long)Di * Hi * Wi >= (1ll << 31) || (long long)Dout * Hout * Wout >= (1ll << 31))
     return FS_ERR_SHAPE;
+  if ((long long)4 * Di * Hi * Wi * 4 >= (1ll << 32)) return FS_ERR_SHAPE;  // 32-bit chunk offsets
   TP p;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
   p.Dout = Dout; p.Hout = Hout; p.Wout = Wout;
   p.Dq = (Dout + 1) / 2; p.Hq = (Hout + 1) / 2; p.Wq = (Wout + 1) / 2;
   hipStream_t st = (hipStream_t)stream;
   if ((long long)B * p.Dq * p.Hq * p.Wq >= (1ll << 31) * 256) return FS_ERR_SHAPE;
-  if (Cout <= 12) {
+  if (Cout <= 6) {
     if (Cout == 1) launch_valu<1>(x, w, bias, y, p, st);
     else if (Cout <= 2) launch_valu<2>(x, w, bias, y, p, st);
     else if (Cout <= 4) launch_valu<4>(x, w, bias, y, p, st);
-    else if (Cout <= 6) launch_valu<6>(x, w, bias, y, p, st);
-    else if (Cout <= 8) launch_valu<8>(x, w, bias, y, p, st);
-    else launch_valu<12>(x, w, bias, y, p, st);
+    else launch_valu<6>(x, w, bias, y, p, st);
     FS_LAUNCH_CHECK();
     return FS_OK;
   }
   FS_REQUIRE_PTR(ws);
   const int cinp = (Cin + 3) / 4 * 4;
-  hipLaunchKernelGGL(wprep_tr_kernel, dim3((cinp * 64 * 32 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout, cinp);
   p.tz = fs::cdiv(p.Dq, 2); p.ty = fs::cdiv(p.Hq, 2); p.tx = fs::cdiv(p.Wq, 32);
   p.tiles = (long long)B * p.tz * p.ty * p.tx;
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
-  hipLaunchKernelGGL((convtr_mfma_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
+  if (Cout <= 16) {
+    hipLaunchKernelGGL(wprep_tr16_kernel, dim3((cinp * 64 * 16 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
+                       cinp);
+    hipLaunchKernelGGL((convtr_mfma16_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y,
+                       p);
+  } else {
+    hipLaunchKernelGGL(wprep_tr_kernel, dim3((cinp * 64 * 32 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
+                       cinp);
+    hipLaunchKernelGGL((convtr_mfma_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
+  }
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
