@@ -14,15 +14,17 @@
 // ConvTranspose3d  G = input, S = grad_out  (dW then already has the [Cin, Cout, k,k,k] layout).
 //
 // Decomposition.  A workgroup (4 waves) owns 32*MT rows of M, one chunk of NC source channels
-// (N tile = NC*k^3 columns, 216 for k=3/NC=8, 256 for k=4/NC=4) and a run of K-steps; a K-step is 32
-// consecutive ox of one output row (b, oz, oy).  Per step it stages in LDS the G tile (32*MT x 32)
-// and the NC*k*k source rows those 32 outputs touch ((32-1)*s + k floats each, zero padded), then
-// each wave feeds 32x32x2 MFMAs for its N tiles: the B operand of column (c,kz,ky,kx) at reduction
-// index ox is simply  row[c][kz][ky][ox*s + kx]  -- a per-lane constant offset plus ox*s -- so im2col
-// exists only as an LDS addressing pattern.  Row pitches are padded so that both operand reads are
-// bank-conflict-free (pitch = k mod 32 for the source rows, 33 for G).  Accumulators stay in registers
-// over the whole run; the epilogue adds the partial tile to dW with float atomics (128 contiguous
-// bytes per half-wave = the full-rate shape; ~100 MB of atomic traffic per layer).
+// (N tile = NC*k^3 columns, 216 for k=3/NC=8, 256 for k=4/NC=4) and a run of K-steps; a K-step is a
+// TZ x TY x 32 brick of output positions (4 rows of 32 ox for k=3, 2 rows for k=4).  Per step it stages
+// in LDS the G brick (32*MT channels x rows x 32) and the source brick with its halo (zero padded),
+// then each wave feeds 32x32x2 MFMAs for its N tiles: the B operand of column (c,kz,ky,kx) at
+// reduction index (tz,ty,ox) is  sS[c][tz*s+kz][ty*s+ky][ox*s+kx]  -- a per-lane constant offset plus
+// a compile-time one -- so im2col exists only as an LDS addressing pattern.  Pitches are padded so that
+// both operand reads are bank-conflict-free (column offset == column index mod 32 for the source brick,
+// odd row pitch for G).  The next brick is prefetched into registers under the MFMA phase; operands
+// are read from LDS one reduction pair ahead of the MFMAs that use them.  Accumulators stay in
+// registers over the whole run; the epilogue adds the partial tile to dW with float atomics (128
+// contiguous bytes per half-wave = the full-rate shape).
 #include "common.hpp"
 
 namespace {
@@ -41,33 +43,44 @@ struct WP {
   int spw;          // K-steps per workgroup
 };
 
-template <int K, int S, int NC, int MT>
-__global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restrict__ G,
-                                                         const float* __restrict__ Src,
-                                                         float* __restrict__ dW, WP p) {
+// (round-1 history: a K-step used to be ONE row of 32 ox -- 9.6x source re-read for k=3, a barrier per
+// 64 MFMAs, 79 TFLOP/s on the 64-channel layers; the brick form shares the halo between rows (4.8x),
+// runs 256 MFMAs between barriers and reaches 98.)
+struct WB {
+  int B, Cg, Cs;
+  int Do, Ho, Wo, Di, Hi, Wi;
+  int pad;
+  int bz, by, bx;    // bricks per axis
+  long long bricks;  // B*bz*by*bx
+  int spw;           // bricks per workgroup
+};
+
+constexpr int pad_to(int n, int want) { return n + (((want - n) % 32) + 32) % 32; }
+
+template <int K, int S, int NC, int MT, int TZ, int TY>
+__global__ __launch_bounds__(256, 2) void conv3d_wrw_brick_kernel(const float* __restrict__ G,
+                                                               const float* __restrict__ Src,
+                                                               float* __restrict__ dW, WB p) {
   constexpr int K3 = K * K * K;
-  constexpr int NTOT = NC * K3;               // live columns of this N chunk
-  constexpr int NT32 = (NTOT + 31) / 32;      // 32-column MFMA tiles
-  constexpr int NPW = (NT32 + 3) / 4;         // N tiles per wave
-  constexpr int RL = (KW - 1) * S + K;        // source row piece needed by 32 outputs
-  constexpr int RLP = RL + ((K - RL % 32) % 32 + 32) % 32;  // padded so that RLP % 32 == K
-  constexpr int ROWS = NC * K * K;
-  constexpr int GLD = KW + 1;
-  static_assert(RLP % 32 == K % 32, "source row pitch");
-  // k = 3: double-buffered tiles, one barrier per K-step, prefetch interleaved with the MFMAs.
-  // k = 4 (25 prefetch registers per thread): single buffer, two barriers, prefetch issued up
-  // front -- the leaner structure keeps it under 256 VGPRs without spills.
-  constexpr bool DB = (K == 3);
-  constexpr bool INTER = (K == 3);
-  __shared__ float sG[DB ? 2 : 1][32 * MT][GLD];
-  __shared__ float sS[DB ? 2 : 1][ROWS][RLP];
+  constexpr int NTOT = NC * K3;
+  constexpr int NT32 = (NTOT + 31) / 32;
+  constexpr int NPW = (NT32 + 3) / 4;
+  constexpr int ROWS = TZ * TY;
+  constexpr int ZT = (TZ - 1) * S + K, YT = (TY - 1) * S + K, XT = (KW - 1) * S + K;
+  constexpr int XP = pad_to(XT, K);                  // == K      (mod 32)
+  constexpr int PSP = pad_to(YT * XP, K * K);        // == K^2    (mod 32)
+  constexpr int CHSP = pad_to(ZT * PSP, K * K * K);  // == K^3    (mod 32)
+  constexpr int GP = ROWS * KW + 1;
+  constexpr int NG = 32 * MT * ROWS * KW;            // G brick elements
+  constexpr int NS = NC * ZT * YT * XT;              // source brick elements (unpadded count)
+  __shared__ float sG[32 * MT * GP];
+  __shared__ float sS[NC * CHSP];
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int c0 = blockIdx.y * NC;            // first source channel of this chunk
-  const int g0 = blockIdx.z * 32 * MT;       // first G channel of this M tile
+  const int c0 = blockIdx.y * NC;
+  const int g0 = blockIdx.z * 32 * MT;
   const size_t gvol = (size_t)p.Do * p.Ho * p.Wo, svol = (size_t)p.Di * p.Hi * p.Wi;
 
-  // per-lane constants of the B operand: column j -> offset of (c, kz, ky, kx) in sS
   int boff[NPW];
 #pragma unroll
   for (int n = 0; n < NPW; ++n) {
@@ -76,11 +89,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
     if (j < NTOT) {
       const int c = j / K3, r = j - c * K3;
       const int kz = r / (K * K), ky = (r / K) % K, kx = r % K;
-      off = ((c * K + kz) * K + ky) * RLP + kx;
+      off = c * CHSP + kz * PSP + ky * XP + kx;
     }
     boff[n] = off;
   }
-  const int kh = lane >> 5;  // which of the 2 reduction elements of an MFMA this lane feeds
+  const int kh = lane >> 5;
 
   f32x16 acc[MT][NPW];
 #pragma unroll
@@ -90,95 +103,88 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  constexpr int ITG = (32 * MT * KW + 255) / 256;  // G-tile elements per thread and step
-  constexpr int ITS = (ROWS * RL + 255) / 256;     // source-row elements per thread and step
+  constexpr int ITG = NG / 256;
+  constexpr int ITS = (NS + 255) / 256;
+  // brick-invariant part of the source staging: the element's (z, y, x, c) inside the brick, packed
+  unsigned szyx[ITS];
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int i = t + 256 * it;
+    const int c = i / (ZT * YT * XT), r1 = i - c * (ZT * YT * XT);
+    const int z = r1 / (YT * XT), r2 = r1 - z * (YT * XT);
+    const int y = r2 / XT, x = r2 - y * XT;
+    const bool ok = i < NS && c0 + c < p.Cs;
+    szyx[it] = ok ? ((unsigned)z | ((unsigned)y << 8) | ((unsigned)x << 16) | ((unsigned)c << 24)) : ~0u;
+  }
   float rG[ITG], rS[ITS];
 
-  // position of the step being FETCHED, advanced incrementally (seg fastest, then oy, oz, b)
   const long long s0 = (long long)blockIdx.x * p.spw;
-  const long long s1 = min(s0 + p.spw, p.steps);
-  int f_seg, f_oy, f_oz, f_b;
-  {
-    long long q = s0;
-    f_seg = (int)(q % p.segs); q /= p.segs;
-    f_oy = (int)(q % p.Ho); q /= p.Ho;
-    f_oz = (int)(q % p.Do);
-    f_b = (int)(q / p.Do);
-  }
-  auto advance = [&]() {
-    if (++f_seg == p.segs) { f_seg = 0; if (++f_oy == p.Ho) { f_oy = 0; if (++f_oz == p.Do) { f_oz = 0; ++f_b; } } }
-  };
-
-  // global -> registers for a quarter of one K-step (zero where the tile leaves G / the padded
-  // source).  Called four times per step, spread over the MFMA loop, so that the address
-  // arithmetic issues in the shadow of the 64-cycle matrix instructions.
-  auto fetch = [&](int part) {
-    const int ox0 = f_seg * KW;
-    // wave-uniform bases + 32-bit byte offsets: one address VGPR per load (saddr form)
-    const char* gb = reinterpret_cast<const char*>(G + ((size_t)f_b * p.Cg + g0) * gvol +
-                                                   ((size_t)f_oz * p.Ho + f_oy) * p.Wo + ox0);
+  const long long s1 = min(s0 + p.spw, p.bricks);
+  auto fetch = [&](long long q) {
+    const int bxi = (int)(q % p.bx); q /= p.bx;
+    const int byi = (int)(q % p.by); q /= p.by;
+    const int bzi = (int)(q % p.bz);
+    const int b = (int)(q / p.bz);
+    const int oz0 = bzi * TZ, oy0 = byi * TY, ox0 = bxi * KW;
+    // G brick: element i -> (channel r, row, ox)
+    const char* gb = reinterpret_cast<const char*>(G + ((size_t)b * p.Cg + g0) * gvol);
 #pragma unroll
     for (int it = 0; it < ITG; ++it) {
-      if (part >= 0 && (it & 3) != part) continue;
       const int i = t + 256 * it;
-      const int r = i / KW, col = i - r * KW;
+      const int r = i / (ROWS * KW), row = (i / KW) % ROWS, col = i % KW;
+      const int oz = oz0 + row / TY, oy = oy0 + row % TY, ox = ox0 + col;
       float v = 0.f;
-      if (i < 32 * MT * KW && g0 + r < p.Cg && ox0 + col < p.Wo)
-        v = *reinterpret_cast<const float*>(gb + ((unsigned)r * (unsigned)gvol + (unsigned)col) * 4u);
+      if (g0 + r < p.Cg && oz < p.Do && oy < p.Ho && ox < p.Wo)
+        v = *reinterpret_cast<const float*>(
+            gb + ((unsigned)r * (unsigned)gvol + ((unsigned)oz * p.Ho + oy) * p.Wo + ox) * 4u);
       rG[it] = v;
     }
-    const int ix0 = ox0 * S - p.pad;
-    const char* sb = reinterpret_cast<const char*>(Src + ((size_t)f_b * p.Cs + c0) * svol);
+    const int gz0 = oz0 * S - p.pad, gy0 = oy0 * S - p.pad, gx0 = ox0 * S - p.pad;
+    const char* sb = reinterpret_cast<const char*>(Src + ((size_t)b * p.Cs + c0) * svol);
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-      if (part >= 0 && (it & 3) != part) continue;
-      const int i = t + 256 * it;
-      const int r = i / RL, col = i - r * RL;
-      const int c = r / (K * K), kz = (r / K) % K, ky = r % K;
-      const int iz = f_oz * S + kz - p.pad, iy = f_oy * S + ky - p.pad, ix = ix0 + col;
+      const unsigned zyx = szyx[it];
+      const int gz = gz0 + (int)(zyx & 255u), gy = gy0 + (int)((zyx >> 8) & 255u), gx = gx0 + (int)((zyx >> 16) & 255u);
       float v = 0.f;
-      if (i < ROWS * RL && c0 + c < p.Cs && iz >= 0 && iz < p.Di && iy >= 0 && iy < p.Hi && ix >= 0 &&
-          ix < p.Wi)
+      if (zyx != ~0u && (unsigned)gz < (unsigned)p.Di && (unsigned)gy < (unsigned)p.Hi &&
+          (unsigned)gx < (unsigned)p.Wi)
         v = *reinterpret_cast<const float*>(
-            sb + ((unsigned)c * (unsigned)svol + ((unsigned)iz * p.Hi + iy) * p.Wi + ix) * 4u);
+            sb + ((zyx >> 24) * (unsigned)svol + ((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u);
       rS[it] = v;
     }
   };
-  auto park = [&](int buf) {  // registers -> LDS buffer `buf`
+  auto park = [&]() {
 #pragma unroll
     for (int it = 0; it < ITG; ++it) {
       const int i = t + 256 * it;
-      if (i < 32 * MT * KW) sG[buf][i / KW][i % KW] = rG[it];
+      sG[(i / (ROWS * KW)) * GP + (i % (ROWS * KW))] = rG[it];
     }
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       const int i = t + 256 * it;
-      if (i < ROWS * RL) sS[buf][i / RL][i % RL] = rS[it];
+      if (i < NS) {
+        const int c = i / (ZT * YT * XT), r1 = i - c * (ZT * YT * XT);
+        const int z = r1 / (YT * XT), r2 = r1 - z * (YT * XT);
+        const int y = r2 / XT, x = r2 - y * XT;
+        sS[c * CHSP + z * PSP + y * XP + x] = rS[it];
+      }
     }
   };
 
-  if (s0 < s1) {
-    fetch(-1);  // whole step
-    advance();
-  }
+  if (s0 < s1) fetch(s0);
   for (long long st = s0; st < s1; ++st) {
-    const int buf = DB ? (int)((st - s0) & 1) : 0;
-    park(buf);
-    // double-buffered: ONE barrier per step (the other buffer was last read in the previous step's
-    // MFMA phase, which every wave has left before it can arrive here)
+    park();
     __syncthreads();
-    const bool more = (st + 1 < s1);
-    const float* sSf = &sS[buf][0][0];
-    if (!INTER && more) fetch(-1);
-    // operands of reduction pair kk: one A float per M tile, one B float per N tile of this wave.
-    // They are read from LDS ONE PAIR AHEAD of the MFMAs that use them (register rotation): issued
-    // right before use, every pair would expose an LDS round trip (~100 cycles per 256 MFMA cycles).
-    auto lds_ops = [&](int kk, float (&a)[MT], float (&bq)[NPW]) {
+    if (st + 1 < s1) fetch(st + 1);
+    // reduction pair kk of row `row`: positions ox = 2 kk + kh
+    auto lds_ops = [&](int q, float (&a)[MT], float (&bq)[NPW]) {
+      const int row = q / (KW / 2), kk = q % (KW / 2);
       const int ox = 2 * kk + kh;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = sG[buf][m * 32 + (lane & 31)][ox];
+      for (int m = 0; m < MT; ++m) a[m] = sG[(m * 32 + (lane & 31)) * GP + row * KW + ox];
 #pragma unroll
-      for (int n = 0; n < NPW; ++n) bq[n] = sSf[boff[n] + ox * S];
+      for (int n = 0; n < NPW; ++n)
+        bq[n] = sS[boff[n] + (row / TY) * S * PSP + (row % TY) * S * XP + ox * S];
     };
     auto mma = [&](const float (&a)[MT], const float (&bq)[NPW]) {
 #pragma unroll
@@ -190,27 +196,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
         }
       }
     };
+    constexpr int NQ = ROWS * (KW / 2);
     float a0[MT], b0[NPW], a1[MT], b1[NPW];
     lds_ops(0, a0, b0);
 #pragma unroll
-    for (int part = 0; part < 4; ++part) {
-      if (INTER && more) fetch(part);  // next step's quarter: in flight under the matrix instructions
-#pragma unroll
-      for (int k4 = 0; k4 < KW / 8; k4 += 2) {
-        const int kk = part * (KW / 8) + k4;
-        lds_ops(kk + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of the MFMAs they do not feed
-        mma(a0, b0);
-        if (kk + 2 < KW / 2) lds_ops(kk + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-      }
+    for (int q = 0; q < NQ; q += 2) {
+      lds_ops(q + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      if (q + 2 < NQ) lds_ops(q + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
     }
-    if (more) advance();
-    if (!DB) __syncthreads();  // single buffer: MFMA reads done before the next park
+    __syncthreads();
   }
 
-  // ---- epilogue: dW[g, c0*K3 + j] += acc  (row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31)
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -227,24 +227,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_kernel(const float* __restr
     }
 }
 
-template <int K, int S, int NC>
-int launch(const float* G, const float* Src, float* dW, WP& p, hipStream_t st) {
+template <int K, int S, int NC, int TZ, int TY>
+int launch_brick(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st) {
+  WB p;
+  p.B = w.B; p.Cg = w.Cg; p.Cs = w.Cs; p.Do = w.Do; p.Ho = w.Ho; p.Wo = w.Wo;
+  p.Di = w.Di; p.Hi = w.Hi; p.Wi = w.Wi; p.pad = w.pad;
+  p.bz = fs::cdiv(p.Do, TZ); p.by = fs::cdiv(p.Ho, TY); p.bx = fs::cdiv(p.Wo, KW);
+  p.bricks = (long long)p.B * p.bz * p.by * p.bx;
   const int mt = (p.Cg > 32) ? 2 : 1;
   const int mtiles = fs::cdiv(p.Cg, 32 * mt);
   const int nchunks = fs::cdiv(p.Cs, NC);
-  // enough workgroups to fill the chip a few times, runs long enough to amortise the epilogue
-  long long want = 4096 / ((long long)mtiles * nchunks);
+  // ~1024 workgroups (two per workgroup slot of the chip): fewer, longer runs keep the atomic epilogue
+  // (one 32*MT x NC*k^3 tile per workgroup) small; measured best among 512..8192 on the 256^3 layers
+  long long want = 1024 / ((long long)mtiles * nchunks);
   if (want < 1) want = 1;
-  long long spw = (p.steps + want - 1) / want;
-  if (spw < 8) spw = 8;
+  long long spw = (p.bricks + want - 1) / want;
+  if (spw < 2) spw = 2;
   p.spw = (int)(spw > (1 << 20) ? (1 << 20) : spw);
-  const long long gx = (p.steps + p.spw - 1) / p.spw;
+  const long long gx = (p.bricks + p.spw - 1) / p.spw;
   if (gx >= (1ll << 31) || nchunks > 65535 || mtiles > 65535) return FS_ERR_SHAPE;
   dim3 grid((unsigned)gx, nchunks, mtiles);
   if (mt == 2)
-    hipLaunchKernelGGL((conv3d_wrw_kernel<K, S, NC, 2>), grid, dim3(256), 0, st, G, Src, dW, p);
+    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 2, TZ, TY>), grid, dim3(256), 0, st, G, Src, dW, p);
   else
-    hipLaunchKernelGGL((conv3d_wrw_kernel<K, S, NC, 1>), grid, dim3(256), 0, st, G, Src, dW, p);
+    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 1, TZ, TY>), grid, dim3(256), 0, st, G, Src, dW, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -273,10 +279,10 @@ extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B,
   p.segs = fs::cdiv(Wo, KW);
   p.steps = (long long)B * Do * Ho * p.segs;
   hipStream_t st = (hipStream_t)stream;
-  if (kernel == 3) return launch<3, 1, 8>(g, src, dw, p, st);
+  if (kernel == 3) return launch_brick<3, 1, 8, 1, 4>(g, src, dw, p, st);
   // k = 4: 64 columns per source channel.  NC = 4 gives every wave two 32-column tiles, NC = 2 one;
   // pick the chunking with less padded matrix work (Cs = 1, 2, 5, 6: the IFNet heads / block0 input)
   const int cost2 = (Cs + 1) / 2, cost4 = 2 * ((Cs + 3) / 4);
-  if (cost2 < cost4) return launch<4, 2, 2>(g, src, dw, p, st);
-  return launch<4, 2, 4>(g, src, dw, p, st);
+  if (cost2 < cost4) return launch_brick<4, 2, 2, 1, 2>(g, src, dw, p, st);
+  return launch_brick<4, 2, 4, 1, 2>(g, src, dw, p, st);
 }
