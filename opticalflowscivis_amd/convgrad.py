@@ -85,13 +85,14 @@ def _wrw_from_patches(src, g, k, stride, padding):
     return dW.view((Cg, Cs) + tuple(k))
 
 
-_MIN_WORKGROUPS = int(os.environ.get("FLOWSCI_CONV_FWD_MIN_WG", "128"))
-_MIN_TR_POSITIONS = int(os.environ.get("FLOWSCI_CONV_TR_MIN_POS", "16384"))  # input voxels (all samples)
+_MIN_WORKGROUPS = int(os.environ.get("FLOWSCI_CONV_FWD_MIN_WG", "0"))
+_MIN_TR_POSITIONS = int(os.environ.get("FLOWSCI_CONV_TR_MIN_POS", "0"))  # input voxels (all samples)
 
 
 def _hip_fwd_ok(x, cout, out_dhw, k, stride, padding):
-    """Route this convolution through fs_conv3d_fwd?  Supported (k,s) pairs, fp32 on the GPU, and
-    enough output bricks to fill the chip (small trunk layers stay on MIOpen, which wins there)."""
+    """Route this convolution through fs_conv3d_fwd?  Supported (k,s) pairs, fp32 on the GPU.  (The
+    workgroup threshold is a tuning hook; the kernel picks quarter-size bricks for small layers and
+    beats MIOpen on every IFNet-3D shape measured, scripts/fwdbench.py.)"""
     if _MODE != "mfma" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5:
         return False
     from . import ops

@@ -275,8 +275,18 @@ extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, 
   hipLaunchKernelGGL(wprep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, ws, Cout, Cin, K3, cinp,
                      p.CoutP, wmode);
   if (kernel == 3) {
-    if (Wo > 16) return launch<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
-    return launch<3, 1, 4, 2, 4, 2, 8, 16>(x, ws, bias, y, p, st);
+    // big bricks (2 x 8 x 32 / 2 x 16 x 16 voxels) when they fill the chip, else quarter-size bricks
+    // (1 x 4 x 32 / 1 x 8 x 16): the 16^3 / 32^3 trunk layers of the coarse blocks have only 8K-64K
+    // output voxels per launch
+    const bool wide = Wo > 16;
+    const long long big = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, wide ? 8 : 16) * fs::cdiv(Wo, wide ? 32 : 16) *
+                          (p.CoutP / 64);
+    if (big >= 512) {
+      if (wide) return launch<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
+      return launch<3, 1, 4, 2, 4, 2, 8, 16>(x, ws, bias, y, p, st);
+    }
+    if (wide) return launch<3, 1, 4, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
+    return launch<3, 1, 4, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
   }
   if (p.CoutP == 32) {
     if (Wo > 16) return launch<4, 2, 2, 1, 2, 1, 8, 32>(x, ws, bias, y, p, st);

@@ -803,13 +803,17 @@ def conv3d_wrw(g, src, k, stride, pad):
 
 
 def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
-    """Workgroups fs_conv3d_fwd launches for this layer (mirrors its tile choice, csrc/convfwd.hip)."""
+    """Workgroups fs_conv3d_fwd launches for this layer (mirrors its brick choice, csrc/convfwd.hip)."""
     Do, Ho, Wo = out_dhw
+    cd = lambda a, b: -(-a // b)
     tw = 32 if Wo > 16 else 16
-    tyr = 8 * (32 // tw)
-    tz = 2 if k == 3 else 1
-    mg = 1 if (k == 4 and Cout <= 32) else -(-Cout // 64)
-    return B * (-(-Do // tz)) * (-(-Ho // tyr)) * (-(-Wo // tw)) * mg
+    r = 32 // tw
+    if k == 3:
+        mg = cd(Cout, 64)
+        big = B * cd(Do, 2) * cd(Ho, 8 * r) * cd(Wo, tw) * mg
+        return big if big >= 512 else B * Do * cd(Ho, 4 * r) * cd(Wo, tw) * mg
+    mg = 1 if Cout <= 32 else cd(Cout, 64)
+    return B * Do * cd(Ho, 8 * r) * cd(Wo, tw) * mg
 
 
 def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0):

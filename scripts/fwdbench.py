@@ -43,6 +43,8 @@ case(64, 64, 3, 1, S // 4)
 case(64, 64, 3, 1, S // 4, wmode=1)
 case(64, 64, 3, 1, S // 8)
 case(128, 128, 3, 1, S // 16)
+case(128, 128, 3, 1, S // 16, wmode=1)
+case(64, 64, 3, 1, S // 8, wmode=1)
 case(11, 32, 4, 2, S)
 case(12, 32, 4, 2, S)
 case(32, 64, 4, 2, S // 2)
