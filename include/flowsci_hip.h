@@ -304,10 +304,13 @@ int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, fl
  *   grad_x[e] = x > 0 ? g : a[c] g ;  grad_weight[c] = sum_{b,spatial} (x > 0 ? 0 : x g).
  * x, grad_out, grad_x [B,C,S]; weight, grad_weight [num_weights]; ws: device scratch of
  * B*C*FS_PRELU_MAX_CHUNKS floats.  One pass + a tiny deterministic finishing kernel.
+ * grad_bias (may be NULL) [C]: additionally sum_{b,spatial} grad_x per channel -- the bias gradient
+ * of the convolution that produced x, for free in the same pass (ws must then hold
+ * 2*B*C*FS_PRELU_MAX_CHUNKS floats).
  */
 #define FS_PRELU_MAX_CHUNKS 64
 int fs_prelu_bwd(const float* x, const float* grad_out, const float* weight,
-                 float* grad_x, float* grad_weight, float* ws,
+                 float* grad_x, float* grad_weight, float* grad_bias, float* ws,
                  int B, int C, int S, int num_weights, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -51,7 +51,7 @@ SIGNATURES = {
     "fs_distill_fwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_distill_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_interp3d_bwd": [_f32p] * 3 + [_int] * 10 + [_stream],
-    "fs_prelu_bwd": [_f32p] * 6 + [_int] * 4 + [_stream],
+        "fs_prelu_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_corr3d_fwd": [_f32p] * 3 + [_int] * 6 + [_stream],
     "fs_corr3d_bwd": [_f32p] * 5 + [_int] * 6 + [_stream],
     "fs_conv3d_wrw": [_f32p] * 3 + [_int] * 12 + [_stream],

@@ -115,22 +115,62 @@ def _conv_out(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
+def _conv_forward(x, w, b, stride, padding, transposed):
+    nd = x.dim() - 2
+    if transposed and nd == 3 and _hip_tr_ok(x, w.shape[1], tuple(w.shape[2:]), stride, padding):
+        from . import ops
+        return ops.conv3d_tr(x, w, b)
+    if transposed:
+        return (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
+    if nd == 3 and _hip_fwd_ok(x, w.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
+                                               zip(x.shape[2:], w.shape[2:], stride, padding)],
+                               tuple(w.shape[2:]), stride, padding):
+        from . import ops
+        return ops.conv3d_fwd(x, w, b, w.shape[2], stride[0], padding[0], 0)
+    return (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, padding)
+
+
+def _conv_grad_input(x, w, gy, stride, padding, transposed):
+    nd = x.dim() - 2
+    k = tuple(w.shape[2:])
+    if (not transposed and all(s == 1 for s in stride) and all(2 * p == kk - 1 for p, kk in zip(padding, k))):
+        # stride-1 "same" convolution: its input gradient IS a forward convolution of grad_out with the
+        # flipped, channel-transposed filter
+        if nd == 3 and _hip_fwd_ok(gy, w.shape[1], x.shape[2:], k, stride, padding):
+            from . import ops  # flip + transpose happen in the kernel's weight re-layout
+            return ops.conv3d_fwd(gy, w, None, k[0], 1, padding[0], 1)
+        wf = w.transpose(0, 1).flip(*range(2, 2 + nd)).contiguous()
+        return (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, stride, padding)
+    if (transposed and nd == 3 and _hip_fwd_ok(gy, w.shape[0], x.shape[2:], k, stride, padding) and
+            all(_conv_out(n, kk, s, p) == m for n, kk, s, p, m in
+                zip(gy.shape[2:], k, stride, padding, x.shape[2:]))):
+        # input gradient of a transposed convolution = the strided convolution of grad_out with the same
+        # weight tensor read as [out = Cin_t][in = Cout_t]
+        from . import ops
+        return ops.conv3d_fwd(gy, w, None, k[0], stride[0], padding[0], 0)
+    if (not transposed and nd == 3 and _hip_tr_ok(gy, w.shape[1], k, stride, padding) and
+            all(n in (2 * m, 2 * m + 1) for n, m in zip(x.shape[2:], gy.shape[2:]))):
+        # input gradient of Conv3d(4, 2, 1) = the transposed convolution of grad_out with the layer's
+        # weight [Cout][Cin][64] read as [in][out][64]
+        from . import ops
+        return ops.conv3d_tr(gy, w, None, x.shape[2:])
+    return torch.ops.aten.convolution_backward(  # MIOpen backward-data
+        gy, x, w, None, list(stride), list(padding), [1] * nd, transposed, [0] * nd, 1,
+        [True, False, False])[0]
+
+
+def _conv_grad_weight(x, w, gy, stride, padding, transposed):
+    k = tuple(w.shape[2:])
+    if transposed:
+        # y = conv_transpose(x, w[Cin,Cout,k]):  dW[ci,co,k] = sum x[b,ci,i] * gy[b,co,i*s+k-p]
+        return _wrw_from_patches(gy, x, k, stride, padding)  # [Cin, Cout, *k]
+    return _wrw_from_patches(x, gy, k, stride, padding)
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, transposed):
-        nd = x.dim() - 2
-        if transposed and nd == 3 and _hip_tr_ok(x, w.shape[1], tuple(w.shape[2:]), stride, padding):
-            from . import ops
-            y = ops.conv3d_tr(x, w, b)
-        elif transposed:
-            y = (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
-        elif nd == 3 and _hip_fwd_ok(x, w.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
-                                                     zip(x.shape[2:], w.shape[2:], stride, padding)],
-                                     tuple(w.shape[2:]), stride, padding):
-            from . import ops
-            y = ops.conv3d_fwd(x, w, b, w.shape[2], stride[0], padding[0], 0)
-        else:
-            y = (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, padding)
+        y = _conv_forward(x, w, b, stride, padding, transposed)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, transposed, b is not None)
         return y
@@ -143,45 +183,55 @@ class _ConvFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            k = tuple(w.shape[2:])
-            if (not transposed and all(s == 1 for s in stride) and all(2 * p == kk - 1 for p, kk in zip(padding, k))):
-                # stride-1 "same" convolution: its input gradient IS a forward convolution of grad_out
-                # with the flipped, channel-transposed filter -> MIOpen's forward kernel (CK, 2.0 ms per
-                # 64->64 layer at 64^3) instead of its backward-data solvers (2.7 ms CK / >4 ms GEMM+Col2Im,
-                # whichever its un-tuned find step happens to pick)
-                if nd == 3 and _hip_fwd_ok(gy, w.shape[1], x.shape[2:], k, stride, padding):
-                    from . import ops  # flip + transpose happen in the kernel's weight re-layout
-                    gx = ops.conv3d_fwd(gy, w, None, k[0], 1, padding[0], 1)
-                else:
-                    wf = w.transpose(0, 1).flip(*range(2, 2 + nd)).contiguous()
-                    gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, stride, padding)
-            elif (transposed and nd == 3 and _hip_fwd_ok(gy, w.shape[0], x.shape[2:], k, stride, padding) and
-                  all(_conv_out(n, kk, s, p) == m for n, kk, s, p, m in
-                      zip(gy.shape[2:], k, stride, padding, x.shape[2:]))):
-                # input gradient of a transposed convolution = the strided convolution of grad_out with
-                # the same weight tensor read as [out = Cin_t][in = Cout_t]
-                from . import ops
-                gx = ops.conv3d_fwd(gy, w, None, k[0], stride[0], padding[0], 0)
-            elif (not transposed and nd == 3 and _hip_tr_ok(gy, w.shape[1], k, stride, padding) and
-                  all(n in (2 * m, 2 * m + 1) for n, m in zip(x.shape[2:], gy.shape[2:]))):
-                # input gradient of Conv3d(4, 2, 1) = the transposed convolution of grad_out with the
-                # layer's weight [Cout][Cin][64] read as [in][out][64]
-                from . import ops
-                gx = ops.conv3d_tr(gy, w, None, x.shape[2:])
-            else:  # MIOpen backward-data
-                gx = torch.ops.aten.convolution_backward(
-                    gy, x, w, None, list(stride), list(padding), [1] * nd, transposed, [0] * nd, 1,
-                    [True, False, False])[0]
+            gx = _conv_grad_input(x, w, gy, stride, padding, transposed)
         if ctx.needs_input_grad[1]:
-            k = tuple(w.shape[2:])
-            if transposed:
-                # y = conv_transpose(x, w[Cin,Cout,k]):  dW[ci,co,k] = sum x[b,ci,i] * gy[b,co,i*s+k-p]
-                gw = _wrw_from_patches(gy, x, k, stride, padding)  # [Cin, Cout, *k]
-            else:
-                gw = _wrw_from_patches(x, gy, k, stride, padding)
+            gw = _conv_grad_weight(x, w, gy, stride, padding, transposed)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(dim=(0,) + tuple(range(2, 2 + nd)))
         return gx, gw, gb, None, None, None
+
+
+class _ConvPReLUFn(torch.autograd.Function):
+    """conv (or transposed conv) + bias + per-channel PReLU as ONE autograd node: the PReLU backward
+    pass (csrc/prelu.hip) already streams the convolution's grad_out, so it also produces the bias
+    gradient -- no separate reduction over the activation."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, a, stride, padding, transposed):
+        y = _conv_forward(x, w, b, stride, padding, transposed)
+        z = F.prelu(y, a)
+        ctx.save_for_backward(x, w, y, a)
+        ctx.cfg = (stride, padding, transposed, b is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        from . import ops
+        x, w, y, a = ctx.saved_tensors
+        stride, padding, transposed, has_bias = ctx.cfg
+        gy, ga, gb = ops.prelu_backward(y, gz.contiguous(), a, want_bias_grad=has_bias)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv_grad_input(x, w, gy, stride, padding, transposed)
+        if ctx.needs_input_grad[1]:
+            gw = _conv_grad_weight(x, w, gy, stride, padding, transposed)
+        return gx, gw, gb, ga, None, None, None
+
+
+class ConvPReLU(nn.Sequential):
+    """nn.Sequential(conv, PReLU) -- the reference's `conv()` / `deconv()` helpers
+    (Flow-3D/model/IFNet.py:13-29) -- with the same children (`0` = convolution, `1` = PReLU: identical
+    state_dict keys and initialisation order), whose training forward on the GPU is the fused node."""
+
+    def forward(self, x):
+        conv, act = self[0], self[1]
+        if (_use_gemm(x) and x.dim() == 5 and x.dtype == torch.float32 and isinstance(conv, (Conv3d, ConvTranspose3d))
+                and act.weight.numel() in (1, conv.out_channels) and conv.groups == 1
+                and _tuple(conv.dilation, 3) == (1, 1, 1) and getattr(conv, "padding_mode", "zeros") == "zeros"
+                and _tuple(getattr(conv, "output_padding", 0), 3) == (0, 0, 0)):
+            return _ConvPReLUFn.apply(x, conv.weight, conv.bias, act.weight, _tuple(conv.stride, 3),
+                                      _tuple(conv.padding, 3), isinstance(conv, ConvTranspose3d))
+        return act(conv(x))
 
 
 def _use_gemm(x):

@@ -16,8 +16,8 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ a,
                                                         float* __restrict__ gx, float* __restrict__ ws,
-                                                        int C, int S, int nchunk, int chunk_len,
-                                                        int shared_a) {
+                                                        float* __restrict__ wsb, int C, int S, int nchunk,
+                                                        int chunk_len, int shared_a) {
   // blockIdx.x = (b*C + c) * nchunk + chunk
   const int chunk = blockIdx.x % nchunk;
   const long long row = blockIdx.x / nchunk;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
   const float slope = a[shared_a ? 0 : c];
   const long long base = row * (long long)S;
   const int lo = chunk * chunk_len, hi = min(lo + chunk_len, S);
-  float acc = 0.f;
+  float acc = 0.f, accb = 0.f;  // accb: sum of grad_x = the bias gradient of the producing convolution
   const bool vec = ((base + lo) % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) |
                                                 reinterpret_cast<uintptr_t>(gx)) % 16 == 0);
   int i = lo + threadIdx.x * 4;
@@ -38,26 +38,35 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
       o.y = xv.y > 0.f ? gv.y : slope * gv.y; acc += xv.y > 0.f ? 0.f : xv.y * gv.y;
       o.z = xv.z > 0.f ? gv.z : slope * gv.z; acc += xv.z > 0.f ? 0.f : xv.z * gv.z;
       o.w = xv.w > 0.f ? gv.w : slope * gv.w; acc += xv.w > 0.f ? 0.f : xv.w * gv.w;
+      accb += (o.x + o.y) + (o.z + o.w);
       *reinterpret_cast<float4*>(gx + base + i) = o;
     }
     // tail (< 4 elements of this chunk): handled by the threads whose quad straddles `hi`
     for (int j = i; j < hi && j < i + 4; ++j) {
       const float xv = x[base + j], gv = g[base + j];
-      gx[base + j] = xv > 0.f ? gv : slope * gv;
+      const float o = xv > 0.f ? gv : slope * gv;
+      gx[base + j] = o;
+      accb += o;
       acc += xv > 0.f ? 0.f : xv * gv;
     }
   } else {
     for (int j = lo + threadIdx.x; j < hi; j += 256) {
       const float xv = x[base + j], gv = g[base + j];
-      gx[base + j] = xv > 0.f ? gv : slope * gv;
+      const float o = xv > 0.f ? gv : slope * gv;
+      gx[base + j] = o;
+      accb += o;
       acc += xv > 0.f ? 0.f : xv * gv;
     }
   }
-  __shared__ float red[4];
+  __shared__ float red[2][4];
   acc = fs::wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  accb = fs::wave_sum(accb);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = acc; red[1][threadIdx.x >> 6] = accb; }
   __syncthreads();
-  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    if (wsb != nullptr) wsb[blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
 }
 
 __global__ __launch_bounds__(256) void prelu_ga_kernel(const float* __restrict__ ws,
@@ -89,8 +98,8 @@ __global__ __launch_bounds__(256) void prelu_ga_kernel(const float* __restrict__
 }  // namespace
 
 extern "C" int fs_prelu_bwd(const float* x, const float* grad_out, const float* weight, float* grad_x,
-                            float* grad_weight, float* ws, int B, int C, int S, int num_weights,
-                            fs_stream_t stream) {
+                            float* grad_weight, float* grad_bias, float* ws, int B, int C, int S,
+                            int num_weights, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(grad_out); FS_REQUIRE_PTR(weight);
   FS_REQUIRE_PTR(grad_x); FS_REQUIRE_PTR(grad_weight); FS_REQUIRE_PTR(ws);
@@ -106,10 +115,13 @@ extern "C" int fs_prelu_bwd(const float* x, const float* grad_out, const float* 
   if (blocks >= (1ll << 31)) return FS_ERR_SHAPE;
   const int shared_a = (num_weights == 1) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
+  float* wsb = grad_bias ? ws + (size_t)B * C * PCH : nullptr;
   hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, grad_out, weight,
-                     grad_x, ws, C, S, nchunk, chunk_len, shared_a);
+                     grad_x, ws, wsb, C, S, nchunk, chunk_len, shared_a);
   hipLaunchKernelGGL(prelu_ga_kernel, dim3(num_weights), dim3(256), 0, st, ws, grad_weight, B, C, nchunk,
                      shared_a);
+  if (grad_bias)  // always per channel, same fixed-order fp64 finish
+    hipLaunchKernelGGL(prelu_ga_kernel, dim3(C), dim3(256), 0, st, wsb, grad_bias, B, C, nchunk, 0);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

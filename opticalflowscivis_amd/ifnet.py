@@ -23,13 +23,25 @@ _INTERP = {2: "bilinear", 3: "trilinear"}
 
 
 def _conv(nd, cin, cout, kernel_size=3, stride=1, padding=1):
-    return nn.Sequential(_CONV[nd](cin, cout, kernel_size, stride, padding, bias=True),
-                         convgrad.PReLU(cout))
+    # Sequential(conv, PReLU) as in the reference (same keys / init order); in 3-D the pair trains as one
+    # fused autograd node (convgrad.ConvPReLU)
+    seq = convgrad.ConvPReLU if nd == 3 else nn.Sequential
+    return seq(_CONV[nd](cin, cout, kernel_size, stride, padding, bias=True), convgrad.PReLU(cout))
+
+
+class _Head(nn.Sequential):
+    """Sequential(deconv, PReLU, deconv) of the reference heads (children 0, 1, 2); the first pair runs
+    as the fused node in 3-D training."""
+
+    def forward(self, x):
+        if isinstance(self[0], convgrad.ConvTranspose3d):
+            return self[2](convgrad.ConvPReLU.forward(self, x))
+        return super().forward(x)
 
 
 def _head(nd, c, cout):
-    return nn.Sequential(_DECONV[nd](c, c // 2, 4, 2, 1), convgrad.PReLU(c // 2),
-                         _DECONV[nd](c // 2, cout, 4, 2, 1))
+    return _Head(_DECONV[nd](c, c // 2, 4, 2, 1), convgrad.PReLU(c // 2),
+                 _DECONV[nd](c // 2, cout, 4, 2, 1))
 
 
 def _resize(t, factor, mode):

@@ -709,6 +709,23 @@ def interpolate3d(x, scale_factor):
 _PRELU_MAX_CHUNKS = 64
 
 
+def prelu_backward(x, gy, weight, want_bias_grad=False):
+    """fs_prelu_bwd: (grad_x, grad_weight, grad_bias or None) of y = prelu(x, weight) in one pass over
+    [B,C,*]; grad_bias = per-channel sum of grad_x (the producing convolution's bias gradient)."""
+    x = _need_cuda_f32("x", x, x.dim())
+    gy = _need_cuda_f32("grad_output", gy, x.dim())
+    B, C, S = _flat3(x)
+    gx = torch.empty_like(x)
+    gw = torch.empty_like(weight)
+    gb = x.new_empty(C) if want_bias_grad else None
+    ws = x.new_empty((2 if want_bias_grad else 1) * B * C * _PRELU_MAX_CHUNKS)
+    with torch.cuda.device(x.device):
+        _call("fs_prelu_bwd", x.data_ptr(), gy.data_ptr(), weight.data_ptr(), gx.data_ptr(),
+              gw.data_ptr(), _ptr(gb), ws.data_ptr(), B, C, S, weight.numel(), _stream(x),
+              algo_bytes=12 * x.numel())
+    return gx, gw, gb
+
+
 class _PReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
@@ -719,16 +736,7 @@ class _PReLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        x = _need_cuda_f32("x", x, x.dim())
-        gy = _need_cuda_f32("grad_output", gy, x.dim())
-        B, C, S = _flat3(x)
-        gx = torch.empty_like(x)
-        gw = torch.empty_like(weight)
-        ws = x.new_empty(B * C * _PRELU_MAX_CHUNKS)
-        with torch.cuda.device(x.device):
-            _call("fs_prelu_bwd", x.data_ptr(), gy.data_ptr(), weight.data_ptr(), gx.data_ptr(),
-                  gw.data_ptr(), ws.data_ptr(), B, C, S, weight.numel(), _stream(x),
-                  algo_bytes=12 * x.numel())
+        gx, gw, _ = prelu_backward(x, gy, weight)
         return gx, gw
 
 

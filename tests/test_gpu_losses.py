@@ -358,3 +358,38 @@ def test_conv3d_fwd_mfma_vs_fp64(ops, cfg, monkeypatch):
         with torch.no_grad():
             m.weight.copy_(wd); m.bias.copy_(bd)
             assert torch.equal(m(xd), y)
+
+
+@pytest.mark.parametrize("tr,nw", [(False, 7), (True, 7), (False, 1)])
+def test_conv_prelu_fused_node_vs_fp64(ops, tr, nw):
+    """convgrad.ConvPReLU: conv + bias + PReLU as one autograd node (bias gradient from the PReLU
+    backward pass) against an fp64 CPU graph; module keys are those of Sequential(conv, PReLU)."""
+    import torch.nn.functional as F
+    from opticalflowscivis_amd import convgrad
+    g = torch.Generator().manual_seed(31 + nw + int(tr))
+    cin, cout, k, s = (6, 7, 4, 2) if tr else (5, 7, 3, 1)
+    x = torch.randn(2, cin, 5, 9, 13, generator=g)
+    conv = (convgrad.ConvTranspose3d if tr else convgrad.Conv3d)(cin, cout, k, s, 1)
+    seq = convgrad.ConvPReLU(conv, convgrad.PReLU(cout if nw > 1 else 1))
+    assert sorted(seq.state_dict().keys()) == ["0.bias", "0.weight", "1.weight"]
+    with torch.no_grad():
+        seq[1].weight.copy_(torch.rand(seq[1].weight.shape, generator=g) - 0.3)  # negative slopes too
+    ref = [p.detach().double().requires_grad_() for p in (x, conv.weight, conv.bias, seq[1].weight)]
+    fn = F.conv_transpose3d if tr else F.conv3d
+    zr = F.prelu(fn(ref[0], ref[1], ref[2], s, 1), ref[3])
+    G = torch.randn(zr.shape, generator=g)
+    gref = torch.autograd.grad((zr * G.double()).sum(), ref)
+    seq = seq.to(DEV)
+    xd = x.to(DEV).requires_grad_()
+    ops.enable_kernel_timing(True)
+    z = seq(xd)
+    got = torch.autograd.grad((z * G.to(DEV)).sum(), [xd, seq[0].weight, seq[0].bias, seq[1].weight])
+    names = set(ops.kernel_timings().keys())
+    ops.enable_kernel_timing(False)
+    assert "fs_prelu_bwd" in names and z.grad_fn.__class__.__name__.startswith("_ConvPReLUFn")
+    assert float((z.detach().cpu().double() - zr.detach()).abs().max()) < 3e-5 * float(zr.abs().max())
+    for a, b in zip(got, gref):
+        assert a.shape == b.shape
+        assert float((a.detach().cpu().double() - b).abs().max()) < 5e-5 * float(b.abs().max())
+    with torch.no_grad():  # inference path of the same module: unfused children
+        assert float((seq(xd) - z).abs().max()) < 1e-6
