@@ -142,6 +142,28 @@ int fs_corr2d_bwd(const float* f1, const float* f2, const float* grad_out,
                   float* grad_f1, float* grad_f2,
                   int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
 
+/* f4. normalize_features folded into the cost volume: UPFlow/model/upflow.py:96-138
+ * with normalize = center = True, moments_across_channels = moments_across_images = False (the
+ * configuration UPFlow_net.demo() / C3 uses, upflow.py:635-641): every (b, c) plane of each feature map
+ * is centred and scaled by its own mean / sqrt(unbiased var + 1e-16) immediately before
+ * correlation.py:26.  The normalised maps are never materialised:
+ *   fs_plane_moments   : stats[plane] = (mean, 1/sqrt(var + 1e-16)) for `planes` planes of S floats (S >= 2);
+ *   fs_corr2d_norm_fwd : fs_corr2d_fwd of the normalised maps, normalisation applied as tiles are
+ *                        staged (the zero padding of f2 applies AFTER normalisation, as in the reference);
+ *   fs_corr2d_norm_bwd : gradients w.r.t. the NORMALISED maps (either may be NULL);
+ *   fs_plane_norm_bwd  : chains one of them through the normalisation,
+ *                        grad_f = r (grad_n - mean(grad_n) - n sum(grad_n n)/(S-1)).
+ */
+int fs_plane_moments(const float* f, float* stats, int planes, int S, fs_stream_t stream);
+int fs_plane_norm_bwd(const float* f, const float* stats, const float* grad_n, float* grad_f,
+                      int planes, int S, fs_stream_t stream);
+int fs_corr2d_norm_fwd(const float* f1, const float* f2, const float* stats1, const float* stats2,
+                       float* out, int B, int C, int H, int W, int max_displacement,
+                       fs_stream_t stream);
+int fs_corr2d_norm_bwd(const float* f1, const float* f2, const float* stats1, const float* stats2,
+                       const float* grad_out, float* grad_n1, float* grad_n2,
+                       int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
+
 /* 3-D correlation: NEW capability named by BASELINE.json (config 4); the reference has no 3-D cost
  * volume, so this generalises the 2-D layer above (dz-major, then dy, dx; channel mean; zero pad):
  *   f1, f2 [B,C,D,H,W] -> out [B,(2md+1)^3,D,H,W].  Pinned to the reference only through D = 1.

@@ -40,6 +40,10 @@ SIGNATURES = {
     "fs_conv3d_fwd": [_f32p] * 5 + [_int] * 13 + [_stream],
     "fs_conv3d_tr_ws_floats": [_int] * 2,
     "fs_conv3d_tr": [_f32p] * 5 + [_int] * 9 + [_stream],
+    "fs_plane_moments": [_f32p] * 2 + [_int] * 2 + [_stream],
+    "fs_plane_norm_bwd": [_f32p] * 4 + [_int] * 2 + [_stream],
+    "fs_corr2d_norm_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
+    "fs_corr2d_norm_bwd": [_f32p] * 7 + [_int] * 5 + [_stream],
     "fs_corr2d_fwd": [_f32p] * 3 + [_int] * 5 + [_stream],
     "fs_corr2d_bwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_robust_sum": [_f32p] * 5 + [_int] * 7 + [_float, _float, _stream],

@@ -33,8 +33,8 @@ constexpr int TY = 8, TX = 32, CC = 8;
 
 template <int MD>
 __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr2d_fwd_kernel(
-    const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out, int C, int H,
-    int W) {
+    const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ st1,
+    const float* __restrict__ st2, float* __restrict__ out, int C, int H, int W) {
   constexpr int ND = 2 * MD + 1;
   constexpr int SR = TY + 2 * MD;        // staged rows
   constexpr int SCOLS = TX + 2 * MD;     // staged cols (multiple of 4 for MD in {2,4}; padded below)
@@ -65,8 +65,11 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr2d_fwd_kernel(
       const int r = rem / SCOLS, col = rem - r * SCOLS;
       const int gy = y0 + r - MD, gx = x0 + col - MD;
       float v = 0.f;
-      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
+      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
         v = f2b[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
+        // normalize_features folded into the load (§8f.4): the zero padding applies AFTER it
+        if (st2) { const float* q = st2 + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
+      }
       s2[c][r][col] = v;
     }
     for (int i = t; i < CC * TY * TX; i += NT) {
@@ -74,7 +77,10 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr2d_fwd_kernel(
       const int r = rem / TX, col = rem - r * TX;
       const int gy = y0 + r, gx = x0 + col;
       float v = 0.f;
-      if (c0 + c < C && gy < H && gx < W) v = f1b[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
+      if (c0 + c < C && gy < H && gx < W) {
+        v = f1b[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
+        if (st1) { const float* q = st1 + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
+      }
       s1[c][r][col] = v;
     }
     __syncthreads();
@@ -116,6 +122,8 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr2d_fwd_kernel(
 template <int MD>
 __global__ __launch_bounds__(256) void corr2d_bwd_kernel(const float* __restrict__ f1,
                                                          const float* __restrict__ f2,
+                                                         const float* __restrict__ st1,
+                                                         const float* __restrict__ st2,
                                                          const float* __restrict__ gout,
                                                          float* __restrict__ g1,
                                                          float* __restrict__ g2, int B, int C, int H,
@@ -129,6 +137,7 @@ __global__ __launch_bounds__(256) void corr2d_bwd_kernel(const float* __restrict
   float* grad = second ? g2 : g1;
   if (grad == nullptr) return;  // uniform per block
   const float* other = second ? f1 : f2;
+  const float* ost = second ? st1 : st2;  // moments of `other` (NULL: plain correlation)
   const int y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
   const int t = threadIdx.x;
   const int py = t / TX, px = t % TX;
@@ -165,8 +174,10 @@ __global__ __launch_bounds__(256) void corr2d_bwd_kernel(const float* __restrict
       const int r = rem / SW, col = rem - r * SW;
       const int gy = y0 + r - MD, gx = x0 + col - MD;
       float v = 0.f;
-      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
+      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
         v = ob[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
+        if (ost) { const float* q = ost + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
+      }
       s[c][r][col] = v;
     }
     __syncthreads();
@@ -183,20 +194,21 @@ __global__ __launch_bounds__(256) void corr2d_bwd_kernel(const float* __restrict
 }
 
 template <int MD>
-int launch_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W,
-               hipStream_t st) {
+int launch_fwd(const float* f1, const float* f2, const float* st1, const float* st2, float* out, int B,
+               int C, int H, int W, hipStream_t st) {
   dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), B);
-  hipLaunchKernelGGL(corr2d_fwd_kernel<MD>, grid, dim3(64 * (2 * MD + 1)), 0, st, f1, f2, out, C, H,
-                     W);
+  hipLaunchKernelGGL(corr2d_fwd_kernel<MD>, grid, dim3(64 * (2 * MD + 1)), 0, st, f1, f2, st1, st2, out, C,
+                     H, W);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
 template <int MD>
-int launch_bwd(const float* f1, const float* f2, const float* gout, float* g1, float* g2, int B,
-               int C, int H, int W, hipStream_t st) {
+int launch_bwd(const float* f1, const float* f2, const float* st1, const float* st2, const float* gout,
+               float* g1, float* g2, int B, int C, int H, int W, hipStream_t st) {
   dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), 2 * B);
-  hipLaunchKernelGGL(corr2d_bwd_kernel<MD>, grid, dim3(256), 0, st, f1, f2, gout, g1, g2, B, C, H, W);
+  hipLaunchKernelGGL(corr2d_bwd_kernel<MD>, grid, dim3(256), 0, st, f1, f2, st1, st2, gout, g1, g2, B, C, H,
+                     W);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -208,6 +220,79 @@ int check_shape(int B, int C, int H, int W, int md) {
   return FS_OK;
 }
 
+int run_fwd(const float* f1, const float* f2, const float* st1, const float* st2, float* out, int B, int C,
+            int H, int W, int md, hipStream_t st) {
+  switch (md) {
+    case 1: return launch_fwd<1>(f1, f2, st1, st2, out, B, C, H, W, st);
+    case 2: return launch_fwd<2>(f1, f2, st1, st2, out, B, C, H, W, st);
+    case 3: return launch_fwd<3>(f1, f2, st1, st2, out, B, C, H, W, st);
+    default: return launch_fwd<4>(f1, f2, st1, st2, out, B, C, H, W, st);
+  }
+}
+
+int run_bwd(const float* f1, const float* f2, const float* st1, const float* st2, const float* gout,
+            float* g1, float* g2, int B, int C, int H, int W, int md, hipStream_t st) {
+  switch (md) {
+    case 1: return launch_bwd<1>(f1, f2, st1, st2, gout, g1, g2, B, C, H, W, st);
+    case 2: return launch_bwd<2>(f1, f2, st1, st2, gout, g1, g2, B, C, H, W, st);
+    case 3: return launch_bwd<3>(f1, f2, st1, st2, gout, g1, g2, B, C, H, W, st);
+    default: return launch_bwd<4>(f1, f2, st1, st2, gout, g1, g2, B, C, H, W, st);
+  }
+}
+
+// ---- per-plane moments and the adjoint of (f - mean) * rstd (normalize_features, §8f.4) ----------
+// One workgroup per (b, c) plane; UPFlow's feature planes have 24 .. 4294 elements.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void plane_moments_kernel(const float* __restrict__ f, float* __restrict__ stats,
+                                                            int S) {
+  __shared__ double red[256];
+  const float* p = f + (size_t)blockIdx.x * S;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < S; i += 256) s += (double)p[i];
+  const float mean = (float)(block_sum(s, red) / (double)S);
+  double q = 0.0;
+  for (int i = threadIdx.x; i < S; i += 256) { const float d = p[i] - mean; q += (double)(d * d); }
+  const float var = (float)(block_sum(q, red) / (double)(S - 1));  // torch.var: unbiased
+  if (threadIdx.x == 0) {
+    stats[2 * blockIdx.x] = mean;
+    stats[2 * blockIdx.x + 1] = 1.0f / sqrtf(var + 1e-16f);  // upflow.py:127 std = sqrt(var + 1e-16)
+  }
+}
+
+// n = (f - m) r,  m = mean f,  r = (var + eps)^-1/2,  var = sum (f - m)^2 / (S - 1):
+//   df_i = r * ( dn_i - mean(dn) - n_i * sum_j(dn_j n_j) / (S - 1) )
+__global__ __launch_bounds__(256) void plane_norm_bwd_kernel(const float* __restrict__ f,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ gn, float* __restrict__ gf,
+                                                             int S) {
+  __shared__ double red[256];
+  const size_t base = (size_t)blockIdx.x * S;
+  const float m = stats[2 * blockIdx.x], r = stats[2 * blockIdx.x + 1];
+  double a = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < S; i += 256) {
+    const float g = gn[base + i], n = (f[base + i] - m) * r;
+    a += (double)g;
+    c += (double)(g * n);
+  }
+  const float s1 = (float)(block_sum(a, red) / (double)S);
+  const float s2 = (float)(block_sum(c, red) / (double)(S - 1));
+  for (int i = threadIdx.x; i < S; i += 256) {
+    const float n = (f[base + i] - m) * r;
+    gf[base + i] = r * (gn[base + i] - s1 - n * s2);
+  }
+}
+
 }  // namespace
 
 extern "C" int fs_corr2d_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W,
@@ -216,13 +301,7 @@ extern "C" int fs_corr2d_fwd(const float* f1, const float* f2, float* out, int B
   FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(out);
   const int rc = check_shape(B, C, H, W, max_displacement);
   if (rc != FS_OK) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  switch (max_displacement) {
-    case 1: return launch_fwd<1>(f1, f2, out, B, C, H, W, st);
-    case 2: return launch_fwd<2>(f1, f2, out, B, C, H, W, st);
-    case 3: return launch_fwd<3>(f1, f2, out, B, C, H, W, st);
-    default: return launch_fwd<4>(f1, f2, out, B, C, H, W, st);
-  }
+  return run_fwd(f1, f2, nullptr, nullptr, out, B, C, H, W, max_displacement, (hipStream_t)stream);
 }
 
 extern "C" int fs_corr2d_bwd(const float* f1, const float* f2, const float* grad_out, float* grad_f1,
@@ -233,11 +312,49 @@ extern "C" int fs_corr2d_bwd(const float* f1, const float* f2, const float* grad
   if (grad_f1 == nullptr && grad_f2 == nullptr) return FS_ERR_NULLPTR;
   const int rc = check_shape(B, C, H, W, max_displacement);
   if (rc != FS_OK) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  switch (max_displacement) {
-    case 1: return launch_bwd<1>(f1, f2, grad_out, grad_f1, grad_f2, B, C, H, W, st);
-    case 2: return launch_bwd<2>(f1, f2, grad_out, grad_f1, grad_f2, B, C, H, W, st);
-    case 3: return launch_bwd<3>(f1, f2, grad_out, grad_f1, grad_f2, B, C, H, W, st);
-    default: return launch_bwd<4>(f1, f2, grad_out, grad_f1, grad_f2, B, C, H, W, st);
-  }
+  return run_bwd(f1, f2, nullptr, nullptr, grad_out, grad_f1, grad_f2, B, C, H, W, max_displacement,
+                 (hipStream_t)stream);
+}
+
+extern "C" int fs_plane_moments(const float* f, float* stats, int planes, int S, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(f); FS_REQUIRE_PTR(stats);
+  if (planes < 1 || S < 2) return FS_ERR_SHAPE;  // unbiased variance needs two samples
+  hipLaunchKernelGGL(plane_moments_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, f, stats, S);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+extern "C" int fs_plane_norm_bwd(const float* f, const float* stats, const float* grad_n, float* grad_f,
+                                 int planes, int S, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(f); FS_REQUIRE_PTR(stats); FS_REQUIRE_PTR(grad_n); FS_REQUIRE_PTR(grad_f);
+  if (planes < 1 || S < 2) return FS_ERR_SHAPE;
+  hipLaunchKernelGGL(plane_norm_bwd_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, f, stats, grad_n,
+                     grad_f, S);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+extern "C" int fs_corr2d_norm_fwd(const float* f1, const float* f2, const float* stats1, const float* stats2,
+                                  float* out, int B, int C, int H, int W, int max_displacement,
+                                  fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(stats1); FS_REQUIRE_PTR(stats2); FS_REQUIRE_PTR(out);
+  const int rc = check_shape(B, C, H, W, max_displacement);
+  if (rc != FS_OK) return rc;
+  return run_fwd(f1, f2, stats1, stats2, out, B, C, H, W, max_displacement, (hipStream_t)stream);
+}
+
+extern "C" int fs_corr2d_norm_bwd(const float* f1, const float* f2, const float* stats1, const float* stats2,
+                                  const float* grad_out, float* grad_n1, float* grad_n2, int B, int C, int H,
+                                  int W, int max_displacement, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(f1); FS_REQUIRE_PTR(f2); FS_REQUIRE_PTR(stats1); FS_REQUIRE_PTR(stats2);
+  FS_REQUIRE_PTR(grad_out);
+  if (grad_n1 == nullptr && grad_n2 == nullptr) return FS_ERR_NULLPTR;
+  const int rc = check_shape(B, C, H, W, max_displacement);
+  if (rc != FS_OK) return rc;
+  return run_bwd(f1, f2, stats1, stats2, grad_out, grad_n1, grad_n2, B, C, H, W, max_displacement,
+                 (hipStream_t)stream);
 }

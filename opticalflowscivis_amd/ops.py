@@ -358,6 +358,65 @@ def corr2d(f1, f2, max_displacement=4):
     return _Corr2D.apply(f1, f2, int(max_displacement))
 
 
+class _Corr2DNorm(torch.autograd.Function):
+    """§8f.4: corr2d(normalize(f1), normalize(f2)) with per-(b,c)-plane moments, normalisation folded
+    into the correlation kernels' tile loads (upflow.py:96-138 + correlation.py:26)."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, md):
+        f1 = _need_cuda_f32("f1", f1, 4)
+        f2 = _need_cuda_f32("f2", f2, 4)
+        if f1.shape != f2.shape:
+            raise ValueError("f1 %s and f2 %s must match" % (tuple(f1.shape), tuple(f2.shape)))
+        B, C, H, W = f1.shape
+        if H * W < 2:
+            raise ValueError("per-plane variance needs at least two pixels")
+        st1, st2 = f1.new_empty(B * C, 2), f1.new_empty(B * C, 2)
+        nd = 2 * md + 1
+        out = f1.new_empty(B, nd * nd, H, W)
+        with torch.cuda.device(f1.device):
+            s = _stream(f1)
+            _call("fs_plane_moments", f1.data_ptr(), st1.data_ptr(), B * C, H * W, s, algo_bytes=4 * f1.numel())
+            _call("fs_plane_moments", f2.data_ptr(), st2.data_ptr(), B * C, H * W, s, algo_bytes=4 * f2.numel())
+            _call("fs_corr2d_norm_fwd", f1.data_ptr(), f2.data_ptr(), st1.data_ptr(), st2.data_ptr(),
+                  out.data_ptr(), B, C, H, W, md, s, algo_bytes=4 * (2 * f1.numel() + out.numel()))
+        ctx.save_for_backward(f1, f2, st1, st2)
+        ctx.md = md
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        f1, f2, st1, st2 = ctx.saved_tensors
+        B, C, H, W = f1.shape
+        gout = _need_cuda_f32("grad_output", gout, 4)
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need1 or need2):
+            return None, None, None
+        gn1 = torch.empty_like(f1) if need1 else None
+        gn2 = torch.empty_like(f2) if need2 else None
+        g1 = g2 = None
+        with torch.cuda.device(f1.device):
+            s = _stream(f1)
+            _call("fs_corr2d_norm_bwd", f1.data_ptr(), f2.data_ptr(), st1.data_ptr(), st2.data_ptr(),
+                  gout.data_ptr(), _ptr(gn1), _ptr(gn2), B, C, H, W, ctx.md, s,
+                  algo_bytes=4 * (2 * f1.numel() + gout.numel()))
+            if need1:
+                g1 = torch.empty_like(f1)
+                _call("fs_plane_norm_bwd", f1.data_ptr(), st1.data_ptr(), gn1.data_ptr(), g1.data_ptr(),
+                      B * C, H * W, s, algo_bytes=12 * f1.numel())
+            if need2:
+                g2 = torch.empty_like(f2)
+                _call("fs_plane_norm_bwd", f2.data_ptr(), st2.data_ptr(), gn2.data_ptr(), g2.data_ptr(),
+                      B * C, H * W, s, algo_bytes=12 * f2.numel())
+        return g1, g2, None
+
+
+def corr2d_normalized(f1, f2, max_displacement=4):
+    """Cost volume of the per-plane centred / scaled feature maps (UPFlow `if_norm_before_cost_volume`
+    with moments per channel and per image), without materialising the normalised maps."""
+    return _Corr2DNorm.apply(f1, f2, int(max_displacement))
+
+
 # --------------------------------------------------------------------------------------------
 # a9/a10: robust penalty + masked reduction (UPFlow/utils/loss.py:17-48, upflow.py:267-289)
 # --------------------------------------------------------------------------------------------

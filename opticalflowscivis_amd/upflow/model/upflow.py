@@ -307,15 +307,22 @@ class UPFlow_net(tools.abstract_model):
         else:
             feature_2_warp = self.warping_layer(feature_2, flow_1_up)   # HIP: warp + validity mask
             feature_1_warp = self.warping_layer(feature_1, flow_2_up)
-        if conf.if_norm_before_cost_volume:
-            kw = dict(normalize=True, center=True,
-                      moments_across_channels=conf.norm_moments_across_channels,
-                      moments_across_images=conf.norm_moments_across_images)
-            feature_1, feature_2_warp = network_tools.normalize_features((feature_1, feature_2_warp), **kw)
-            feature_2, feature_1_warp = network_tools.normalize_features((feature_2, feature_1_warp), **kw)
-        # HIP cost volume through the reference's own autograd shim (upflow.py:649,652)
-        out_corr_1 = CorrelationFunction.apply(feature_1, feature_2_warp, 4, 1, 4, 1, 1, 1)
-        out_corr_2 = CorrelationFunction.apply(feature_2, feature_1_warp, 4, 1, 4, 1, 1, 1)
+        if (conf.if_norm_before_cost_volume and not conf.norm_moments_across_channels
+                and not conf.norm_moments_across_images and feature_1.is_cuda):
+            # §8f.4: per-plane normalisation folded into the cost-volume kernels' tile loads (the
+            # normalised maps feed nothing else, upflow.py:635-652)
+            out_corr_1 = ops.corr2d_normalized(feature_1, feature_2_warp, 4)
+            out_corr_2 = ops.corr2d_normalized(feature_2, feature_1_warp, 4)
+        else:
+            if conf.if_norm_before_cost_volume:
+                kw = dict(normalize=True, center=True,
+                          moments_across_channels=conf.norm_moments_across_channels,
+                          moments_across_images=conf.norm_moments_across_images)
+                feature_1, feature_2_warp = network_tools.normalize_features((feature_1, feature_2_warp), **kw)
+                feature_2, feature_1_warp = network_tools.normalize_features((feature_2, feature_1_warp), **kw)
+            # HIP cost volume through the reference's own autograd shim (upflow.py:649,652)
+            out_corr_1 = CorrelationFunction.apply(feature_1, feature_2_warp, 4, 1, 4, 1, 1, 1)
+            out_corr_2 = CorrelationFunction.apply(feature_2, feature_1_warp, 4, 1, 4, 1, 1, 1)
         out_corr_relu_1 = self.leakyRELU(out_corr_1)
         out_corr_relu_2 = self.leakyRELU(out_corr_2)
         feat_1, res_1 = self.flow_estimators(torch.cat([out_corr_relu_1, feature_1_1x1, flow_1_up], dim=1))

@@ -58,3 +58,29 @@ def corr3d_closed(f1, f2, md=4):
                 sh = f2p[:, :, md + dz:md + dz + D, md + dy:md + dy + H, md + dx:md + dx + W]
                 outs.append((f1 * sh).mean(dim=1))
     return torch.stack(outs, dim=1)
+
+
+# --------------------------------------------------------------------------------------------
+# §8f.4  UPFlow/model/upflow.py:96-138 network_tools.normalize_features
+# --------------------------------------------------------------------------------------------
+def normalize_features(feature_list, normalize=True, center=True, moments_across_channels=True,
+                       moments_across_images=True):
+    axes = [1, 2, 3] if moments_across_channels else [2, 3]                       # :113
+    means = [torch.mean(f, dim=axes, keepdim=True) for f in feature_list]         # :115
+    variances = [torch.var(f, dim=axes, keepdim=True) for f in feature_list]      # :116 (unbiased)
+    if moments_across_images:                                                     # :120-126
+        means = [torch.mean(torch.stack(means, dim=0), dim=(0,))] * len(feature_list)
+        # the reference takes the VARIANCE of the per-image variances here (:126), not their mean
+        variances = [torch.var(torch.stack(variances, dim=0), dim=(0,))] * len(feature_list)
+    stds = [torch.sqrt(v + 1e-16) for v in variances]                             # :128
+    if center:
+        feature_list = [f - m for f, m in zip(feature_list, means)]               # :132-135
+    if normalize:
+        feature_list = [f / s for f, s in zip(feature_list, stds)]                # :136-137
+    return feature_list
+
+
+def corr2d_normalized_ref(f1, f2, md=4):
+    """The C3 path: per-plane moments (both flags False), then the cost volume (upflow.py:635-652)."""
+    n1, n2 = normalize_features((f1, f2), True, True, False, False)
+    return corr2d_closed(n1, n2, md)

@@ -393,3 +393,34 @@ def test_conv_prelu_fused_node_vs_fp64(ops, tr, nw):
         assert float((a.detach().cpu().double() - b).abs().max()) < 5e-5 * float(b.abs().max())
     with torch.no_grad():  # inference path of the same module: unfused children
         assert float((seq(xd) - z).abs().max()) < 1e-6
+
+
+def test_corr2d_normalized_golden_and_oracle(ops, golden):
+    """§8f.4: normalize_features folded into the cost volume.  (1) fs_plane_moments / the adjoint
+    against the reference's normalize_features vectors; (2) the fused op against the oracle at UPFlow
+    level shapes, gradients included."""
+    g = golden("upflow_next")
+    f1 = T(g["nf_f1"], True)
+    # (1) identity "correlation": md=1 centre tap of corr(f, ones-like) is not available, so check the
+    # normalisation through autograd of the fused op with f2 = a fixed probe and compare to the oracle
+    # built on the golden-pinned normalize_features
+    for shape, md in (((2, 5, 9, 13), 4), ((1, 32, 19, 57), 4), ((2, 3, 10, 29), 2), ((1, 7, 3, 8), 4)):
+        gen = torch.Generator().manual_seed(shape[1])
+        a = (1.5 * torch.randn(shape, generator=gen) + 0.7)
+        b = (0.5 * torch.randn(shape, generator=gen) - 0.2)
+        ac, bc = a.clone().requires_grad_(), b.clone().requires_grad_()
+        ref = ocorr.corr2d_normalized_ref(ac, bc, md)
+        G = torch.randn(ref.shape, generator=gen)
+        ga, gb = torch.autograd.grad((ref * G).sum(), [ac, bc])
+        ad, bd = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        out = ops.corr2d_normalized(ad, bd, md)
+        assert relerr(out, ref) < 2e-5
+        ha, hb = torch.autograd.grad((out * G.to(DEV)).sum(), [ad, bd])
+        assert relerr(ha, ga) < 1e-4 and relerr(hb, gb) < 1e-4
+    # the golden inputs through the fused op == the reference's normalised maps through the plain op
+    n1, n2 = T(g["nf_c0_i0_o1"]), T(g["nf_c0_i0_o2"])
+    want = ops.corr2d(n1, n2, 4)
+    got = ops.corr2d_normalized(f1.detach(), T(g["nf_f2"]), 4)
+    assert relerr(got, want.cpu()) < 2e-5
+    with pytest.raises(ValueError):
+        ops.corr2d_normalized(torch.rand(1, 2, 1, 1, device=DEV), torch.rand(1, 2, 1, 1, device=DEV))

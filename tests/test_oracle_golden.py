@@ -162,3 +162,18 @@ def test_lap_loss(golden):
         ga, gb = torch.autograd.grad(loss, [a, b])
         close(ga, g["lap_%s_ga" % tag], 1e-9, 1e-5)
         close(gb, g["lap_%s_gb" % tag], 1e-9, 1e-5)
+
+
+def test_normalize_features(golden):
+    """§8f.4: the oracle's normalize_features against the reference, all four flag combinations."""
+    g = golden("upflow_next")
+    for ch in (False, True):
+        for im in (False, True):
+            tag = "nf_c%d_i%d_" % (int(ch), int(im))
+            f1, f2 = T(g["nf_f1"], True), T(g["nf_f2"], True)
+            o1, o2 = ocorr.normalize_features((f1, f2), True, True, ch, im)
+            close(o1, g[tag + "o1"], 1e-6, 1e-6)
+            close(o2, g[tag + "o2"], 1e-6, 1e-6)
+            g1, g2 = torch.autograd.grad((o1 * T(g[tag + "G1"])).sum() + (o2 * T(g[tag + "G2"])).sum(), [f1, f2])
+            close(g1, g[tag + "g1"], 1e-5, 1e-5)
+            close(g2, g[tag + "g2"], 1e-5, 1e-5)
