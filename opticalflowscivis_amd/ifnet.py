@@ -118,8 +118,11 @@ class IFNet(nn.Module):
         self.block_tea = IFBlock(nd, 6 + fc, c=64)
 
     def forward(self, x, scale=(4, 2, 1), timestep=0.5):
-        img0, img1 = x[:, :1], x[:, 1:2]
+        # channel slices of [B,3,...] are strided: split once into contiguous frames (every warp and
+        # epilogue launch would otherwise copy them again)
+        img0, img1 = x[:, :1].contiguous(), x[:, 1:2].contiguous()
         gt = x[:, 2:3] if self.nd == 2 else x[:, 2:]  # empty at inference time
+        gt = gt.contiguous()
         flow_list, merged, mask_list, mask_logits = [], [], [], []
         warped_img0, warped_img1 = img0, img1
         flow = mask = None
