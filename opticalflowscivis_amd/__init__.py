@@ -10,11 +10,13 @@ import os as _os
 
 # MIOpen has no gfx950 find-db in ROCm 7.2, so the first call of every convolution shape runs a
 # "find" that also times its naive direct kernels -- 1.4 s per call for a 128^3 IFNet-3D layer,
-# minutes per step at 256^3 -- although they never win forward / backward-data.  The convolutions
-# are not part of this package's hot path (they stay on MIOpen), but its entry points must start in
-# bounded time, so the naive fwd/bwd solvers are taken out of the search unless the user has
-# already chosen otherwise.  (Weight-gradient is left alone: for a few IFNet layers naive_wrw IS
-# MIOpen's fastest applicable solver.)
-for _k in ("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD"):
+# minutes per step at 256^3; 63 ms x 656 calls = 42 s of `naive_conv_ab_nonpacked_wrw` before the
+# first UPFlow step at C3 -- although they never win (the 3-D layers run on this package's own
+# kernels, csrc/conv{fwd,tr,wrw}.hip; for the 2-D nets the igemm / Winograd solvers are picked with
+# or without them: C2 13.6 ms and C3 88 ms per step either way).  The package's entry points must
+# start in bounded time, so the naive solvers are taken out of the search unless the user has already
+# chosen otherwise.
+for _k in ("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD",
+           "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW"):
     _os.environ.setdefault(_k, "0")
 del _k
