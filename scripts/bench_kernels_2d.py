@@ -59,3 +59,57 @@ row("warp2d pwc+mask fwd 32x32x38x113", t(lambda: ops.warp2d_pwc(f, fl, True)), 
 i0, i1 = torch.rand(16, 1, 160, 224, device=dev), torch.rand(16, 1, 160, 224, device=dev)
 f4 = torch.randn(16, 4, 160, 224, device=dev)
 row("warp2d pair fwd 16x1x160x224 (C2)", t(lambda: ops.warp_pair(i0, i1, f4)), 2 * 16 * 16 * 160 * 224)
+# §8f.2: occlusion check (one launch) vs the stock-op sequence it replaces
+ff = 2.0 * torch.randn(B, 2, 1, 1, device=dev) + torch.randn(B, 2, 150, 450, device=dev)
+fbk = -ff + 0.5 * torch.randn(B, 2, 150, 450, device=dev)
+row("occ_check2d 'obj' 32x2x150x450 (fused)", t(lambda: ops.occ_check2d(ff, fbk, 0.1, 0.5, 1, "obj")), 24 * npx)
+from opticalflowscivis_amd.upflow.utils.tools import tools as _tools
+_m = _tools.occ_check_model(occ_alpha_1=0.1, occ_alpha_2=0.5, obj_out_all="obj")
+
+
+def _occ_stock():
+    o1, o2 = _m._forward_backward_occ_check(ff, fbk, 1)
+    return (_m.torch_get_obj_occ_check(o1, _m.torch_outgoing_occ_check(ff)),
+            _m.torch_get_obj_occ_check(o2, _m.torch_outgoing_occ_check(fbk)))
+
+
+row("occ_check 'obj' stock ops + HIP warps", t(_occ_stock), 24 * npx)
+# §8f.3: Laplacian-pyramid loss at C2 (fwd + bwd), fused vs the stock-op pyramid
+from opticalflowscivis_amd import rife as _rife
+a = torch.rand(16, 1, 160, 224, device=dev, requires_grad=True)
+b = torch.rand(16, 1, 160, 224, device=dev)
+
+
+def _lap_hip():
+    (g,) = torch.autograd.grad(ops.laploss2d(a, b, 5), [a])
+    return g
+
+
+def _lap_stock():
+    k = _rife._gauss_kernel(1, a.device)
+    pa, pb = _rife._laplacian_pyramid(a, k, 5), _rife._laplacian_pyramid(b, k, 5)
+    loss = sum(torch.nn.functional.l1_loss(x, y) for x, y in zip(pa, pb))
+    (g,) = torch.autograd.grad(loss, [a])
+    return g
+
+
+row("laploss2d fwd+bwd 16x1x160x224 (fused)", t(_lap_hip), 16 * 16 * 160 * 224)
+row("LapLoss fwd+bwd stock ops", t(_lap_stock, n=20), 16 * 16 * 160 * 224)
+# §8f.4: normalised cost volume at the finest UPFlow level, fused vs normalize_features + corr2d
+from opticalflowscivis_amd.upflow.model.upflow import network_tools as _nt
+f1 = torch.randn(B, 32, 38, 113, device=dev, requires_grad=True)
+f2 = torch.randn(B, 32, 38, 113, device=dev, requires_grad=True)
+Gc = torch.randn(B, 81, 38, 113, device=dev)
+
+
+def _cn_hip():
+    return torch.autograd.grad(ops.corr2d_normalized(f1, f2, 4), [f1, f2], Gc)
+
+
+def _cn_stock():
+    n1, n2 = _nt.normalize_features((f1, f2), True, True, False, False)
+    return torch.autograd.grad(ops.corr2d(n1, n2, 4), [f1, f2], Gc)
+
+
+row("corr2d_normalized fwd+bwd C=32 38x113 (fused)", t(_cn_hip), 4 * (6 * 32 + 2 * 81) * 38 * 113 * B)
+row("normalize_features + corr2d fwd+bwd (stock)", t(_cn_stock), 4 * (6 * 32 + 2 * 81) * 38 * 113 * B)
