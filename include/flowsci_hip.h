@@ -315,6 +315,18 @@ int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, f
  * Cout <= 32 (FS_ERR_ARG otherwise).  ws: fs_conv3d_tr_ws_floats(Cin, Cout) floats of device scratch
  * (0 for Cout <= 6: those run on the vector ALUs with scalar-loaded weights).
  */
+/* fs_conv3d_fwd_prelu / fs_conv3d_tr_prelu: the same convolutions with the PReLU that follows every one of
+ * them in IFNet (`conv()` / `deconv()`, Flow-3D/model/IFNet.py:13-29) applied in the epilogue:
+ * y = conv(x) + bias (kept: the PReLU backward needs it) and z = y > 0 ? y : prelu_weight[c] * y are written
+ * in the same pass (num_prelu_weights = 1 or Cout).  fwd_prelu is wmode 0 only. */
+int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
+                        float* y, float* z, float* ws,
+                        int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                        int kernel, int stride, int pad, int num_prelu_weights, fs_stream_t stream);
+int fs_conv3d_tr_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
+                       float* y, float* z, float* ws,
+                       int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
+                       int num_prelu_weights, fs_stream_t stream);
 long long fs_conv3d_tr_ws_floats(int Cin, int Cout);
 int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws,
                  int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,

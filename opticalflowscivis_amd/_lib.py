@@ -38,6 +38,8 @@ SIGNATURES = {
     "fs_laploss2d_bwd": [_f32p] * 4 + [_int] * 4 + [_stream],
     "fs_conv3d_fwd_ws_floats": [_int] * 3,
     "fs_conv3d_fwd": [_f32p] * 5 + [_int] * 13 + [_stream],
+    "fs_conv3d_fwd_prelu": [_f32p] * 7 + [_int] * 13 + [_stream],
+    "fs_conv3d_tr_prelu": [_f32p] * 7 + [_int] * 10 + [_stream],
     "fs_conv3d_tr_ws_floats": [_int] * 2,
     "fs_conv3d_tr": [_f32p] * 5 + [_int] * 9 + [_stream],
     "fs_plane_moments": [_f32p] * 2 + [_int] * 2 + [_stream],

@@ -115,19 +115,26 @@ def _conv_out(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
-def _conv_forward(x, w, b, stride, padding, transposed):
+def _conv_forward(x, w, b, stride, padding, transposed, prelu_weight=None):
+    """y = conv(x); with `prelu_weight` returns (y, prelu(y)) -- from the convolution's own epilogue on
+    the HIP paths, as a separate pass otherwise."""
     nd = x.dim() - 2
+    y = None
     if transposed and nd == 3 and _hip_tr_ok(x, w.shape[1], tuple(w.shape[2:]), stride, padding):
         from . import ops
-        return ops.conv3d_tr(x, w, b)
-    if transposed:
-        return (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
-    if nd == 3 and _hip_fwd_ok(x, w.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
-                                               zip(x.shape[2:], w.shape[2:], stride, padding)],
-                               tuple(w.shape[2:]), stride, padding):
+        y = ops.conv3d_tr(x, w, b, None, prelu_weight)
+    elif transposed:
+        y = (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
+    elif nd == 3 and _hip_fwd_ok(x, w.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
+                                                 zip(x.shape[2:], w.shape[2:], stride, padding)],
+                                 tuple(w.shape[2:]), stride, padding):
         from . import ops
-        return ops.conv3d_fwd(x, w, b, w.shape[2], stride[0], padding[0], 0)
-    return (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, padding)
+        y = ops.conv3d_fwd(x, w, b, w.shape[2], stride[0], padding[0], 0, prelu_weight)
+    else:
+        y = (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, padding)
+    if prelu_weight is None or isinstance(y, tuple):
+        return y
+    return y, F.prelu(y, prelu_weight)
 
 
 def _conv_grad_input(x, w, gy, stride, padding, transposed):
@@ -198,8 +205,7 @@ class _ConvPReLUFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, a, stride, padding, transposed):
-        y = _conv_forward(x, w, b, stride, padding, transposed)
-        z = F.prelu(y, a)
+        y, z = _conv_forward(x, w, b, stride, padding, transposed, a)
         ctx.save_for_backward(x, w, y, a)
         ctx.cfg = (stride, padding, transposed, b is not None)
         return z

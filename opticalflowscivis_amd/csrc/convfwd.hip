@@ -35,6 +35,10 @@ struct FP {
   int pad;
   int tz, ty, tx;  // tiles per axis
   long long tiles;
+  // optional fused PReLU: Z = prelu(Y) written next to Y (Y is kept: the PReLU backward needs it)
+  const float* slope;
+  float* Z;
+  int nslope;  // 1 (shared) or Cout
 };
 
 // Wt[ci][tap][co] (ci < CinP, co < CoutP; zero outside the real channels)
@@ -212,7 +216,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (co < p.Cout) yb[(size_t)co * yvol] = acc[m][n][r] + (bias ? bias[co] : 0.f);
+          if (co < p.Cout) {
+            const float v = acc[m][n][r] + (bias ? bias[co] : 0.f);
+            yb[(size_t)co * yvol] = v;
+            if (p.Z != nullptr)
+              p.Z[(yb - Y) + (size_t)co * yvol] = v > 0.f ? v : p.slope[p.nslope == 1 ? 0 : co] * v;
+          }
         }
     }
   }
@@ -247,11 +256,11 @@ extern "C" long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel) {
   return (long long)cinp * kernel * kernel * kernel * coutp;
 }
 
-extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B,
-                             int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kernel,
-                             int stride, int pad, int wmode, fs_stream_t stream) {
-  FS_ENTER();
+static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
+                           float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
+                           int Ho, int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y); FS_REQUIRE_PTR(ws);
+  if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1 || Do < 1 || Ho < 1 || Wo < 1)
     return FS_ERR_SHAPE;
   if (!((kernel == 3 && stride == 1) || (kernel == 4 && stride == 2)) || pad < 0 || pad >= kernel ||
@@ -267,6 +276,7 @@ extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, 
   FP p;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Do; p.Ho = Ho; p.Wo = Wo;
   p.pad = pad;
+  p.slope = slope; p.Z = z; p.nslope = nslope;
   int cinp;
   wt_dims(Cin, Cout, kernel, &cinp, &p.CoutP);
   hipStream_t st = (hipStream_t)stream;
@@ -294,4 +304,22 @@ extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, 
   }
   if (Wo > 16) return launch<4, 2, 2, 2, 2, 1, 8, 32>(x, ws, bias, y, p, st);
   return launch<4, 2, 2, 2, 2, 1, 8, 16>(x, ws, bias, y, p, st);
+}
+
+extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B,
+                             int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kernel,
+                             int stride, int pad, int wmode, fs_stream_t stream) {
+  FS_ENTER();
+  return conv3d_fwd_impl(x, w, bias, nullptr, 0, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, kernel,
+                         stride, pad, wmode, stream);
+}
+
+extern "C" int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
+                                   float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi,
+                                   int Wi, int Do, int Ho, int Wo, int kernel, int stride, int pad,
+                                   int num_prelu_weights, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
+  return conv3d_fwd_impl(x, w, bias, prelu_weight, num_prelu_weights, y, z, ws, B, Cin, Cout, Di, Hi, Wi, Do,
+                         Ho, Wo, kernel, stride, pad, 0, stream);
 }

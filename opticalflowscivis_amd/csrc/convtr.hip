@@ -34,6 +34,10 @@ struct TP {
   int Dq, Hq, Wq;        // input-grid positions that own outputs: ceil(out / 2)
   int tz, ty, tx;
   long long tiles;
+  // optional fused PReLU: Z = prelu(Y) written next to Y
+  const float* slope;
+  float* Z;
+  int nslope;
 };
 
 // tap a (0/1) of output parity p along one axis: input offset d and kernel index k
@@ -50,9 +54,10 @@ __global__ __launch_bounds__(256) void wprep_tr_kernel(const float* __restrict__
   }
 }
 
-// all 8 outputs of position q for channel co; float2 stores when the rows are 8-byte aligned
+// all 8 outputs of position q for channel co; float2 stores when the rows are 8-byte aligned.
+// zc / sl: the same channel's plane of the fused PReLU output and its slope (zc may be null).
 __device__ __forceinline__ void store8(float* __restrict__ yc, const float (&v)[8], int qz, int qy, int qx,
-                                       const TP& p) {
+                                       const TP& p, float* __restrict__ zc = nullptr, float sl = 0.f) {
 #pragma unroll
   for (int pz = 0; pz < 2; ++pz)
 #pragma unroll
@@ -66,6 +71,16 @@ __device__ __forceinline__ void store8(float* __restrict__ yc, const float (&v)[
       } else {
         row[0] = v0;
         if (x + 1 < p.Wout) row[1] = v1;
+      }
+      if (zc != nullptr) {
+        float* zrow = zc + (row - yc);
+        const float z0 = v0 > 0.f ? v0 : sl * v0, z1 = v1 > 0.f ? v1 : sl * v1;
+        if ((p.Wout & 1) == 0) {
+          *reinterpret_cast<float2*>(zrow) = make_float2(z0, z1);
+        } else {
+          zrow[0] = z0;
+          if (x + 1 < p.Wout) zrow[1] = z1;
+        }
       }
     }
 }
@@ -183,7 +198,8 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __rest
       float v[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = acc[c][r] + bv;
-      store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p);
+      store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p,
+             p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
     }
   }
 }
@@ -322,7 +338,8 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma16_kernel(const float* __re
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = acc[n][c][r] + bv;
-        store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p);
+        store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p,
+               p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
       }
     }
   }
@@ -388,7 +405,9 @@ __global__ __launch_bounds__(256) void convtr_valu_kernel(const float* __restric
   const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
 #pragma unroll
   for (int co = 0; co < CO; ++co)
-    if (co < p.Cout) store8(Y + ((size_t)b * p.Cout + co) * yvol, acc[co], qz, qy, qx, p);
+    if (co < p.Cout)
+      store8(Y + ((size_t)b * p.Cout + co) * yvol, acc[co], qz, qy, qx, p,
+             p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
 }
 
 template <int CO>
@@ -406,11 +425,11 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   return (long long)((Cin + 3) / 4 * 4) * 64 * (Cout <= 16 ? 16 : 32);
 }
 
-extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws, int B,
-                            int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
-                            fs_stream_t stream) {
-  FS_ENTER();
+static int conv3d_tr_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
+                          float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout,
+                          int Hout, int Wout, fs_stream_t stream) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y);
+  if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1) return FS_ERR_SHAPE;
   if (Cout > 32) return FS_ERR_ARG;
   // transposed convolution: out = 2 in; input gradient of Conv3d(4,2,1): in_x = 2 out or 2 out + 1
@@ -424,6 +443,7 @@ extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, f
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
   p.Dout = Dout; p.Hout = Hout; p.Wout = Wout;
   p.Dq = (Dout + 1) / 2; p.Hq = (Hout + 1) / 2; p.Wq = (Wout + 1) / 2;
+  p.slope = slope; p.Z = z; p.nslope = nslope;
   hipStream_t st = (hipStream_t)stream;
   if ((long long)B * p.Dq * p.Hq * p.Wq >= (1ll << 31) * 256) return FS_ERR_SHAPE;
   if (Cout <= 6) {
@@ -451,4 +471,20 @@ extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, f
   }
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+
+extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws, int B,
+                            int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
+                            fs_stream_t stream) {
+  FS_ENTER();
+  return conv3d_tr_impl(x, w, bias, nullptr, 0, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout, stream);
+}
+
+extern "C" int fs_conv3d_tr_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
+                                  float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                                  int Dout, int Hout, int Wout, int num_prelu_weights, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
+  return conv3d_tr_impl(x, w, bias, prelu_weight, num_prelu_weights, y, z, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout,
+                        Wout, stream);
 }

@@ -61,9 +61,10 @@ def kernel_timings():
     return {k: [(a.elapsed_time(b), nb, fl) for a, b, nb, fl in v] for k, v in _timing.items()}
 
 
-def _call(name, *args, algo_bytes=0, algo_flops=0):
+def _call(name, *args, algo_bytes=0, algo_flops=0, record_as=None):
     """Launch a C-ABI entry point.  `algo_bytes` / `algo_flops` = compulsory HBM bytes / useful flops of
-    this launch, only used by the optional timing records."""
+    this launch, only used by the optional timing records (`record_as`: file the record
+    under another entry point's name -- the *_prelu variants are the same kernels with one more store)."""
     fn = getattr(_lib.lib(), name)
     if _timing is None:
         _lib.check(fn(*args), name)
@@ -74,7 +75,7 @@ def _call(name, *args, algo_bytes=0, algo_flops=0):
     code = fn(*args)
     e1.record()
     _lib.check(code, name)
-    _timing.setdefault(name, []).append((e0, e1, algo_bytes, algo_flops))
+    _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops))
 
 
 # --------------------------------------------------------------------------------------------
@@ -883,9 +884,10 @@ def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
     return B * Do * cd(Ho, 8 * r) * cd(Wo, tw) * mg
 
 
-def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0):
+def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None):
     """fs_conv3d_fwd: y = conv3d(x, W, bias, stride, pad) with W = w (wmode 0, [Cout,Cin,k,k,k]) or the
-    flipped transpose of w (wmode 1, w [Cin,Cout,k,k,k]: input gradient of a stride-1 same conv)."""
+    flipped transpose of w (wmode 1, w [Cin,Cout,k,k,k]: input gradient of a stride-1 same conv).
+    With `prelu_weight` (wmode 0): returns (y, prelu(y)), both written by the convolution's epilogue."""
     x = _need_cuda_f32("x", x, 5)
     w = _need_cuda_f32("w", w, 5)
     B, Cin = x.shape[:2]
@@ -902,20 +904,33 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0):
         raise ValueError("convolution output is empty for input %s" % (tuple(x.shape),))
     y = x.new_empty((B, Cout, Do, Ho, Wo))
     ws = x.new_empty(int(_lib.lib().fs_conv3d_fwd_ws_floats(Cin, Cout, int(k))))
+    nb, fl = 4 * (x.numel() + y.numel()), 2 * y.numel() * Cin * int(k) ** 3
     with torch.cuda.device(x.device):
-        _call("fs_conv3d_fwd", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin, Cout,
-              Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode), _stream(x),
-              algo_bytes=4 * (x.numel() + y.numel()), algo_flops=2 * y.numel() * Cin * int(k) ** 3)
-    return y
+        if prelu_weight is None:
+            _call("fs_conv3d_fwd", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
+                  Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode), _stream(x),
+                  algo_bytes=nb, algo_flops=fl)
+            return y
+        if wmode:
+            raise ValueError("the fused PReLU epilogue is forward-only (wmode 0)")
+        a = _need_cuda_f32("prelu_weight", prelu_weight, 1)
+        if a.numel() not in (1, Cout):
+            raise ValueError("prelu_weight must have 1 or %d elements" % Cout)
+        z = torch.empty_like(y)
+        _call("fs_conv3d_fwd_prelu", x.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), y.data_ptr(),
+              z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad),
+              a.numel(), _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_fwd")
+    return y, z
 
 
 def conv3d_tr_supported(cout, k, stride, padding):
     return (tuple(k) == (4, 4, 4) and tuple(stride) == (2, 2, 2) and tuple(padding) == (1, 1, 1) and cout <= 32)
 
 
-def conv3d_tr(x, w, bias, out_dhw=None):
+def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None):
     """fs_conv3d_tr: ConvTranspose3d(4, 2, 1)(x) with weight w [Cin,Cout,4,4,4]; with out_dhw = the
-    input extent of a Conv3d(4, 2, 1) layer and w = that layer's weight, its input gradient."""
+    input extent of a Conv3d(4, 2, 1) layer and w = that layer's weight, its input gradient.
+    With `prelu_weight`: returns (y, prelu(y)), both written by the epilogue."""
     x = _need_cuda_f32("x", x, 5)
     w = _need_cuda_f32("w", w, 5)
     B, Cin = x.shape[:2]
@@ -933,11 +948,20 @@ def conv3d_tr(x, w, bias, out_dhw=None):
     if nws < 0:
         raise ValueError("fs_conv3d_tr supports at most 32 output channels, got %d" % Cout)
     ws = x.new_empty(max(nws, 1))
+    nb, fl = 4 * (x.numel() + y.numel()), 2 * x.numel() * Cout * 64
     with torch.cuda.device(x.device):
-        _call("fs_conv3d_tr", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin, Cout,
-              Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=4 * (x.numel() + y.numel()),
-              algo_flops=2 * x.numel() * Cout * 64)
-    return y
+        if prelu_weight is None:
+            _call("fs_conv3d_tr", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
+                  Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb, algo_flops=fl)
+            return y
+        a = _need_cuda_f32("prelu_weight", prelu_weight, 1)
+        if a.numel() not in (1, Cout):
+            raise ValueError("prelu_weight must have 1 or %d elements" % Cout)
+        z = torch.empty_like(y)
+        _call("fs_conv3d_tr_prelu", x.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), y.data_ptr(),
+              z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, a.numel(), _stream(x),
+              algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_tr")
+    return y, z
 
 
 # --------------------------------------------------------------------------------------------
