@@ -263,6 +263,15 @@ int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws, int B, int
                     int Din, int Hin, int Win, int Dout, int Hout, int Wout,
                     int factor, int upsample, fs_stream_t stream);
 
+/* Forward companion for the up-sampling side (Flow-3D/model/IFNet.py:118-119 followed by the
+ * accumulation at :213-214 / :228-229):
+ *   out = prev + scale * interpolate(small, scale_factor = factor, trilinear, align_corners=False)
+ * small [B,C,Din,Hin,Win] -> out [B,C,factor*Din,...]; prev (same shape as out) may be NULL (= 0);
+ * factor in {2, 4}.  ATen's index / weight arithmetic and summation order.  The adjoint of the
+ * interpolation is fs_interp3d_bwd (times scale); d out / d prev is the identity. */
+int fs_upsample3d_scale_add(const float* small, const float* prev, float* out, int B, int C,
+                            int Din, int Hin, int Win, int factor, float scale, fs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * f3. Laplacian-pyramid L1 loss of Flow-2D: Flow-2D/model/laplacian.py:10-88
  * (gauss_kernel :10-19, downsample :21-22, upsample :24-36, conv_gauss :38-47,
@@ -327,6 +336,11 @@ int fs_conv3d_tr_prelu(const float* x, const float* w, const float* bias, const 
                        float* y, float* z, float* ws,
                        int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
                        int num_prelu_weights, fs_stream_t stream);
+/* fs_conv3d_tr_add: y = conv_transpose(x) + bias + addend (addend has y's shape): the head's flow / mask
+ * delta accumulated onto the running flow / mask (Flow-3D/model/IFNet.py:213-214, 228-229) in the epilogue. */
+int fs_conv3d_tr_add(const float* x, const float* w, const float* bias, const float* addend, float* y,
+                     float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                     int Dout, int Hout, int Wout, fs_stream_t stream);
 long long fs_conv3d_tr_ws_floats(int Cin, int Cout);
 int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws,
                  int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,

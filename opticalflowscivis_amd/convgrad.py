@@ -198,6 +198,33 @@ class _ConvFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+class _ConvTrAddFn(torch.autograd.Function):
+    """y = conv_transpose(x, w, b) + addend with the addition done in the kernel's epilogue
+    (fs_conv3d_tr_add); d y / d addend is the identity."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, addend, stride, padding):
+        from . import ops
+        y = ops.conv3d_tr(x, w, b, None, None, addend)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv_grad_input(x, w, gy, stride, padding, True)
+        if ctx.needs_input_grad[1]:
+            gw = _conv_grad_weight(x, w, gy, stride, padding, True)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(0, 2, 3, 4))
+        return gx, gw, gb, (gy if ctx.needs_input_grad[3] else None), None, None
+
+
 class _ConvPReLUFn(torch.autograd.Function):
     """conv (or transposed conv) + bias + per-channel PReLU as ONE autograd node: the PReLU backward
     pass (csrc/prelu.hip) already streams the convolution's grad_out, so it also produces the bias
@@ -259,15 +286,30 @@ class Conv3d(nn.Conv3d):
 
 
 class ConvTranspose3d(nn.ConvTranspose3d):
-    def forward(self, x):
+    def _plain(self):
+        return (self.groups == 1 and _tuple(self.dilation, 3) == (1, 1, 1) and
+                _tuple(self.output_padding, 3) == (0, 0, 0))
+
+    def forward(self, x, addend=None):
+        """`addend` (optional, the output's shape): returns conv_transpose(x) + addend, accumulated in the
+        kernel's epilogue where the HIP path applies."""
+        st, pd, k = _tuple(self.stride, 3), _tuple(self.padding, 3), tuple(self.weight.shape[2:])
+        hip = x.dim() == 5 and self._plain() and _hip_tr_ok(x, self.weight.shape[1], k, st, pd)
+        if addend is not None:
+            if hip and tuple(addend.shape[2:]) == tuple(2 * n for n in x.shape[2:]) and \
+                    addend.shape[1] == self.weight.shape[1] and addend.dtype == torch.float32:
+                if _use_gemm(x):
+                    return _ConvTrAddFn.apply(x, self.weight, self.bias, addend, st, pd)
+                from . import ops
+                return ops.conv3d_tr(x, self.weight.detach(), None if self.bias is None else self.bias.detach(),
+                                     None, None, addend)
+            return self.forward(x) + addend
         if not _use_gemm(x):
-            st, pd, k = _tuple(self.stride, 3), _tuple(self.padding, 3), tuple(self.weight.shape[2:])
-            if x.dim() == 5 and self.groups == 1 and _tuple(self.dilation, 3) == (1, 1, 1) and \
-                    _tuple(self.output_padding, 3) == (0, 0, 0) and _hip_tr_ok(x, self.weight.shape[1], k, st, pd):
+            if hip:
                 from . import ops  # inference: same kernel, no autograd node
                 return ops.conv3d_tr(x, self.weight.detach(), None if self.bias is None else self.bias.detach())
             return super().forward(x)
-        return _ConvFn.apply(x, self.weight, self.bias, _tuple(self.stride, 3), _tuple(self.padding, 3), True)
+        return _ConvFn.apply(x, self.weight, self.bias, st, pd, True)
 
 
 class PReLU(nn.PReLU):

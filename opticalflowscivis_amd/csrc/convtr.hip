@@ -38,6 +38,9 @@ struct TP {
   const float* slope;
   float* Z;
   int nslope;
+  // optional residual: Y = conv + bias + addend (same shape as Y) -- IFNet's `flow = flow + flow_d`
+  const float* addend;
+  const float* Ybase;  // = Y (to locate the addend plane of a channel)
 };
 
 // tap a (0/1) of output parity p along one axis: input offset d and kernel index k
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256) void wprep_tr_kernel(const float* __restrict__
 // zc / sl: the same channel's plane of the fused PReLU output and its slope (zc may be null).
 __device__ __forceinline__ void store8(float* __restrict__ yc, const float (&v)[8], int qz, int qy, int qx,
                                        const TP& p, float* __restrict__ zc = nullptr, float sl = 0.f) {
+  const float* __restrict__ ac = p.addend ? p.addend + (yc - p.Ybase) : nullptr;
 #pragma unroll
   for (int pz = 0; pz < 2; ++pz)
 #pragma unroll
@@ -65,7 +69,12 @@ __device__ __forceinline__ void store8(float* __restrict__ yc, const float (&v)[
       const int z = 2 * qz + pz, y = 2 * qy + py, x = 2 * qx;
       if (z >= p.Dout || y >= p.Hout || x >= p.Wout) continue;
       float* row = yc + ((size_t)z * p.Hout + y) * p.Wout + x;
-      const float v0 = v[(pz * 2 + py) * 2], v1 = v[(pz * 2 + py) * 2 + 1];
+      float v0 = v[(pz * 2 + py) * 2], v1 = v[(pz * 2 + py) * 2 + 1];
+      if (ac != nullptr) {
+        const float* arow = ac + (row - yc);
+        v0 += arow[0];
+        if (x + 1 < p.Wout) v1 += arow[1];
+      }
       if ((p.Wout & 1) == 0) {
         *reinterpret_cast<float2*>(row) = make_float2(v0, v1);
       } else {
@@ -426,8 +435,8 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
 }
 
 static int conv3d_tr_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
-                          float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout,
-                          int Hout, int Wout, fs_stream_t stream) {
+                          const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di,
+                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1) return FS_ERR_SHAPE;
@@ -444,6 +453,7 @@ static int conv3d_tr_impl(const float* x, const float* w, const float* bias, con
   p.Dout = Dout; p.Hout = Hout; p.Wout = Wout;
   p.Dq = (Dout + 1) / 2; p.Hq = (Hout + 1) / 2; p.Wq = (Wout + 1) / 2;
   p.slope = slope; p.Z = z; p.nslope = nslope;
+  p.addend = addend; p.Ybase = y;
   hipStream_t st = (hipStream_t)stream;
   if ((long long)B * p.Dq * p.Hq * p.Wq >= (1ll << 31) * 256) return FS_ERR_SHAPE;
   if (Cout <= 6) {
@@ -477,7 +487,17 @@ extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, f
                             int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
                             fs_stream_t stream) {
   FS_ENTER();
-  return conv3d_tr_impl(x, w, bias, nullptr, 0, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout, stream);
+  return conv3d_tr_impl(x, w, bias, nullptr, 0, nullptr, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout,
+                        stream);
+}
+
+extern "C" int fs_conv3d_tr_add(const float* x, const float* w, const float* bias, const float* addend, float* y,
+                                float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout,
+                                int Wout, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(addend);
+  return conv3d_tr_impl(x, w, bias, nullptr, 0, addend, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout,
+                        stream);
 }
 
 extern "C" int fs_conv3d_tr_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
@@ -485,6 +505,6 @@ extern "C" int fs_conv3d_tr_prelu(const float* x, const float* w, const float* b
                                   int Dout, int Hout, int Wout, int num_prelu_weights, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
-  return conv3d_tr_impl(x, w, bias, prelu_weight, num_prelu_weights, y, z, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout,
-                        Wout, stream);
+  return conv3d_tr_impl(x, w, bias, prelu_weight, num_prelu_weights, nullptr, y, z, ws, B, Cin, Cout, Di, Hi, Wi,
+                        Dout, Hout, Wout, stream);
 }

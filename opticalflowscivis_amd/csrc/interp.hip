@@ -163,6 +163,39 @@ __global__ __launch_bounds__(256) void interp_axis_adjoint_kernel(const float* _
   }
 }
 
+// ---- forward: out = prev + scale * trilinear_upsample(small) -------------------------------------
+// IFBlock's `flow = flow + interpolate(flow_d, scale_factor=s) * s` and `mask = mask + interpolate(mask_d, s)`
+// (Flow-3D/model/IFNet.py:118-119 with :213-214 / :228-229) in one pass: write the sum once instead of
+// materialising the upsampled tensor, scaling it and adding it (4.8 GB -> 1.6 GB for a 256^3 flow).
+// Index / weight arithmetic and summation order are ATen's upsample_trilinear3d_out_frame.
+__global__ __launch_bounds__(256) void upsample3d_scale_add_kernel(const float* __restrict__ small,
+                                                                   const float* __restrict__ prev,
+                                                                   float* __restrict__ out, IP p, float scale) {
+#pragma clang fp contract(off)
+  const long long nin = (long long)p.Di * p.Hi * p.Wi;
+  const long long nout = (long long)p.Do * p.Ho * p.Wo;
+  const long long total = p.nBC * nout;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long bc = e / nout;
+    const int r = (int)(e - bc * nout);
+    const int x = r % p.Wo, y = (r / p.Wo) % p.Ho, z = r / (p.Wo * p.Ho);
+    float sz = p.rs * ((float)z + 0.5f) - 0.5f, sy = p.rs * ((float)y + 0.5f) - 0.5f,
+          sx = p.rs * ((float)x + 0.5f) - 0.5f;
+    sz = sz < 0.f ? 0.f : sz; sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+    const int z0 = (int)sz, y0 = (int)sy, x0 = (int)sx;
+    const int zp = (z0 < p.Di - 1) ? 1 : 0, yp = (y0 < p.Hi - 1) ? 1 : 0, xp = (x0 < p.Wi - 1) ? 1 : 0;
+    const float lz1 = sz - (float)z0, ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float lz0 = 1.f - lz1, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* s = small + bc * nin + ((long long)z0 * p.Hi + y0) * p.Wi + x0;
+    const int dy = yp * p.Wi, dz = zp * p.Hi * p.Wi;
+    const float v =
+        lz0 * (ly0 * (lx0 * s[0] + lx1 * s[xp]) + ly1 * (lx0 * s[dy] + lx1 * s[dy + xp])) +
+        lz1 * (ly0 * (lx0 * s[dz] + lx1 * s[dz + xp]) + ly1 * (lx0 * s[dz + dy] + lx1 * s[dz + dy + xp]));
+    const float up = v * scale;
+    out[e] = prev ? prev[e] + up : up;
+  }
+}
+
 unsigned grid_for(long long total) {
   const long long want = (total + 255) / 256;
   return (unsigned)(want < (1 << 20) ? want : (1 << 20));
@@ -231,6 +264,25 @@ extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws,
     hipLaunchKernelGGL(interp3d_adjoint_kernel<8>, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
                        grad_in, p);
   }
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+extern "C" int fs_upsample3d_scale_add(const float* small, const float* prev, float* out, int B, int C, int Din,
+                                       int Hin, int Win, int factor, float scale, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(small); FS_REQUIRE_PTR(out);
+  if (B < 1 || C < 1 || Din < 1 || Hin < 1 || Win < 1) return FS_ERR_SHAPE;
+  if (factor != 2 && factor != 4) return FS_ERR_ARG;
+  if ((long long)Din * Hin * Win * factor * factor * factor >= (1ll << 31)) return FS_ERR_SHAPE;
+  IP p;
+  p.Di = Din; p.Hi = Hin; p.Wi = Win;
+  p.Do = Din * factor; p.Ho = Hin * factor; p.Wo = Win * factor;
+  p.up = 1; p.s = factor; p.rs = 1.0f / (float)factor;
+  p.nBC = (long long)B * C;
+  const long long total = p.nBC * p.Do * p.Ho * p.Wo;
+  hipLaunchKernelGGL(upsample3d_scale_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, small,
+                     prev, out, p, scale);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -31,12 +31,14 @@ def _conv(nd, cin, cout, kernel_size=3, stride=1, padding=1):
 
 class _Head(nn.Sequential):
     """Sequential(deconv, PReLU, deconv) of the reference heads (children 0, 1, 2); the first pair runs
-    as the fused node in 3-D training."""
+    as the fused node in 3-D training, the last deconv can accumulate onto `addend` in its epilogue."""
 
-    def forward(self, x):
+    def forward(self, x, addend=None):
         if isinstance(self[0], convgrad.ConvTranspose3d):
-            return self[2](convgrad.ConvPReLU.forward(self, x))
-        return super().forward(x)
+            h = convgrad.ConvPReLU.forward(self, x)
+            return self[2](h) if addend is None else self[2](h, addend)
+        y = super().forward(x)
+        return y if addend is None else y + addend
 
 
 def _head(nd, c, cout):
@@ -81,7 +83,11 @@ class IFBlock(nn.Module):
         self.conv1 = _head(nd, c, 2 * nd)  # flow: 4 (2-D) or 6 (3-D) channels
         self.conv2 = _head(nd, c, 1)       # blend-mask logit
 
-    def forward(self, x, flow, scale):
+    def forward(self, x, flow, scale, flow_base=None, mask_base=None, accumulate=False):
+        """Returns (flow_delta, mask_delta) as the reference's IFBlock does.  With `accumulate=True`
+        returns (flow_base + flow_delta, mask_base + mask_delta, True) when the sums can be formed inside
+        the producing kernels (3-D, GPU, delta and base of equal extent; a base may be None = zero), else
+        (flow_delta, mask_delta, False)."""
         mode = _INTERP[self.nd]
         if scale != 1:
             x = _resize(x, 1. / scale, mode)
@@ -94,12 +100,20 @@ class IFBlock(nn.Module):
         x = self.convblock1(x) + x
         x = self.convblock2(x) + x
         x = self.convblock3(x) + x
+        if accumulate and self.nd == 3 and x.is_cuda and x.dtype == torch.float32 and scale in (1, 2, 4):
+            full = tuple(4 * scale * n for n in x.shape[2:])  # two stride-2 deconvs, then x scale
+            if all(b is None or tuple(b.shape[2:]) == full for b in (flow_base, mask_base)):
+                if scale == 1:
+                    return self.conv1(x, flow_base), self.conv2(x, mask_base), True
+                # prev + scale * upsample(delta) in one pass (csrc/interp.hip)
+                return (ops.upsample3d_scale_add(self.conv1(x), flow_base, scale, float(scale)),
+                        ops.upsample3d_scale_add(self.conv2(x), mask_base, scale, 1.0), True)
         flow = self.conv1(x)
         mask = self.conv2(x)
         if scale != 1:
             flow = _resize(flow, scale, mode) * scale
             mask = _resize(mask, scale, mode)
-        return flow, mask
+        return (flow, mask, False) if accumulate else (flow, mask)
 
 
 class IFNet(nn.Module):
@@ -136,12 +150,15 @@ class IFNet(nn.Module):
                 img0, img1 = _crop(img0, sp), _crop(img1, sp)
                 warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
                 mask, flow = _crop(mask, sp), _crop(flow, sp)
-                flow_d, mask_d = stu[i](torch.cat((img0, img1, warped_img0, warped_img1, mask), 1),
-                                        flow, scale=scale[i])
-                flow = flow + _crop(flow_d, img0.shape[2:])
-                mask = mask + _crop(mask_d, img0.shape[2:])
+                flow_d, mask_d, summed = stu[i](torch.cat((img0, img1, warped_img0, warped_img1, mask), 1),
+                                                flow, scale[i], flow, mask, accumulate=True)
+                if summed:  # flow + flow_d, mask + mask_d formed inside the producing kernels
+                    flow, mask = flow_d, mask_d
+                else:
+                    flow = flow + _crop(flow_d, img0.shape[2:])
+                    mask = mask + _crop(mask_d, img0.shape[2:])
             else:
-                flow, mask = stu[i](torch.cat((img0, img1), 1), None, scale=scale[i])
+                flow, mask, _ = stu[i](torch.cat((img0, img1), 1), None, scale[i], accumulate=True)
             if self.nd == 2:
                 flow, mask = _crop(flow, img0.shape[2:]), _crop(mask, img0.shape[2:])
             sp = _min_spatial(img0, warped_img0)
@@ -159,11 +176,15 @@ class IFNet(nn.Module):
             img0, img1 = _crop(img0, sp), _crop(img1, sp)
             warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
             mask, flow, gt = _crop(mask, sp), _crop(flow, sp), _crop(gt, sp)
-            flow_d, mask_d = self.block_tea(
-                torch.cat((img0, img1, warped_img0, warped_img1, mask, gt), 1), flow, scale=1)
-            flow_teacher = flow + _crop(flow_d, sp)
+            flow_d, mask_d, summed = self.block_tea(
+                torch.cat((img0, img1, warped_img0, warped_img1, mask, gt), 1), flow, 1, flow, mask,
+                accumulate=True)
+            if summed:
+                flow_teacher, mask_teacher = flow_d, mask_d
+            else:
+                flow_teacher, mask_teacher = flow + _crop(flow_d, sp), mask + _crop(mask_d, sp)
             w0t, w1t = ops.warp_pair(img0, img1, flow_teacher)
-            merged_teacher, _ = ops.merge(w0t, w1t, mask + _crop(mask_d, sp))
+            merged_teacher, _ = ops.merge(w0t, w1t, mask_teacher)
         else:
             flow_teacher = None
             merged_teacher = None

@@ -750,6 +750,49 @@ class _Interp3D(torch.autograd.Function):
         return gx, None, None
 
 
+class _UpsampleScaleAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, small, prev, factor, scale):
+        small = _need_cuda_f32("small", small, 5)
+        B, C, Di, Hi, Wi = small.shape
+        out_shape = (B, C, Di * factor, Hi * factor, Wi * factor)
+        if prev is not None:
+            prev = _need_cuda_f32("prev", prev, 5)
+            if tuple(prev.shape) != out_shape:
+                raise ValueError("prev %s must have the up-sampled shape %s" % (tuple(prev.shape), out_shape))
+        out = small.new_empty(out_shape)
+        with torch.cuda.device(small.device):
+            _call("fs_upsample3d_scale_add", small.data_ptr(), _ptr(prev), out.data_ptr(), B, C, Di, Hi, Wi,
+                  int(factor), float(scale), _stream(small),
+                  algo_bytes=4 * (small.numel() + out.numel() * (2 if prev is not None else 1)))
+        ctx.cfg = (tuple(small.shape), int(factor), float(scale), prev is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        shape, factor, scale, has_prev = ctx.cfg
+        gout = _need_cuda_f32("grad_output", gout, 5)
+        gs = None
+        if ctx.needs_input_grad[0]:
+            gs = gout.new_empty(shape)
+            B, C, Di, Hi, Wi = shape
+            Do, Ho, Wo = gout.shape[2:]
+            ws = gout.new_empty(B * C * (Do * Ho * Wi + Do * Hi * Wi))
+            with torch.cuda.device(gout.device):
+                _call("fs_interp3d_bwd", gout.data_ptr(), gs.data_ptr(), ws.data_ptr(), B, C, Di, Hi, Wi, Do, Ho,
+                      Wo, factor, 1, _stream(gout), algo_bytes=4 * (gout.numel() + gs.numel()))
+            if scale != 1.0:
+                gs.mul_(scale)
+        gp = gout if (has_prev and ctx.needs_input_grad[1]) else None
+        return gs, gp, None, None
+
+
+def upsample3d_scale_add(small, prev, factor, scale=1.0):
+    """prev + scale * F.interpolate(small, scale_factor=factor, trilinear, align_corners=False) in one pass
+    (IFBlock's flow / mask accumulation); prev may be None."""
+    return _UpsampleScaleAdd.apply(small, prev, int(factor), float(scale))
+
+
 def interpolate3d(x, scale_factor):
     """F.interpolate(x, scale_factor, mode="trilinear", align_corners=False) for the IFBlock factors
     (4, 2, 1/2, 1/4): ATen forward, HIP gather backward.  Other factors: stock autograd."""
@@ -927,10 +970,11 @@ def conv3d_tr_supported(cout, k, stride, padding):
     return (tuple(k) == (4, 4, 4) and tuple(stride) == (2, 2, 2) and tuple(padding) == (1, 1, 1) and cout <= 32)
 
 
-def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None):
+def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
     """fs_conv3d_tr: ConvTranspose3d(4, 2, 1)(x) with weight w [Cin,Cout,4,4,4]; with out_dhw = the
     input extent of a Conv3d(4, 2, 1) layer and w = that layer's weight, its input gradient.
-    With `prelu_weight`: returns (y, prelu(y)), both written by the epilogue."""
+    With `prelu_weight`: returns (y, prelu(y)), both written by the epilogue.  With `addend` (y's shape):
+    y = conv_transpose(x) + bias + addend."""
     x = _need_cuda_f32("x", x, 5)
     w = _need_cuda_f32("w", w, 5)
     B, Cin = x.shape[:2]
@@ -950,6 +994,16 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None):
     ws = x.new_empty(max(nws, 1))
     nb, fl = 4 * (x.numel() + y.numel()), 2 * x.numel() * Cout * 64
     with torch.cuda.device(x.device):
+        if addend is not None:
+            if prelu_weight is not None:
+                raise ValueError("addend and prelu_weight are mutually exclusive")
+            addend = _need_cuda_f32("addend", addend, 5)
+            if addend.shape != y.shape:
+                raise ValueError("addend %s must have the output shape %s" % (tuple(addend.shape), tuple(y.shape)))
+            _call("fs_conv3d_tr_add", x.data_ptr(), w.data_ptr(), _ptr(bias), addend.data_ptr(), y.data_ptr(),
+                  ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb + 4 * y.numel(),
+                  algo_flops=fl, record_as="fs_conv3d_tr")
+            return y
         if prelu_weight is None:
             _call("fs_conv3d_tr", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
                   Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb, algo_flops=fl)

@@ -424,3 +424,69 @@ def test_corr2d_normalized_golden_and_oracle(ops, golden):
     assert relerr(got, want.cpu()) < 2e-5
     with pytest.raises(ValueError):
         ops.corr2d_normalized(torch.rand(1, 2, 1, 1, device=DEV), torch.rand(1, 2, 1, 1, device=DEV))
+
+
+@pytest.mark.parametrize("shape,factor,with_prev", [((2, 6, 5, 7, 9), 2, True), ((1, 1, 4, 6, 8), 4, True),
+                                                    ((1, 6, 3, 5, 4), 4, False)])
+def test_upsample3d_scale_add_vs_aten(ops, shape, factor, with_prev):
+    """prev + s * interpolate(small, s) in one pass == the reference's three ops (IFNet.py:118-119, 213-214)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sum(shape) + factor)
+    small = torch.randn(shape, generator=g).to(DEV).requires_grad_()
+    out_shape = shape[:2] + tuple(factor * n for n in shape[2:])
+    prev = torch.randn(out_shape, generator=g).to(DEV).requires_grad_() if with_prev else None
+    sc = float(factor)
+    ref = F.interpolate(small, scale_factor=factor, mode="trilinear", align_corners=False,
+                        recompute_scale_factor=False) * sc
+    if with_prev:
+        ref = prev + ref
+    got = ops.upsample3d_scale_add(small, prev, factor, sc)
+    assert float((got - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+    G = torch.randn(out_shape, generator=g).to(DEV)
+    ins = [small] + ([prev] if with_prev else [])
+    gr = torch.autograd.grad((ref * G).sum(), ins, retain_graph=True)
+    gg = torch.autograd.grad((got * G).sum(), ins)
+    for a, b in zip(gg, gr):
+        assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_conv3d_tr_addend_and_block_accumulate(ops):
+    """fs_conv3d_tr_add, and IFBlock(accumulate=True) == base + the reference-style deltas."""
+    import torch.nn.functional as F
+    from opticalflowscivis_amd import convgrad
+    from opticalflowscivis_amd.ifnet import IFBlock
+    g = torch.Generator().manual_seed(77)
+    for cout in (6, 1, 20):
+        m = convgrad.ConvTranspose3d(8, cout, 4, 2, 1).to(DEV)
+        x = torch.randn(2, 8, 3, 5, 17, generator=g).to(DEV).requires_grad_()
+        add = torch.randn(2, cout, 6, 10, 34, generator=g).to(DEV).requires_grad_()
+        ref = F.conv_transpose3d(x, m.weight, m.bias, 2, 1) + add
+        got = m(x, add)
+        assert float((got - ref).abs().max()) < 1e-5
+        G = torch.randn(ref.shape, generator=g).to(DEV)
+        gr = torch.autograd.grad((ref * G).sum(), [x, add, m.weight, m.bias], retain_graph=True)
+        gg = torch.autograd.grad((got * G).sum(), [x, add, m.weight, m.bias])
+        for a, b in zip(gg, gr):
+            assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max()))
+    torch.manual_seed(5)
+    for scale in (1, 2, 4):
+        blk = IFBlock(3, 5 + 6, c=16).to(DEV)
+        S = 16 * scale
+        x = torch.randn(1, 5, S, S, S, generator=g).to(DEV)
+        flow = torch.randn(1, 6, S, S, S, generator=g).to(DEV).requires_grad_()
+        mask = torch.randn(1, 1, S, S, S, generator=g).to(DEV).requires_grad_()
+        fd, md = blk(x, flow, scale)
+        fa, ma, summed = blk(x, flow, scale, flow, mask, accumulate=True)
+        assert summed
+        assert float((fa - (flow + fd)).abs().max()) < 2e-5 * max(1.0, float(fd.abs().max()))
+        assert float((ma - (mask + md)).abs().max()) < 2e-5 * max(1.0, float(md.abs().max()))
+        g1 = torch.autograd.grad((flow + fd).square().sum() + (mask + md).square().sum(), [flow, mask])
+        g2 = torch.autograd.grad(fa.square().sum() + ma.square().sum(), [flow, mask])
+        for a, b in zip(g2, g1):
+            assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
+        # extents that are not multiples of the block stride: falls back to the deltas
+        xo = torch.randn(1, 5, S + 4, S, S, generator=g).to(DEV)
+        fo = torch.randn(1, 6, S + 4, S, S, generator=g).to(DEV)
+        mo = torch.randn(1, 1, S + 4, S, S, generator=g).to(DEV)
+        out = blk(xo, fo, scale, fo, mo, accumulate=True)
+        assert out[2] == (tuple(out[0].shape[2:]) == tuple(fo.shape[2:]))
