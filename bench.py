@@ -62,8 +62,8 @@ def pmc_traffic(kernel, S, B):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=256, help="volume edge (BASELINE: 256)")
     ap.add_argument("--batch", type=int, default=2, help="volume pairs per GPU (BASELINE: 2)")
     ap.add_argument("--dataset", default="droplet3d", choices=["droplet3d", "jets3d"])
