@@ -327,9 +327,15 @@ int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, f
 /* fs_conv3d_fwd_prelu / fs_conv3d_tr_prelu: the same convolutions with the PReLU that follows every one of
  * them in IFNet (`conv()` / `deconv()`, Flow-3D/model/IFNet.py:13-29) applied in the epilogue:
  * y = conv(x) + bias (kept: the PReLU backward needs it) and z = y > 0 ? y : prelu_weight[c] * y are written
- * in the same pass (num_prelu_weights = 1 or Cout).  fwd_prelu is wmode 0 only. */
+ * in the same pass (num_prelu_weights = 1 or Cout).  fwd_prelu is wmode 0 only; its `residual` (may be
+ * NULL, z's shape) is added to z: the `convblock(x) + x` of IFBlock.forward (Flow-3D/model/IFNet.py:101-104).
+ * fs_conv3d_fwd_add: y = conv(x) + bias + addend (y's shape) -- with wmode 1 the input gradient of such a
+ * residual unit, whose skip branch contributes grad_out itself. */
+int fs_conv3d_fwd_add(const float* x, const float* w, const float* bias, const float* addend, float* y,
+                      float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                      int kernel, int stride, int pad, int wmode, fs_stream_t stream);
 int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
-                        float* y, float* z, float* ws,
+                        const float* residual, float* y, float* z, float* ws,
                         int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                         int kernel, int stride, int pad, int num_prelu_weights, fs_stream_t stream);
 int fs_conv3d_tr_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,

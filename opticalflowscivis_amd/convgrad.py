@@ -267,6 +267,58 @@ class ConvPReLU(nn.Sequential):
         return act(conv(x))
 
 
+class _ResUnitFn(torch.autograd.Function):
+    """out = PReLU(conv2(PReLU(conv1(x)))) + x  -- one `convblockN(x) + x` line of IFBlock.forward
+    (Flow-3D/model/IFNet.py:101-104) -- as ONE autograd node on the HIP kernels: the skip addition
+    happens in conv2's epilogue, and in the backward pass the skip branch's gradient (grad_out itself)
+    is added in the epilogue of conv1's input-gradient convolution.  Stride-1 "same" k = 3 layers only."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, a1, w2, b2, a2):
+        from . import ops
+        k, p = w1.shape[2], (w1.shape[2] - 1) // 2
+        y1, z1 = ops.conv3d_fwd(x, w1, b1, k, 1, p, 0, a1)
+        y2, out = ops.conv3d_fwd(z1, w2, b2, k, 1, p, 0, a2, x)
+        ctx.save_for_backward(x, w1, a1, y1, z1, w2, a2, y2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+        x, w1, a1, y1, z1, w2, a2, y2 = ctx.saved_tensors
+        k, p = w1.shape[2], (w1.shape[2] - 1) // 2
+        s3, p3 = (1, 1, 1), (p, p, p)
+        gout = gout.contiguous()
+        gy2, ga2, gb2 = ops.prelu_backward(y2, gout, a2, want_bias_grad=ctx.has_bias[1])
+        gw2 = _conv_grad_weight(z1, w2, gy2, s3, p3, False) if ctx.needs_input_grad[4] else None
+        gz1 = ops.conv3d_fwd(gy2, w2, None, k, 1, p, 1)
+        gy1, ga1, gb1 = ops.prelu_backward(y1, gz1, a1, want_bias_grad=ctx.has_bias[0])
+        gw1 = _conv_grad_weight(x, w1, gy1, s3, p3, False) if ctx.needs_input_grad[1] else None
+        gx = ops.conv3d_fwd(gy1, w1, None, k, 1, p, 1, None, gout) if ctx.needs_input_grad[0] else None
+        return gx, gw1, gb1, ga1, gw2, gb2, ga2
+
+
+def res_unit(block, x):
+    """`block(x) + x` for block = Sequential(ConvPReLU, ConvPReLU) of stride-1 k=3 "same" Conv3d layers;
+    the fused node when the HIP path applies, else the plain expression."""
+    ok = (_use_gemm(x) and x.dim() == 5 and x.dtype == torch.float32 and len(block) == 2 and
+          all(isinstance(m, ConvPReLU) and isinstance(m[0], Conv3d) and isinstance(m[1], nn.PReLU) for m in block))
+    if ok:
+        for m in block:
+            c = m[0]
+            kk = tuple(c.weight.shape[2:])
+            ok = ok and (kk == (3, 3, 3) and _tuple(c.stride, 3) == (1, 1, 1) and _tuple(c.padding, 3) == (1, 1, 1)
+                         and c.groups == 1 and _tuple(c.dilation, 3) == (1, 1, 1) and c.padding_mode == "zeros"
+                         and c.in_channels == c.out_channels == x.shape[1]
+                         and m[1].weight.numel() in (1, c.out_channels)
+                         and _hip_fwd_ok(x, c.out_channels, x.shape[2:], kk, (1, 1, 1), (1, 1, 1)))
+    if not ok:
+        return block(x) + x
+    (c1, p1), (c2, p2) = block[0], block[1]
+    return _ResUnitFn.apply(x, c1.weight, c1.bias, p1.weight, c2.weight, c2.bias, p2.weight)
+
+
 def _use_gemm(x):
     return _MODE in ("gemm", "mfma") and x.is_cuda and torch.is_grad_enabled()
 

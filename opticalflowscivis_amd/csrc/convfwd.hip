@@ -39,6 +39,10 @@ struct FP {
   const float* slope;
   float* Z;
   int nslope;  // 1 (shared) or Cout
+  // optional tensor of the output's shape added in the epilogue: to Z after the PReLU when Z is
+  // written (the residual of an IFBlock unit, `convblock(x) + x`), else to Y (the residual branch of
+  // that unit's input gradient)
+  const float* addend;
 };
 
 // Wt[ci][tap][co] (ci < CinP, co < CoutP; zero outside the real channels)
@@ -217,10 +221,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
           if (co < p.Cout) {
-            const float v = acc[m][n][r] + (bias ? bias[co] : 0.f);
-            yb[(size_t)co * yvol] = v;
-            if (p.Z != nullptr)
-              p.Z[(yb - Y) + (size_t)co * yvol] = v > 0.f ? v : p.slope[p.nslope == 1 ? 0 : co] * v;
+            float v = acc[m][n][r] + (bias ? bias[co] : 0.f);
+            const size_t o = (yb - Y) + (size_t)co * yvol;
+            if (p.Z != nullptr) {
+              Y[o] = v;
+              float zv = v > 0.f ? v : p.slope[p.nslope == 1 ? 0 : co] * v;
+              if (p.addend != nullptr) zv += p.addend[o];
+              p.Z[o] = zv;
+            } else {
+              if (p.addend != nullptr) v += p.addend[o];
+              Y[o] = v;
+            }
           }
         }
     }
@@ -257,7 +268,7 @@ extern "C" long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel) {
 }
 
 static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
-                           float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
+                           const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
                            int Ho, int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y); FS_REQUIRE_PTR(ws);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
@@ -276,7 +287,7 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   FP p;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Do; p.Ho = Ho; p.Wo = Wo;
   p.pad = pad;
-  p.slope = slope; p.Z = z; p.nslope = nslope;
+  p.slope = slope; p.Z = z; p.nslope = nslope; p.addend = addend;
   int cinp;
   wt_dims(Cin, Cout, kernel, &cinp, &p.CoutP);
   hipStream_t st = (hipStream_t)stream;
@@ -310,16 +321,25 @@ extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, 
                              int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kernel,
                              int stride, int pad, int wmode, fs_stream_t stream) {
   FS_ENTER();
-  return conv3d_fwd_impl(x, w, bias, nullptr, 0, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, kernel,
-                         stride, pad, wmode, stream);
+  return conv3d_fwd_impl(x, w, bias, nullptr, 0, nullptr, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
+                         kernel, stride, pad, wmode, stream);
+}
+
+extern "C" int fs_conv3d_fwd_add(const float* x, const float* w, const float* bias, const float* addend, float* y,
+                                 float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho,
+                                 int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(addend);
+  return conv3d_fwd_impl(x, w, bias, nullptr, 0, addend, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
+                         kernel, stride, pad, wmode, stream);
 }
 
 extern "C" int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
-                                   float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi,
-                                   int Wi, int Do, int Ho, int Wo, int kernel, int stride, int pad,
+                                   const float* residual, float* y, float* z, float* ws, int B, int Cin, int Cout,
+                                   int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kernel, int stride, int pad,
                                    int num_prelu_weights, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
-  return conv3d_fwd_impl(x, w, bias, prelu_weight, num_prelu_weights, y, z, ws, B, Cin, Cout, Di, Hi, Wi, Do,
-                         Ho, Wo, kernel, stride, pad, 0, stream);
+  return conv3d_fwd_impl(x, w, bias, prelu_weight, num_prelu_weights, residual, y, z, ws, B, Cin, Cout, Di, Hi, Wi,
+                         Do, Ho, Wo, kernel, stride, pad, 0, stream);
 }

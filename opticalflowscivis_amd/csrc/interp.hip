@@ -196,6 +196,55 @@ __global__ __launch_bounds__(256) void upsample3d_scale_add_kernel(const float* 
   }
 }
 
+// Four consecutive x per thread (Wo % 4 == 0, 16-byte aligned rows): the z / y weights and the row
+// pointers are shared, prev / out move as float4 -- the scalar form is bound by its index arithmetic.
+__global__ __launch_bounds__(256) void upsample3d_scale_add_v4_kernel(const float* __restrict__ small,
+                                                                      const float4* __restrict__ prev,
+                                                                      float4* __restrict__ out, IP p, float scale) {
+#pragma clang fp contract(off)
+  const int W4 = p.Wo >> 2;
+  const long long rows = p.nBC * p.Do * p.Ho;
+  const long long total = rows * W4;
+  const long long nin = (long long)p.Di * p.Hi * p.Wi;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long row = e / W4;
+    const int x4 = (int)(e - row * W4);
+    const int y = (int)(row % p.Ho);
+    const long long t = row / p.Ho;
+    const int z = (int)(t % p.Do);
+    const long long bc = t / p.Do;
+    float sz = p.rs * ((float)z + 0.5f) - 0.5f, sy = p.rs * ((float)y + 0.5f) - 0.5f;
+    sz = sz < 0.f ? 0.f : sz; sy = sy < 0.f ? 0.f : sy;
+    const int z0 = (int)sz, y0 = (int)sy;
+    const int zp = (z0 < p.Di - 1) ? 1 : 0, yp = (y0 < p.Hi - 1) ? 1 : 0;
+    const float lz1 = sz - (float)z0, ly1 = sy - (float)y0;
+    const float lz0 = 1.f - lz1, ly0 = 1.f - ly1;
+    const float* s00 = small + bc * nin + ((long long)z0 * p.Hi + y0) * p.Wi;
+    const float* s01 = s00 + yp * p.Wi;
+    const float* s10 = s00 + (long long)zp * p.Hi * p.Wi;
+    const float* s11 = s10 + yp * p.Wi;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = 4 * x4 + i;
+      float sx = p.rs * ((float)x + 0.5f) - 0.5f;
+      sx = sx < 0.f ? 0.f : sx;
+      const int x0 = (int)sx;
+      const int xp = (x0 < p.Wi - 1) ? 1 : 0;
+      const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+      const float v = lz0 * (ly0 * (lx0 * s00[x0] + lx1 * s00[x0 + xp]) + ly1 * (lx0 * s01[x0] + lx1 * s01[x0 + xp])) +
+                      lz1 * (ly0 * (lx0 * s10[x0] + lx1 * s10[x0 + xp]) + ly1 * (lx0 * s11[x0] + lx1 * s11[x0 + xp]));
+      o[i] = v * scale;
+    }
+    float4 r = make_float4(o[0], o[1], o[2], o[3]);
+    if (prev) {
+      const float4 q = prev[e];
+      r.x = q.x + r.x; r.y = q.y + r.y; r.z = q.z + r.z; r.w = q.w + r.w;
+    }
+    out[e] = r;
+  }
+}
+
 unsigned grid_for(long long total) {
   const long long want = (total + 255) / 256;
   return (unsigned)(want < (1 << 20) ? want : (1 << 20));
@@ -281,8 +330,12 @@ extern "C" int fs_upsample3d_scale_add(const float* small, const float* prev, fl
   p.up = 1; p.s = factor; p.rs = 1.0f / (float)factor;
   p.nBC = (long long)B * C;
   const long long total = p.nBC * p.Do * p.Ho * p.Wo;
-  hipLaunchKernelGGL(upsample3d_scale_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, small,
-                     prev, out, p, scale);
+  if ((p.Wo & 3) == 0 && (((uintptr_t)out | (uintptr_t)prev) & 15) == 0)
+    hipLaunchKernelGGL(upsample3d_scale_add_v4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                       small, (const float4*)prev, (float4*)out, p, scale);
+  else
+    hipLaunchKernelGGL(upsample3d_scale_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, small,
+                       prev, out, p, scale);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

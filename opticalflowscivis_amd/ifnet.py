@@ -96,10 +96,11 @@ class IFBlock(nn.Module):
                 flow = _resize(flow, 1. / scale, mode) * 1. / scale
             x = torch.cat((x, flow), 1)
         x = self.conv0(x)
-        x = self.convblock0(x) + x
-        x = self.convblock1(x) + x
-        x = self.convblock2(x) + x
-        x = self.convblock3(x) + x
+        res = convgrad.res_unit if self.nd == 3 else (lambda blk, t: blk(t) + t)
+        x = res(self.convblock0, x)
+        x = res(self.convblock1, x)
+        x = res(self.convblock2, x)
+        x = res(self.convblock3, x)
         if accumulate and self.nd == 3 and x.is_cuda and x.dtype == torch.float32 and scale in (1, 2, 4):
             full = tuple(4 * scale * n for n in x.shape[2:])  # two stride-2 deconvs, then x scale
             if all(b is None or tuple(b.shape[2:]) == full for b in (flow_base, mask_base)):

@@ -927,10 +927,11 @@ def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
     return B * Do * cd(Ho, 8 * r) * cd(Wo, tw) * mg
 
 
-def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None):
+def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=None):
     """fs_conv3d_fwd: y = conv3d(x, W, bias, stride, pad) with W = w (wmode 0, [Cout,Cin,k,k,k]) or the
     flipped transpose of w (wmode 1, w [Cin,Cout,k,k,k]: input gradient of a stride-1 same conv).
-    With `prelu_weight` (wmode 0): returns (y, prelu(y)), both written by the convolution's epilogue."""
+    With `prelu_weight` (wmode 0): returns (y, prelu(y) [+ addend]), both written by the convolution's
+    epilogue.  `addend` without `prelu_weight`: y = conv + bias + addend."""
     x = _need_cuda_f32("x", x, 5)
     w = _need_cuda_f32("w", w, 5)
     B, Cin = x.shape[:2]
@@ -948,7 +949,17 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None):
     y = x.new_empty((B, Cout, Do, Ho, Wo))
     ws = x.new_empty(int(_lib.lib().fs_conv3d_fwd_ws_floats(Cin, Cout, int(k))))
     nb, fl = 4 * (x.numel() + y.numel()), 2 * y.numel() * Cin * int(k) ** 3
+    if addend is not None:
+        addend = _need_cuda_f32("addend", addend, 5)
+        if addend.shape != y.shape:
+            raise ValueError("addend %s must have the output shape %s" % (tuple(addend.shape), tuple(y.shape)))
+        nb += 4 * y.numel()
     with torch.cuda.device(x.device):
+        if prelu_weight is None and addend is not None:
+            _call("fs_conv3d_fwd_add", x.data_ptr(), w.data_ptr(), _ptr(bias), addend.data_ptr(), y.data_ptr(),
+                  ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode),
+                  _stream(x), algo_bytes=nb, algo_flops=fl, record_as="fs_conv3d_fwd")
+            return y
         if prelu_weight is None:
             _call("fs_conv3d_fwd", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
                   Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode), _stream(x),
@@ -960,8 +971,9 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None):
         if a.numel() not in (1, Cout):
             raise ValueError("prelu_weight must have 1 or %d elements" % Cout)
         z = torch.empty_like(y)
-        _call("fs_conv3d_fwd_prelu", x.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), y.data_ptr(),
-              z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad),
+        _call("fs_conv3d_fwd_prelu", x.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), _ptr(addend),
+              y.data_ptr(), z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride),
+              int(pad),
               a.numel(), _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_fwd")
     return y, z
 

@@ -490,3 +490,36 @@ def test_conv3d_tr_addend_and_block_accumulate(ops):
         mo = torch.randn(1, 1, S + 4, S, S, generator=g).to(DEV)
         out = blk(xo, fo, scale, fo, mo, accumulate=True)
         assert out[2] == (tuple(out[0].shape[2:]) == tuple(fo.shape[2:]))
+
+
+def test_res_unit_fused_node_vs_fp64(ops):
+    """convgrad.res_unit: PReLU(conv(PReLU(conv(x)))) + x as one autograd node vs an fp64 CPU graph."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from opticalflowscivis_amd import convgrad
+    g = torch.Generator().manual_seed(123)
+    C = 12
+    blk = nn.Sequential(convgrad.ConvPReLU(convgrad.Conv3d(C, C, 3, 1, 1), convgrad.PReLU(C)),
+                        convgrad.ConvPReLU(convgrad.Conv3d(C, C, 3, 1, 1), convgrad.PReLU(C)))
+    with torch.no_grad():
+        for m in blk:
+            m[1].weight.copy_(torch.rand(C, generator=g) - 0.3)
+    x = torch.randn(2, C, 5, 9, 21, generator=g)
+    params = [blk[0][0].weight, blk[0][0].bias, blk[0][1].weight, blk[1][0].weight, blk[1][0].bias, blk[1][1].weight]
+    ref = [t.detach().double().requires_grad_() for t in [x] + params]
+    h = F.prelu(F.conv3d(ref[0], ref[1], ref[2], 1, 1), ref[3])
+    outr = F.prelu(F.conv3d(h, ref[4], ref[5], 1, 1), ref[6]) + ref[0]
+    G = torch.randn(outr.shape, generator=g)
+    gref = torch.autograd.grad((outr * G.double()).sum(), ref)
+    blk = blk.to(DEV)
+    params = [blk[0][0].weight, blk[0][0].bias, blk[0][1].weight, blk[1][0].weight, blk[1][0].bias, blk[1][1].weight]
+    xd = x.to(DEV).requires_grad_()
+    out = convgrad.res_unit(blk, xd)
+    assert out.grad_fn.__class__.__name__.startswith("_ResUnitFn")
+    got = torch.autograd.grad((out * G.to(DEV)).sum(), [xd] + params)
+    assert float((out.detach().cpu().double() - outr.detach()).abs().max()) < 3e-5 * float(outr.abs().max())
+    for a, b in zip(got, gref):
+        assert a.shape == b.shape
+        assert float((a.detach().cpu().double() - b).abs().max()) < 6e-5 * float(b.abs().max())
+    with torch.no_grad():  # inference: the unfused expression on the same modules
+        assert float((convgrad.res_unit(blk, xd) - out).abs().max()) < 1e-5
