@@ -206,34 +206,53 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   }
 
   // ---- epilogue: row (channel) = (r&3) + 8*(r>>2) + 4*kh, column (voxel) = lane & 31
+  // (restrict-qualified local copies: without them every addend load has to wait for the previous
+  // store -- the outputs might alias it -- and the epilogue becomes a chain of memory round trips)
+  const float* __restrict__ ad = p.addend;
+  const float* __restrict__ slope = p.slope;
+  float* __restrict__ Zp = p.Z;
+  float* __restrict__ Yp = Y;
   const int oz = oz0 + wz;
   const int ox = ox0 + lx;
   if (oz < p.Do && ox < p.Wo) {
     const size_t yvol = (size_t)p.Do * p.Ho * p.Wo;
+    float bv[MT][16], sv[MT][16];  // this lane's 16*MT channels: bias and PReLU slope, loaded once
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        bv[m][r] = (bias != nullptr && co < p.Cout) ? bias[co] : 0.f;
+        sv[m][r] = (Zp != nullptr && co < p.Cout) ? slope[p.nslope == 1 ? 0 : co] : 0.f;
+      }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int oy = oy0 + (wy + n) * R + ly;
       if (oy >= p.Ho) continue;
-      float* yb = Y + (size_t)b * p.Cout * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + ox;
+      const size_t o0 = (size_t)b * p.Cout * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + ox;
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m) {
+        float av[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // all loads of the tile first
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          av[r] = (ad != nullptr && co < p.Cout) ? ad[o0 + (size_t)co * yvol] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
           if (co < p.Cout) {
-            float v = acc[m][n][r] + (bias ? bias[co] : 0.f);
-            const size_t o = (yb - Y) + (size_t)co * yvol;
-            if (p.Z != nullptr) {
-              Y[o] = v;
-              float zv = v > 0.f ? v : p.slope[p.nslope == 1 ? 0 : co] * v;
-              if (p.addend != nullptr) zv += p.addend[o];
-              p.Z[o] = zv;
+            const float v = acc[m][n][r] + bv[m][r];
+            const size_t o = o0 + (size_t)co * yvol;
+            if (Zp != nullptr) {
+              Yp[o] = v;
+              Zp[o] = (v > 0.f ? v : sv[m][r] * v) + av[r];
             } else {
-              if (p.addend != nullptr) v += p.addend[o];
-              Y[o] = v;
+              Yp[o] = v + av[r];
             }
           }
         }
+      }
     }
   }
 }
