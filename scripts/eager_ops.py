@@ -1,0 +1,21 @@
+"""Which eager ATen ops remain in one Flow-3D train step, and who calls them (torch profiler, GPU box only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from opticalflowscivis_amd.flow3d.model.RIFE import Model
+from opticalflowscivis_amd.data import synthetic
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+torch.manual_seed(1234)
+m = Model(local_rank=-1, device="cuda:0")
+data = synthetic.droplet3d_batch(2, S, seed=1234).cuda()
+imgs, gt = data[:, :2], data[:, 2:3]
+for _ in range(2):
+    m.update(imgs, gt, learning_rate=1e-4, training=True)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    m.update(imgs, gt, learning_rate=1e-4, training=True)
+    torch.cuda.synchronize()
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=40,
+                                                          max_shapes_column_width=60))

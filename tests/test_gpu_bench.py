@@ -1,0 +1,34 @@
+"""-m gpu: the bench.py contract on a tiny workload -- ONE JSON line on stdout with the required keys."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def test_bench_json_contract():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "32", "--batch", "1", "--steps", "2",
+           "--warmup", "1", "--cpu-size", "16"]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # exactly one line on stdout (RCCL / MIOpen chatter must not leak)
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] - 1 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"] + 1e-9
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] in ("hbm", "mfma")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] in ("port", "reference")
+    assert cb["value"] > 0 and cb["cores"] >= 1
