@@ -89,6 +89,13 @@ class IFBlock(nn.Module):
         the producing kernels (3-D, GPU, delta and base of equal extent; a base may be None = zero), else
         (flow_delta, mask_delta, False)."""
         mode = _INTERP[self.nd]
+        if isinstance(x, (tuple, list)):
+            # the caller's pieces (img0, img1, warped, mask, ...): at scale 1 they are concatenated with
+            # the flow in ONE pass instead of cat(cat(pieces), flow)
+            if scale == 1 and flow is not None:
+                x, flow = torch.cat(tuple(x) + (flow,), 1), None
+            else:
+                x = torch.cat(tuple(x), 1)
         if scale != 1:
             x = _resize(x, 1. / scale, mode)
         if flow is not None:
@@ -151,7 +158,7 @@ class IFNet(nn.Module):
                 img0, img1 = _crop(img0, sp), _crop(img1, sp)
                 warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
                 mask, flow = _crop(mask, sp), _crop(flow, sp)
-                flow_d, mask_d, summed = stu[i](torch.cat((img0, img1, warped_img0, warped_img1, mask), 1),
+                flow_d, mask_d, summed = stu[i]((img0, img1, warped_img0, warped_img1, mask),
                                                 flow, scale[i], flow, mask, accumulate=True)
                 if summed:  # flow + flow_d, mask + mask_d formed inside the producing kernels
                     flow, mask = flow_d, mask_d
@@ -178,8 +185,7 @@ class IFNet(nn.Module):
             warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
             mask, flow, gt = _crop(mask, sp), _crop(flow, sp), _crop(gt, sp)
             flow_d, mask_d, summed = self.block_tea(
-                torch.cat((img0, img1, warped_img0, warped_img1, mask, gt), 1), flow, 1, flow, mask,
-                accumulate=True)
+                (img0, img1, warped_img0, warped_img1, mask, gt), flow, 1, flow, mask, accumulate=True)
             if summed:
                 flow_teacher, mask_teacher = flow_d, mask_d
             else:
