@@ -19,3 +19,12 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=40,
                                                           max_shapes_column_width=60))
+print("==== by stack: copy_/contiguous/add_/mul/cat ====")
+for e in sorted(prof.key_averages(group_by_stack_n=12), key=lambda e: -e.device_time_total):
+    if e.key in ("aten::copy_", "aten::add_", "aten::mul", "aten::cat", "aten::add", "aten::mul_", "aten::fill_", "aten::zero_", "aten::sum") and e.device_time_total > 100:
+        st = [f for f in e.stack if "opticalflowscivis_amd" in f or "bench" in f][:4]
+        print("%-12s n=%3d  %8.3f ms  %s" % (e.key, e.count, e.device_time_total / 1e3, " <- ".join(x.split("/")[-1] for x in st)))
+print("==== all aten ops by device time ====")
+for e in sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)[:40]:
+    if e.self_device_time_total > 50:
+        print("%-60s n=%4d  self %8.3f ms" % (e.key[:60], e.count, e.self_device_time_total / 1e3))
