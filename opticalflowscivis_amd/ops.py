@@ -117,8 +117,20 @@ class _Warp3D(torch.autograd.Function):
         return gin, gflow
 
 
+def _empty_like_graph(shape, *tensors):
+    """Empty-batch result: zeros of `shape` (numel 0) that still hang on the inputs' autograd graph, as
+    `F.grid_sample` / `Corr_pyTorch` return for B = 0.  No kernel is launched for an empty batch."""
+    out = tensors[0].new_zeros(shape)
+    for t in tensors:
+        if t is not None and t.requires_grad:
+            out = out + 0 * t.sum()
+    return out
+
+
 def warp3d(tenInput, tenFlow):
     """Trilinear backward warp with the reference's axis-rotating grid (Flow-3D warplayer.warp)."""
+    if tenInput.dim() == 5 and tenFlow.dim() == 5 and tenInput.shape[0] == 0 and tenFlow.shape[0] == 0:
+        return _empty_like_graph((0, tenInput.shape[1]) + tuple(tenFlow.shape[2:]), tenInput, tenFlow)
     return _Warp3D.apply(tenInput, tenFlow)
 
 
@@ -167,13 +179,21 @@ class _Warp2D(torch.autograd.Function):
         return gin, gflow, None, None, None
 
 
+def _empty2d(x, flow):
+    return x.dim() == 4 and flow.dim() == 4 and x.shape[0] == 0 and flow.shape[0] == 0
+
+
 def warp2d(tenInput, tenFlow):
     """a1: Flow-2D/model/warplayer.py:7-26 (border pad, align_corners=True)."""
+    if _empty2d(tenInput, tenFlow):
+        return _empty_like_graph(tenInput.shape, tenInput, tenFlow)
     return _Warp2D.apply(tenInput, tenFlow, None, WARP2D_RIFE, 0)
 
 
 def warp2d_pwc(x, flow, with_mask):
     """a5/a6: pwc_modules.WarpingLayer_no_div (with_mask) / tools.torch_warp (no mask)."""
+    if _empty2d(x, flow):
+        return _empty_like_graph(x.shape, x, flow)
     return _Warp2D.apply(x, flow, None, WARP2D_PWC, 1 if with_mask else 0)
 
 
@@ -277,6 +297,9 @@ class _WarpPair(torch.autograd.Function):
 
 def warp_pair(img0, img1, flow):
     """(warp(img0, flow[:, :nd]), warp(img1, flow[:, nd:2nd])) in one launch; nd = 2 or 3."""
+    if img0.shape[0] == 0 and img1.shape[0] == 0 and flow.shape[0] == 0 and flow.dim() in (4, 5):
+        shape = (0, img0.shape[1]) + tuple(flow.shape[2:])
+        return _empty_like_graph(shape, img0, flow), _empty_like_graph(shape, img1, flow)
     return _WarpPair.apply(img0, img1, flow)
 
 
@@ -356,6 +379,9 @@ class _Corr2D(torch.autograd.Function):
 
 def corr2d(f1, f2, max_displacement=4):
     """Cost volume [B,(2md+1)^2,H,W] = channel-mean of f1 * shifted f2 (zero padded)."""
+    if f1.dim() == 4 and f2.dim() == 4 and f1.shape[0] == 0 and f2.shape[0] == 0:
+        nd = 2 * int(max_displacement) + 1
+        return _empty_like_graph((0, nd * nd) + tuple(f1.shape[2:]), f1, f2)
     return _Corr2D.apply(f1, f2, int(max_displacement))
 
 

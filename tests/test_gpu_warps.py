@@ -296,3 +296,26 @@ def test_occ_check_vs_oracle_c3_shape(ops):
     w = c.clone(); w[0, 0, 3, 3] = float("nan"); w[0, 1, 5, 5] = float("inf"); w[0, 0, 7, 7] = -1e30
     ops.occ_check2d(w.to(DEV), (-w).to(DEV), 0.1, 0.5, 1, "obj")
     torch.cuda.synchronize()
+
+
+def test_empty_batch_is_a_no_op(ops):
+    """B = 0 (a ragged last shard): empty outputs of the right shape, gradients flow (as empty tensors),
+    no kernel launch -- what F.grid_sample / Corr_pyTorch do for an empty batch."""
+    x3 = torch.zeros(0, 2, 4, 5, 6, device=DEV, requires_grad=True)
+    f3 = torch.zeros(0, 3, 4, 5, 6, device=DEV, requires_grad=True)
+    o = ops.warp3d(x3, f3)
+    assert tuple(o.shape) == (0, 2, 4, 5, 6)
+    o.sum().backward()
+    assert x3.grad.shape == x3.shape and f3.grad.shape == f3.shape
+    x2 = torch.zeros(0, 3, 8, 9, device=DEV, requires_grad=True)
+    f2 = torch.zeros(0, 2, 8, 9, device=DEV)
+    assert tuple(ops.warp2d(x2, f2).shape) == (0, 3, 8, 9)
+    assert tuple(ops.warp2d_pwc(x2, f2, True).shape) == (0, 3, 8, 9)
+    a, b = ops.warp_pair(torch.zeros(0, 1, 8, 9, device=DEV), torch.zeros(0, 1, 8, 9, device=DEV),
+                         torch.zeros(0, 4, 8, 9, device=DEV))
+    assert tuple(a.shape) == tuple(b.shape) == (0, 1, 8, 9)
+    c = ops.corr2d(torch.zeros(0, 5, 6, 7, device=DEV), torch.zeros(0, 5, 6, 7, device=DEV), 4)
+    assert tuple(c.shape) == (0, 81, 6, 7)
+    # mismatched batches are still an error, not silently empty
+    with pytest.raises(ValueError):
+        ops.warp3d(torch.zeros(0, 2, 4, 5, 6, device=DEV), torch.zeros(1, 3, 4, 5, 6, device=DEV))
