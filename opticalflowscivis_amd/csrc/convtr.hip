@@ -19,8 +19,8 @@
 //       the same on v_mfma_f32_16x16x4_f32 (16 channels x 16 positions, the 4 chunk channels per MFMA).
 //   convtr_valu_kernel<CO> (Cout <= 6: the flow / mask heads): padding 6 channels to a 16/32-row MFMA
 //       tile wastes most of the matrix core, and the fp32 vector ALUs have the same peak as the fp32
-//       matrix cores on this part.  One thread per q, 8*CO accumulators, weights are wave-uniform ->
-//       scalar loads feeding v_fmac's SGPR operand.
+//       matrix cores on this part.  One thread per two q (consecutive qy), 16*CO accumulators, weights
+//       are wave-uniform -> scalar loads feeding v_fmac's SGPR operand (each feeds two FMAs).
 #include "common.hpp"
 
 namespace {
@@ -354,45 +354,53 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma16_kernel(const float* __re
   }
 }
 
-template <int CO>
+// NP input-grid positions (consecutive qy) per thread: every scalar-loaded weight feeds NP FMAs.  The
+// kernel is bound by the scalar weight stream (64*CO dwords per input channel and wave through ~100
+// SGPRs), not by the vector ALUs or the address path -- packed FMAs / an LDS-staged input brick did not
+// move it, a second position per thread did.
+template <int CO, int NP>
 __global__ __launch_bounds__(256) void convtr_valu_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                           const float* __restrict__ bias, float* __restrict__ Y,
                                                           TP p) {
-  const long long nq = (long long)p.B * p.Dq * p.Hq * p.Wq;
+  const int Hq2 = (p.Hq + NP - 1) / NP;
+  const long long nq = (long long)p.B * p.Dq * Hq2 * p.Wq;
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= nq) return;
   const int qx = (int)(e % p.Wq);
   long long r = e / p.Wq;
-  const int qy = (int)(r % p.Hq); r /= p.Hq;
+  const int qy = (int)(r % Hq2) * NP; r /= Hq2;
   const int qz = (int)(r % p.Dq);
   const int b = (int)(r / p.Dq);
 
-  // offsets of the 3x3x3 neighbourhood inside one input channel; -1 = outside (reads as zero)
-  int off[27];
+  // offsets of the 3 x (NP+2) x 3 neighbourhood inside one input channel; -1 = outside (reads as zero)
+  constexpr int NY = NP + 2;
+  int off[3 * NY * 3];
 #pragma unroll
   for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int dy = 0; dy < NY; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int z = qz + dz - 1, y = qy + dy - 1, x = qx + dx - 1;
         const bool ok = z >= 0 && z < p.Di && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
-        off[(dz * 3 + dy) * 3 + dx] = ok ? (z * p.Hi + y) * p.Wi + x : -1;
+        off[(dz * NY + dy) * 3 + dx] = ok ? (z * p.Hi + y) * p.Wi + x : -1;
       }
 
-  float acc[CO][8];
+  float acc[NP][CO][8];
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
     const float bv = (bias && co < p.Cout) ? bias[co] : 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[co][c] = bv;
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[q][co][c] = bv;
   }
   const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
   const float* xc = X + (size_t)b * p.Cin * xvol;
   for (int ci = 0; ci < p.Cin; ++ci, xc += xvol) {
-    float xn[27];
+    float xn[3 * NY * 3];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) xn[i] = off[i] >= 0 ? xc[off[i]] : 0.f;
+    for (int i = 0; i < 3 * NY * 3; ++i) xn[i] = off[i] >= 0 ? xc[off[i]] : 0.f;
     const float* wc = W + (size_t)ci * p.Cout * 64;  // wave-uniform: scalar loads
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
@@ -404,8 +412,12 @@ __global__ __launch_bounds__(256) void convtr_valu_kernel(const float* __restric
           for (int tp = 0; tp < 8; ++tp) {
             const int a = tp >> 2, bb = (tp >> 1) & 1, c = tp & 1;
             const int kidx = (tap_k(pz, a) * 4 + tap_k(py, bb)) * 4 + tap_k(px, c);
-            const int didx = ((tap_d(pz, a) + 1) * 3 + (tap_d(py, bb) + 1)) * 3 + (tap_d(px, c) + 1);
-            acc[co][cls] = fmaf(xn[didx], wc[co * 64 + kidx], acc[co][cls]);
+            const float wv = wc[co * 64 + kidx];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+              const int didx = ((tap_d(pz, a) + 1) * NY + (tap_d(py, bb) + 1 + q)) * 3 + (tap_d(px, c) + 1);
+              acc[q][co][cls] = fmaf(xn[didx], wv, acc[q][co][cls]);
+            }
           }
         }
       }
@@ -413,17 +425,20 @@ __global__ __launch_bounds__(256) void convtr_valu_kernel(const float* __restric
   }
   const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
 #pragma unroll
-  for (int co = 0; co < CO; ++co)
-    if (co < p.Cout)
-      store8(Y + ((size_t)b * p.Cout + co) * yvol, acc[co], qz, qy, qx, p,
-             p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
+  for (int q = 0; q < NP; ++q)
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+      if (co < p.Cout && qy + q < p.Hq)
+        store8(Y + ((size_t)b * p.Cout + co) * yvol, acc[q][co], qz, qy + q, qx, p,
+               p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
 }
 
 template <int CO>
 void launch_valu(const float* x, const float* w, const float* bias, float* y, const TP& p, hipStream_t st) {
-  const long long nq = (long long)p.B * p.Dq * p.Hq * p.Wq;
-  hipLaunchKernelGGL(convtr_valu_kernel<CO>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, x, w, bias, y,
-                     p);
+  constexpr int NP = 2;  // 4 was slower for the 1-channel mask head (0.64 vs 0.58 ms)
+  const long long nq = (long long)p.B * p.Dq * ((p.Hq + NP - 1) / NP) * p.Wq;
+  hipLaunchKernelGGL((convtr_valu_kernel<CO, NP>), dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, x, w, bias,
+                     y, p);
 }
 
 }  // namespace
