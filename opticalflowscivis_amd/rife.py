@@ -34,7 +34,10 @@ class ModelBase:
         self.optimG = AdamW(self.flownet.parameters(), lr=1e-6, weight_decay=1e-3)
         if local_rank != -1:
             if self.dev.type == "cuda":
-                self.flownet = DDP(self.flownet, device_ids=[local_rank], output_device=local_rank)
+                # gradients live inside the all-reduce buckets (no per-step grad -> bucket copies); the
+                # net has no buffers to broadcast
+                self.flownet = DDP(self.flownet, device_ids=[local_rank], output_device=local_rank,
+                                   gradient_as_bucket_view=True, broadcast_buffers=False)
             else:  # host-side tests of the sharding logic (gloo); the ops themselves need a GPU
                 self.flownet = DDP(self.flownet)
 
