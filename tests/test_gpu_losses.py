@@ -523,3 +523,40 @@ def test_res_unit_fused_node_vs_fp64(ops):
         assert float((a.detach().cpu().double() - b).abs().max()) < 6e-5 * float(b.abs().max())
     with torch.no_grad():  # inference: the unfused expression on the same modules
         assert float((convgrad.res_unit(blk, xd) - out).abs().max()) < 1e-5
+
+
+def test_conv_entry_points_reject_bad_arguments(ops):
+    """The C-ABI returns FS_ERR_* (never launches) for null pointers, unsupported kernels and shapes that do
+    not belong together; the Python wrappers raise ValueError before reaching it."""
+    import ctypes
+    from opticalflowscivis_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(1, 4, 8, 8, 8, device=DEV)
+    w = torch.zeros(4, 4, 3, 3, 3, device=DEV)
+    y = torch.zeros(1, 4, 8, 8, 8, device=DEV)
+    ws = torch.zeros(int(L.fs_conv3d_fwd_ws_floats(4, 4, 3)), device=DEV)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ok = L.fs_conv3d_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, 4, 4, 8, 8, 8, 8, 8, 8,
+                         3, 1, 1, 0, st)
+    assert ok == 0
+    FS_ERR_NULLPTR, FS_ERR_SHAPE, FS_ERR_ARG = 1, 2, 3
+    assert L.fs_conv3d_fwd(None, w.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, 4, 4, 8, 8, 8, 8, 8, 8, 3, 1, 1,
+                           0, st) == FS_ERR_NULLPTR
+    assert L.fs_conv3d_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, 4, 4, 8, 8, 8, 8, 8, 8,
+                           5, 1, 2, 0, st) == FS_ERR_ARG      # 5^3 kernels are not built
+    assert L.fs_conv3d_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, 4, 4, 8, 8, 8, 7, 8, 8,
+                           3, 1, 1, 0, st) == FS_ERR_SHAPE    # output grid is not the convolution's
+    assert L.fs_conv3d_tr(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, 4, 40, 8, 8, 8, 16, 16,
+                          16, st) == FS_ERR_ARG               # > 32 output channels
+    assert L.fs_conv3d_tr(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, 4, 4, 8, 8, 8, 15, 16, 16,
+                          st) == FS_ERR_SHAPE
+    assert L.fs_upsample3d_scale_add(x.data_ptr(), None, y.data_ptr(), 1, 4, 8, 8, 8, 3, 1.0, st) == FS_ERR_ARG
+    assert L.fs_conv3d_fwd_ws_floats(4, 4, 5) == -1 and L.fs_conv3d_tr_ws_floats(4, 33) == -1
+    assert _lib.lib().fs_error_string(FS_ERR_SHAPE)
+    with pytest.raises(ValueError):
+        ops.conv3d_fwd(x, torch.zeros(4, 5, 3, 3, 3, device=DEV), None, 3, 1, 1)
+    with pytest.raises(ValueError):
+        ops.conv3d_tr(x, torch.zeros(4, 40, 4, 4, 4, device=DEV), None)
+    with pytest.raises(ValueError):
+        ops.upsample3d_scale_add(x, torch.zeros(1, 4, 9, 16, 16, device=DEV), 2)
+    torch.cuda.synchronize()
