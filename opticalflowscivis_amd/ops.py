@@ -482,9 +482,9 @@ class _RobustLoss(torch.autograd.Function):
         S1, S2 = sums[0], sums[1]
         n = float(B * C * S)
         if form == "mean":
-            loss, dS1 = S1 / n, S1.new_tensor(1.0 / n)
+            loss, dS1 = S1 / n, torch.full_like(S1, 1.0 / n)  # fill kernel: graph-capturable
         elif form == "sum":
-            loss, dS1 = S1 * 1.0, S1.new_tensor(1.0)
+            loss, dS1 = S1 * 1.0, torch.ones_like(S1)
         elif form == "ratio":      # sum(l * w) / (sum(w) + 1e-6)          upflow.py:287
             dS1 = 1.0 / (S2 + 1e-6)
             loss = S1 * dS1
@@ -1078,7 +1078,7 @@ class _WSSIMLoss(torch.autograd.Function):
         if use_occ:
             dS1 = 1.0 / (sums[1] + 1e-6)
         else:
-            dS1 = sums.new_tensor(1.0 / float(B * C * (H - 2) * (W - 2)))
+            dS1 = torch.full_like(sums[0], 1.0 / float(B * C * (H - 2) * (W - 2)))
         ctx.save_for_backward(x, y, weight, dS1)
         ctx.use_occ = int(bool(use_occ))
         return sums[0] * dS1
