@@ -310,6 +310,8 @@ def test_laploss2d_vs_oracle_c2_shape(ops):
     dict(cin=64, cout=32, k=4, s=2, size=(3, 6, 18), tr=True),      # deconv head: input gradient = strided conv
     dict(cin=32, cout=6, k=4, s=2, size=(4, 7, 20), tr=True),
     dict(cin=32, cout=1, k=4, s=2, size=(3, 5, 33), tr=True),       # mask head (vector-ALU kernel)
+    dict(cin=8, cout=3, k=4, s=2, size=(4, 5, 9), tr=True),         # vector-ALU kernel, 4-channel instantiation
+    dict(cin=8, cout=2, k=4, s=2, size=(4, 7, 9), tr=True),         # ... 2-channel instantiation, odd row count
     dict(cin=6, cout=20, k=4, s=2, size=(3, 5, 37), tr=True),       # ragged channels on the MFMA kernel
     dict(cin=12, cout=32, k=4, s=2, size=(9, 11, 15), tr=False),    # odd extents: gradient of unused planes = 0
 ])
@@ -560,3 +562,25 @@ def test_conv_entry_points_reject_bad_arguments(ops):
     with pytest.raises(ValueError):
         ops.upsample3d_scale_add(x, torch.zeros(1, 4, 9, 16, 16, device=DEV), 2)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("size,wmode", [((32, 64, 64), 0), ((64, 128, 16), 1)])
+def test_conv3d_fwd_big_bricks_vs_fp64(ops, size, wmode):
+    """The full-size k = 3 bricks (2 x 8 x 32 and 2 x 16 x 16 voxels, NT = 4) are only selected for >= 512
+    workgroups; the small shapes of the other tests all run the quarter-size bricks.  fp64 CPU reference."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(size[0])
+    cin, cout = 6, 64
+    assert ops.conv3d_fwd_workgroups(2, cout, size, 3) >= 512
+    x = torch.randn((2, cin) + size, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    if wmode == 0:
+        ref = F.conv3d(x.double(), w.double(), b.double(), 1, 1)
+        got = ops.conv3d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 3, 1, 1, 0)
+    else:  # input gradient of a conv with weight wt [cin_layer = cout here ... ] read flipped + transposed
+        wt = torch.randn(cin, cout, 3, 3, 3, generator=g) * 0.1   # layer weight [Cout_layer=cin, Cin_layer=cout]
+        ref = F.conv3d(x.double(), wt.transpose(0, 1).flip(2, 3, 4).double(), None, 1, 1)
+        got = ops.conv3d_fwd(x.to(DEV), wt.to(DEV), None, 3, 1, 1, 1)
+    assert got.shape == ref.shape
+    assert float((got.cpu().double() - ref).abs().max()) < 3e-5 * float(ref.abs().max())
