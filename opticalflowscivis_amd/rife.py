@@ -217,7 +217,8 @@ class Model2D(ModelBase):
         loss_photo = ops.rife2d_photometric(flow[2], merged[2], img0, img1)  # RIFE.py:274-279
         lambda_l1, lambda_tea, lambda_distill = 1, 1, 0.01  # RIFE.py:283-289
         lambda_reg, lambda_photo, lambda_flow = 1e-6, 1e-5, 0
-        if math.isnan(float(loss_distill)) or float(loss_distill) > 10.:  # RIFE.py:295-296
+        ld = float(loss_distill.detach()) if torch.is_tensor(loss_distill) else float(loss_distill)
+        if math.isnan(ld) or ld > 10.:  # RIFE.py:295-296 (one host sync per step, as in the reference)
             loss_distill = torch.tensor(0.)
         if dataset in ("droplet2d", "vimeo2d"):
             loss_flow = torch.tensor(0.)

@@ -135,7 +135,7 @@ def run(args, Model, nd):
                 pred, info = model.update(imgs, gt, args.dataset, lr, training=True)
             if rank == 0 and (i % args.log_every == 0):
                 print('epoch:{}/{} {}/{} time:{:.2f} loss_G:{:.4e}'.format(
-                    epoch, args.epoch, i, steps_per_epoch, time.time() - t0, float(info['loss_G'])))
+                    epoch, args.epoch, i, steps_per_epoch, time.time() - t0, float(info['loss_G'].detach())))
                 t0 = time.time()
             step += 1
         loss, p, pt = evaluate(model, val_data, nd, args.dataset, device)
