@@ -50,7 +50,7 @@ def test_product_matches_reference_golden(golden, nd):
             pred, info = m.update(imgs, gt, learning_rate=1e-4, training=True)
         else:
             pred, info = m.update(imgs, gt, "droplet2d", learning_rate=1e-4, training=True)
-        got = [float(info[k]) for k in keys]
+        got = [float(info[k].detach()) if torch.is_tensor(info[k]) else float(info[k]) for k in keys]
         np.testing.assert_allclose(got, g["update_losses"][step], rtol=5e-4, atol=2e-6)
     assert np.abs(pred.detach().cpu().numpy() - g["update_pred_last"]).max() < 5e-4
     np.testing.assert_allclose(_psums(m.flownet), g["param_sums_after"], rtol=1e-4, atol=5e-3)
