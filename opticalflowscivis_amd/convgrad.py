@@ -1,20 +1,26 @@
-"""Weight-gradient of the IFNet convolutions as im2col + split-K GEMM (stock PyTorch / rocBLAS).
+"""The IFNet-3D convolutions on this package's HIP kernels, as drop-in `torch.nn` subclasses.
 
-Why this exists.  The convolutions are NOT part of this package's hot path -- they stay
-`torch.nn.Conv{2,3}d` / `ConvTranspose{2,3}d` on MIOpen.  But ROCm 7.2 ships no gfx950
-tuning database for MIOpen, and for the 3-D IFNet layers its weight-gradient solvers
-(`kernel_batched_gemm_xdlops_bwd_weight` without K-split, `naive_conv_ab_nonpacked_wrw`) take
-10-80 ms PER LAYER at 128^3 -- >90 % of the whole train step (profiles/r01_flow3d_128_*).  The
-weight gradient is a GEMM with a tiny output and a huge reduction:
+Why this exists.  The convolutions are not a SURVEY §8(a) row, but ROCm 7.2 ships no gfx950 tuning
+database for MIOpen: its 3-D weight-gradient solvers took 10-80 ms PER LAYER at 128^3 (>90 % of the
+train step, profiles/r01_flow3d_128_*), its forward runs CK kernels behind NCDHW<->NDHWC transposes and
+every strided / transposed layer goes through GEMM + Col2Im one sample at a time
+(profiles/r01_bench_256_kernel_stats_before_conv_kernels.csv).  `Conv3d`, `ConvTranspose3d` and `PReLU`
+below keep the parameters, state_dict keys and initialisation of their `torch.nn` bases and route
 
-    dW[co, (ci,kz,ky,kx)] = sum over (b, oz, oy, ox) of  gout[b,co,o] * x[b,ci, o*s + k - p]
+    forward            -> fs_conv3d_fwd   (k3 s1 p1, k4 s2 p1)   /  fs_conv3d_tr (ConvTranspose3d k4 s2 p1)
+    input gradient     -> fs_conv3d_fwd   (flipped weights; strided conv of grad_out for the transposed
+                          layers)         /  fs_conv3d_tr (for the k4 s2 convolutions)
+    weight gradient    -> fs_conv3d_wrw
+    PReLU backward     -> fs_prelu_bwd    (also emits the producing convolution's bias gradient)
 
-so it is computed here as  G[Co, K] @ Col[K, Ci*k^3]  with the reduction axis K = B*Do*Ho*Wo split
-into batches (bmm + sum): every CU gets work although the output is only Co x Ci*k^3.  Forward and
-input-gradient keep using MIOpen (they are fast).  Same math as autograd's convolution backward up
-to fp32 summation order.  `FLOWSCI_CONV_WRW=miopen` restores the stock path.
+with fused autograd nodes for the patterns IFBlock is made of: `ConvPReLU` (conv + bias + PReLU),
+`res_unit` (`convblock(x) + x`), and heads that accumulate onto the running flow / mask.  Anything
+outside the supported (kernel, stride, padding) set, non-fp32 or CPU tensors fall through to the
+`torch.nn` implementation.
 
-Module classes subclass the torch.nn ones, so parameter names / state_dicts are unchanged.
+`FLOWSCI_CONV_WRW` selects the stage: `mfma` (default, the kernels above), `gemm` (first replacement:
+im2col + split-K GEMM for the weight gradient with stock torch ops, everything else on MIOpen),
+`miopen` (stock autograd everywhere).
 """
 import os
 

@@ -6,8 +6,10 @@ conv0/convblock0..3/conv1/conv2 inside each block) and the construction order ar
 reference's, so `state_dict()` keys match reference checkpoints and `torch.manual_seed(s)`
 followed by construction yields the reference's initial weights.
 
-The convolutions stay `torch.nn` (MIOpen); the per-frame-pair hot path -- the two backward warps
-per block -- is `ops.warp_pair`, one HIP launch on the 4/6-channel flow in place.
+The per-frame-pair hot path -- the two backward warps per block -- is `ops.warp_pair`, one HIP launch
+on the 4/6-channel flow in place.  2-D convolutions are stock `torch.nn` (MIOpen); the 3-D ones are
+`torch.nn` subclasses running on this package's implicit-GEMM kernels (convgrad.py), fused per
+conv + PReLU pair, per residual unit and with the flow / mask accumulation of every block.
 """
 import torch
 import torch.nn as nn
@@ -15,8 +17,7 @@ import torch.nn.functional as F
 
 from . import convgrad, ops
 
-# 3-D layers: torch.nn modules whose WEIGHT gradient is an im2col + split-K GEMM (convgrad.py);
-# forward and input gradient stay on MIOpen
+# 3-D layers: torch.nn subclasses on fs_conv3d_{fwd,tr,wrw} (convgrad.py); same parameters / keys
 _CONV = {2: nn.Conv2d, 3: convgrad.Conv3d}
 _DECONV = {2: nn.ConvTranspose2d, 3: convgrad.ConvTranspose3d}
 _INTERP = {2: "bilinear", 3: "trilinear"}
