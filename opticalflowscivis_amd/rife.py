@@ -1,6 +1,7 @@
 """RIFE `Model` wrapper (optimiser, DDP, update / inference, checkpoints) shared by the Flow-2D
 and Flow-3D entry points.  Mirrors Flow-2D/model/RIFE.py:19-336 and Flow-3D/model/RIFE.py:18-275.
 """
+import copy
 import math
 
 import torch
@@ -72,8 +73,76 @@ class ModelBase:
             torch.save(self.flownet.state_dict(), '{}/{}'.format(path, model_name))
 
     def _set_lr(self, learning_rate):
+        if getattr(self, "_in_capture", False):
+            return  # the graph must not bake a learning-rate fill; step() sets it before each replay
         for g in self.optimG.param_groups:
-            g['lr'] = learning_rate
+            if torch.is_tensor(g['lr']):  # capturable optimiser: the rate lives in a device tensor
+                g['lr'].fill_(float(learning_rate))
+            else:
+                g['lr'] = learning_rate
+
+    def graphed_update(self, imgs, gt, **update_kwargs):
+        """Capture one training step -- forward, losses, backward, AdamW -- for inputs of this shape into
+        ONE HIP graph and return `step(imgs, gt, learning_rate) -> (pred, info)`, which copies the batch
+        into the graph's static inputs, replays it and returns the graph's static outputs (valid until
+        the next call).  No entry point of the hot path allocates outside the caching allocator,
+        synchronises or copies from the host, so the whole step is capturable; what the graph saves is
+        the ~660 launches' CPU cost and the gaps between short kernels.  Single-process models only
+        (capturing through DDP's reducer needs its own warm-up protocol and is not attempted).
+        Model2D keeps the reference's per-step host check of the distillation loss (RIFE.py:295) and is
+        therefore not capturable."""
+        if self.dev.type != "cuda":
+            raise RuntimeError("HIP graphs need a GPU")
+        if isinstance(self.flownet, DDP):
+            raise NotImplementedError("graph capture of the DDP-wrapped model is not supported")
+        # the optimiser state must live on the device: step counters and the learning rate
+        for grp in self.optimG.param_groups:
+            grp['capturable'] = True
+            if not torch.is_tensor(grp['lr']):
+                grp['lr'] = torch.tensor(float(grp['lr']), device=self.dev)
+        for st in self.optimG.state.values():
+            if torch.is_tensor(st.get('step')) and not st['step'].is_cuda:
+                st['step'] = st['step'].to(self.dev)
+        s_imgs, s_gt = imgs.clone(), gt.clone()
+        # one warm-up step off the capture stream (allocator pools, lazily created state), then restore:
+        # graphed_update() itself leaves weights and optimiser state untouched
+        weights = copy.deepcopy(self.flownet.state_dict())
+        saved = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                 for p, st in self.optimG.state.items()}
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self.update(s_imgs, s_gt, learning_rate=0.0, training=True, **update_kwargs)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        self.flownet.load_state_dict(weights)
+        # the optimiser state now EXISTS (a state created during capture would be re-zeroed by every
+        # replay): put the pre-warm-up values back into the same tensors
+        with torch.no_grad():
+            for p_, st in self.optimG.state.items():
+                old_st = saved.get(p_)
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if old_st is not None and torch.is_tensor(old_st.get(k)):
+                            v.copy_(old_st[k])
+                        else:
+                            v.zero_()
+        self.optimG.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        self._in_capture = True
+        try:
+            with torch.cuda.graph(graph):
+                out = self.update(s_imgs, s_gt, training=True, **update_kwargs)
+        finally:
+            self._in_capture = False
+
+        def step(imgs, gt, learning_rate):
+            s_imgs.copy_(imgs)
+            s_gt.copy_(gt)
+            self._set_lr(learning_rate)
+            graph.replay()
+            return out
+        step.graph = graph
+        return step
 
 
 class Model3D(ModelBase):

@@ -157,43 +157,42 @@ def test_flow2d_c2_train_step_vs_oracle():
 
 
 def test_flow3d_train_step_is_hip_graph_capturable():
-    """The whole Flow-3D training step (forward, losses, backward, AdamW) captures into ONE HIP graph:
-    no entry point allocates outside the caching allocator, synchronises or copies from the host.
-    Replaying the graph reproduces the eager step (same weights, same data)."""
+    """The whole Flow-3D training step (forward, losses, backward, AdamW) captures into ONE HIP graph
+    (`Model.graphed_update`): no entry point allocates outside the caching allocator, synchronises or
+    copies from the host.  Replaying the graph reproduces eager steps from the same weights, follows the
+    learning rate passed per step, and building it leaves the model untouched."""
     import copy
-    from torch.optim import AdamW
     from opticalflowscivis_amd.flow3d.model.RIFE import Model
     from opticalflowscivis_amd.data import synthetic
     torch.manual_seed(7)
     m = Model(local_rank=-1, device=DEV)
     data = synthetic.droplet3d_batch(1, 32, seed=3, device=DEV)
     imgs, gt = data[:, :2].contiguous(), data[:, 2:3].contiguous()
-
-    def fresh_opt():
-        return AdamW(m.flownet.parameters(), lr=torch.tensor(1e-4, device=DEV), weight_decay=1e-3, capturable=True)
-    m._set_lr = lambda lr: None  # the learning rate lives in the optimiser's device tensor
+    data2 = synthetic.droplet3d_batch(1, 32, seed=4, device=DEV)
+    imgs2, gt2 = data2[:, :2].contiguous(), data2[:, 2:3].contiguous()
     state0 = copy.deepcopy(m.flownet.state_dict())
-    # eager reference: two steps from state0
-    m.optimG = fresh_opt()
-    eager = [float(m.update(imgs, gt, training=True)[1]["loss_G"].detach()) for _ in range(2)]
-    # graphed: warm up on a side stream, restore, capture one step, replay twice
-    m.flownet.load_state_dict(state0)
-    m.optimG = fresh_opt()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        m.update(imgs, gt, training=True)
-    torch.cuda.current_stream().wait_stream(s)
-    m.flownet.load_state_dict(state0)
-    m.optimG = fresh_opt()
-    m.optimG.zero_grad(set_to_none=True)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        _, info = m.update(imgs, gt, training=True)
-    # the capture itself does not execute: parameters still at state0
-    losses = []
-    for _ in range(2):
-        g.replay()
-        losses.append(float(info["loss_G"].detach()))
-    for a, b in zip(losses, eager):
-        assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (losses, eager)
+    lrs = (1e-4, 3e-4, 1e-4)
+    batches = ((imgs, gt), (imgs2, gt2), (imgs, gt))  # the third loss sees the effect of the second update
+    eager = [float(m.update(bi, bg, learning_rate=lr, training=True)[1]["loss_G"].detach())
+             for (bi, bg), lr in zip(batches, lrs)]
+    # fresh model state, graphed
+    m2 = Model(local_rank=-1, device=DEV)
+    m2.flownet.load_state_dict(state0)
+    step = m2.graphed_update(imgs, gt)
+    for a, b in zip(m2.flownet.state_dict().values(), state0.values()):
+        assert torch.equal(a, b)  # building the graph did not train
+    graphed = []
+    for (bi, bg), lr in zip(batches, lrs):
+        _, info = step(bi, bg, lr)
+        graphed.append(float(info["loss_G"].detach()))
+    for a, b in zip(graphed, eager):
+        assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (graphed, eager)
+    # AdamW's first steps move every weight by ~lr * sign(grad): the replays honoured the three learning
+    # rates (total displacement ~ their sum; elementwise agreement with the eager run is not defined --
+    # most of these gradients are at the noise level of the atomics-based reductions and Adam normalises
+    # them to +-lr)
+    tot = sum(lrs)
+    w0 = state0["block2.convblock0.0.0.weight"].to(DEV)
+    wg = dict(m2.flownet.named_parameters())["block2.convblock0.0.0.weight"].detach()
+    assert 0.3 * tot < float((wg - w0).abs().median()) < 1.2 * tot
+    assert float((wg - w0).abs().max()) <= tot * 1.001 + 1e-7
