@@ -196,3 +196,28 @@ def test_flow3d_train_step_is_hip_graph_capturable():
     wg = dict(m2.flownet.named_parameters())["block2.convblock0.0.0.weight"].detach()
     assert 0.3 * tot < float((wg - w0).abs().median()) < 1.2 * tot
     assert float((wg - w0).abs().max()) <= tot * 1.001 + 1e-7
+
+
+def test_flow3d_training_trajectory_tracks_oracle():
+    """25 AdamW steps from the same weights on the same batch: the product's losses follow the CPU oracle's
+    step by step while loss_G falls (scripts/soak_vs_oracle.py follows them for 100+ steps, to 1/4 of the
+    initial loss).  A wrong gradient in any kernel of the step shows up here within a few steps."""
+    from opticalflowscivis_amd.data import synthetic
+    from oracle.ifnet_ref import ModelRef
+    torch.manual_seed(0)
+    m = _product(3)
+    o = ModelRef(3)
+    o.flownet.load_state_dict({k: v.cpu() for k, v in m.flownet.state_dict().items()})
+    data = synthetic.droplet3d_batch(2, 32, seed=5)
+    imgs, gt = data[:, :2].contiguous(), data[:, 2:3].contiguous()
+    gi, gg = imgs.to(DEV), gt.to(DEV)
+    first = last = None
+    for i in range(26):
+        _, pi = m.update(gi, gg, learning_rate=3e-5, training=True)
+        _, oi = o.update(imgs, gt, learning_rate=3e-5)
+        a, b = float(pi["loss_G"].detach()), float(oi["loss_G"].detach())
+        assert abs(a - b) < 2e-3 * abs(b) + 1e-5, (i, a, b)
+        if i == 0:
+            first = b
+        last = b
+    assert last < 0.97 * first  # it actually trained
