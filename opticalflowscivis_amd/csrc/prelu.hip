@@ -69,21 +69,26 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void prelu_ga_kernel(const float* __restrict__ ws,
-                                                       float* __restrict__ ga, int B, int C, int nchunk,
-                                                       int shared_a) {
-  // one block per output weight; fixed summation order, fp64
-  const int c = blockIdx.x;
+// Finishing pass: blocks [0, nw) reduce the slope-gradient partials (per channel, or over everything when
+// the slope is shared); blocks [nw, nw + C) -- present only with a bias gradient -- reduce the per-channel
+// partials of sum(grad_x).  One block per output, fixed summation order, fp64: deterministic.
+__global__ __launch_bounds__(256) void prelu_ga_kernel(const float* __restrict__ ws, const float* __restrict__ wsb,
+                                                       float* __restrict__ ga, float* __restrict__ gb, int B,
+                                                       int C, int nchunk, int nw) {
+  const bool bias_blk = (int)blockIdx.x >= nw;
+  const float* src = bias_blk ? wsb : ws;
+  const int c = bias_blk ? blockIdx.x - nw : blockIdx.x;
+  const bool all = !bias_blk && nw == 1 && C != 1;  // shared slope: sum over every (b, c)
   __shared__ double red[256];
   double s = 0.0;
-  if (shared_a) {
+  if (all) {
     const long long n = (long long)B * C * nchunk;
-    for (long long i = threadIdx.x; i < n; i += 256) s += (double)ws[i];
+    for (long long i = threadIdx.x; i < n; i += 256) s += (double)src[i];
   } else {
     const int n = B * nchunk;
     for (int i = threadIdx.x; i < n; i += 256) {
       const int b = i / nchunk, k = i - b * nchunk;
-      s += (double)ws[((long long)b * C + c) * nchunk + k];
+      s += (double)src[((long long)b * C + c) * nchunk + k];
     }
   }
   red[threadIdx.x] = s;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void prelu_ga_kernel(const float* __restrict__
     if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) ga[c] = (float)red[0];
+  if (threadIdx.x == 0) (bias_blk ? gb : ga)[c] = (float)red[0];
 }
 
 }  // namespace
@@ -118,10 +123,8 @@ extern "C" int fs_prelu_bwd(const float* x, const float* grad_out, const float* 
   float* wsb = grad_bias ? ws + (size_t)B * C * PCH : nullptr;
   hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, grad_out, weight,
                      grad_x, ws, wsb, C, S, nchunk, chunk_len, shared_a);
-  hipLaunchKernelGGL(prelu_ga_kernel, dim3(num_weights), dim3(256), 0, st, ws, grad_weight, B, C, nchunk,
-                     shared_a);
-  if (grad_bias)  // always per channel, same fixed-order fp64 finish
-    hipLaunchKernelGGL(prelu_ga_kernel, dim3(C), dim3(256), 0, st, wsb, grad_bias, B, C, nchunk, 0);
+  hipLaunchKernelGGL(prelu_ga_kernel, dim3(num_weights + (grad_bias ? C : 0)), dim3(256), 0, st, ws, wsb,
+                     grad_weight, grad_bias, B, C, nchunk, num_weights);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
