@@ -241,6 +241,11 @@ def main():
                        "global_batch": world * B, "volume": [S, S, S],
                        "parallelism": "dp%d" % world},
             "roofline": roofline(dom, kern[dom], S, B),
+            # the hot-path row the metric is named after (the trilinear backward warp pair)
+            # against the HBM roofline, with its measured HBM traffic per launch; `roofline` above is the
+            # kernel that dominates the step's time
+            "roofline_hbm": (roofline("fs_warp3d_pair_bwd", kern["fs_warp3d_pair_bwd"], S, B)
+                             if "fs_warp3d_pair_bwd" in kern else None),
             "kernels": kern,
             "loss_G": loss,
         }

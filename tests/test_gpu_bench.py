@@ -29,6 +29,8 @@ def test_bench_json_contract():
     rf = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] in ("hbm", "mfma")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    rh = d["roofline_hbm"]
+    assert rh["bound"] == "hbm" and rh["kernel"] == "fs_warp3d_pair_bwd" and 0 < rh["frac"] < 1
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] in ("port", "reference")
     assert cb["value"] > 0 and cb["cores"] >= 1
