@@ -152,7 +152,7 @@ def main():
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank)  # RCCL on ROCm
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)  # RCCL on ROCm
 
     from opticalflowscivis_amd import ops
     from opticalflowscivis_amd.data import synthetic
