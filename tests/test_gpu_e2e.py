@@ -200,7 +200,7 @@ def test_flow3d_train_step_is_hip_graph_capturable():
 
 def test_flow3d_training_trajectory_tracks_oracle():
     """25 AdamW steps from the same weights on the same batch: the product's losses follow the CPU oracle's
-    step by step while loss_G falls (scripts/soak_vs_oracle.py follows them for 100+ steps, to 1/4 of the
+    step by step while loss_G falls (tests/tools/soak_vs_oracle.py follows them for 100+ steps, to 1/4 of the
     initial loss).  A wrong gradient in any kernel of the step shows up here within a few steps."""
     from opticalflowscivis_amd.data import synthetic
     from oracle.ifnet_ref import ModelRef

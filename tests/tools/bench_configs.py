@@ -2,7 +2,7 @@
 160x224 B=16 and C3 UPFlow 150x450 B=32 train steps on one MI355X, with the oracle / stock CPU step
 beside them.  GPU box only.  usage: bench_configs.py [c2|c3|all]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from opticalflowscivis_amd.data import synthetic
 

@@ -1,7 +1,7 @@
 """Loss trajectory of the product (GPU) and of the CPU oracle from the same weights / data, constant lr.
 Test infrastructure (imports oracle/); GPU box only."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from opticalflowscivis_amd.flow3d.model.RIFE import Model
 from opticalflowscivis_amd.data import synthetic
