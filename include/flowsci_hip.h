@@ -327,9 +327,7 @@ int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, f
 /* fs_conv3d_fwd_prelu / fs_conv3d_tr_prelu: the same convolutions with the PReLU that follows every one of
  * them in IFNet (`conv()` / `deconv()`, Flow-3D/model/IFNet.py:13-29) applied in the epilogue:
  * y = conv(x) + bias (kept: the PReLU backward needs it) and z = y > 0 ? y : prelu_weight[c] * y are written
- * in the same pass (num_prelu_weights = 1 or Cout).  sparse_y = 1 (no residual): y is stored only for channels
- * whose slope is <= FS_PRELU_POS -- fs_prelu_bwd(z = ...) reads the others back from z, saving the y
- * store.  fwd_prelu is wmode 0 only; its `residual` (may be
+ * in the same pass (num_prelu_weights = 1 or Cout).  fwd_prelu is wmode 0 only; its `residual` (may be
  * NULL, z's shape) is added to z: the `convblock(x) + x` of IFBlock.forward (Flow-3D/model/IFNet.py:101-104).
  * fs_conv3d_fwd_add: y = conv(x) + bias + addend (y's shape) -- with wmode 1 the input gradient of such a
  * residual unit, whose skip branch contributes grad_out itself. */
@@ -339,12 +337,11 @@ int fs_conv3d_fwd_add(const float* x, const float* w, const float* bias, const f
 int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
                         const float* residual, float* y, float* z, float* ws,
                         int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                        int kernel, int stride, int pad, int num_prelu_weights, int sparse_y,
-                        fs_stream_t stream);
+                        int kernel, int stride, int pad, int num_prelu_weights, fs_stream_t stream);
 int fs_conv3d_tr_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
                        float* y, float* z, float* ws,
                        int B, int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
-                       int num_prelu_weights, int sparse_y, fs_stream_t stream);
+                       int num_prelu_weights, fs_stream_t stream);
 /* fs_conv3d_tr_add: y = conv_transpose(x) + bias + addend (addend has y's shape): the head's flow / mask
  * delta accumulated onto the running flow / mask (Flow-3D/model/IFNet.py:213-214, 228-229) in the epilogue. */
 int fs_conv3d_tr_add(const float* x, const float* w, const float* bias, const float* addend, float* y,
@@ -364,13 +361,9 @@ int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, fl
  * grad_bias (may be NULL) [C]: additionally sum_{b,spatial} grad_x per channel -- the bias gradient
  * of the convolution that produced x, for free in the same pass (ws must then hold
  * 2*B*C*FS_PRELU_MAX_CHUNKS floats).
- * z (may be NULL) [B,C,S] = prelu(x): for channels whose slope is > FS_PRELU_POS the kernel reads z
- * instead of x (same sign; x = z / slope on the non-positive side), so a producer that wrote z may skip
- * storing x for those channels (the `sparse_y` option of fs_conv3d_{fwd,tr}_prelu).
  */
 #define FS_PRELU_MAX_CHUNKS 64
-#define FS_PRELU_POS 1e-6f
-int fs_prelu_bwd(const float* x, const float* z, const float* grad_out, const float* weight,
+int fs_prelu_bwd(const float* x, const float* grad_out, const float* weight,
                  float* grad_x, float* grad_weight, float* grad_bias, float* ws,
                  int B, int C, int S, int num_weights, fs_stream_t stream);
 

@@ -39,9 +39,9 @@ SIGNATURES = {
     "fs_conv3d_fwd_ws_floats": [_int] * 3,
     "fs_conv3d_fwd": [_f32p] * 5 + [_int] * 13 + [_stream],
     "fs_upsample3d_scale_add": [_f32p] * 3 + [_int] * 6 + [_float, _stream],
-    "fs_conv3d_fwd_prelu": [_f32p] * 8 + [_int] * 14 + [_stream],
+    "fs_conv3d_fwd_prelu": [_f32p] * 8 + [_int] * 13 + [_stream],
     "fs_conv3d_fwd_add": [_f32p] * 6 + [_int] * 13 + [_stream],
-    "fs_conv3d_tr_prelu": [_f32p] * 7 + [_int] * 11 + [_stream],
+    "fs_conv3d_tr_prelu": [_f32p] * 7 + [_int] * 10 + [_stream],
     "fs_conv3d_tr_add": [_f32p] * 6 + [_int] * 9 + [_stream],
     "fs_conv3d_tr_ws_floats": [_int] * 2,
     "fs_conv3d_tr": [_f32p] * 5 + [_int] * 9 + [_stream],
@@ -60,7 +60,7 @@ SIGNATURES = {
     "fs_distill_fwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_distill_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_interp3d_bwd": [_f32p] * 3 + [_int] * 10 + [_stream],
-        "fs_prelu_bwd": [_f32p] * 8 + [_int] * 4 + [_stream],
+        "fs_prelu_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_corr3d_fwd": [_f32p] * 3 + [_int] * 6 + [_stream],
     "fs_corr3d_bwd": [_f32p] * 5 + [_int] * 6 + [_stream],
     "fs_conv3d_wrw": [_f32p] * 3 + [_int] * 12 + [_stream],

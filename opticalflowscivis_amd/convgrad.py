@@ -121,29 +121,26 @@ def _conv_out(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
-def _conv_forward(x, w, b, stride, padding, transposed, prelu_weight=None, sparse_y=False):
+def _conv_forward(x, w, b, stride, padding, transposed, prelu_weight=None):
     """y = conv(x); with `prelu_weight` returns (y, prelu(y)) -- from the convolution's own epilogue on
     the HIP paths, as a separate pass otherwise."""
     nd = x.dim() - 2
     y = None
     if transposed and nd == 3 and _hip_tr_ok(x, w.shape[1], tuple(w.shape[2:]), stride, padding):
         from . import ops
-        y = ops.conv3d_tr(x, w, b, None, prelu_weight, None, sparse_y and prelu_weight is not None)
+        y = ops.conv3d_tr(x, w, b, None, prelu_weight)
     elif transposed:
         y = (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
     elif nd == 3 and _hip_fwd_ok(x, w.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
                                                  zip(x.shape[2:], w.shape[2:], stride, padding)],
                                  tuple(w.shape[2:]), stride, padding):
         from . import ops
-        y = ops.conv3d_fwd(x, w, b, w.shape[2], stride[0], padding[0], 0, prelu_weight, None,
-                           sparse_y and prelu_weight is not None)
+        y = ops.conv3d_fwd(x, w, b, w.shape[2], stride[0], padding[0], 0, prelu_weight)
     else:
         y = (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, padding)
-    if prelu_weight is None:
+    if prelu_weight is None or isinstance(y, tuple):
         return y
-    if isinstance(y, tuple):  # (y, z) from the kernel's epilogue; y is sparse if it was asked for
-        return y + (bool(sparse_y),)
-    return y, F.prelu(y, prelu_weight), False
+    return y, F.prelu(y, prelu_weight)
 
 
 def _conv_grad_input(x, w, gy, stride, padding, transposed):
@@ -241,19 +238,17 @@ class _ConvPReLUFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, a, stride, padding, transposed):
-        # sparse y: the epilogue stores the pre-activation only for channels whose slope is not positive;
-        # the backward pass reads the others back from the output z
-        y, z, sparse = _conv_forward(x, w, b, stride, padding, transposed, a, sparse_y=True)
-        ctx.save_for_backward(x, w, y, a, z)
-        ctx.cfg = (stride, padding, transposed, b is not None, sparse)
+        y, z = _conv_forward(x, w, b, stride, padding, transposed, a)
+        ctx.save_for_backward(x, w, y, a)
+        ctx.cfg = (stride, padding, transposed, b is not None)
         return z
 
     @staticmethod
     def backward(ctx, gz):
         from . import ops
-        x, w, y, a, z = ctx.saved_tensors
-        stride, padding, transposed, has_bias, sparse = ctx.cfg
-        gy, ga, gb = ops.prelu_backward(y, gz.contiguous(), a, want_bias_grad=has_bias, z=z if sparse else None)
+        x, w, y, a = ctx.saved_tensors
+        stride, padding, transposed, has_bias = ctx.cfg
+        gy, ga, gb = ops.prelu_backward(y, gz.contiguous(), a, want_bias_grad=has_bias)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = _conv_grad_input(x, w, gy, stride, padding, transposed)
@@ -288,8 +283,8 @@ class _ResUnitFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, a1, w2, b2, a2):
         from . import ops
         k, p = w1.shape[2], (w1.shape[2] - 1) // 2
-        y1, z1 = ops.conv3d_fwd(x, w1, b1, k, 1, p, 0, a1, None, True)  # sparse y1: read back from z1
-        y2, out = ops.conv3d_fwd(z1, w2, b2, k, 1, p, 0, a2, x)        # out includes the skip: y2 is kept
+        y1, z1 = ops.conv3d_fwd(x, w1, b1, k, 1, p, 0, a1)
+        y2, out = ops.conv3d_fwd(z1, w2, b2, k, 1, p, 0, a2, x)
         ctx.save_for_backward(x, w1, a1, y1, z1, w2, a2, y2)
         ctx.has_bias = (b1 is not None, b2 is not None)
         return out
@@ -304,7 +299,7 @@ class _ResUnitFn(torch.autograd.Function):
         gy2, ga2, gb2 = ops.prelu_backward(y2, gout, a2, want_bias_grad=ctx.has_bias[1])
         gw2 = _conv_grad_weight(z1, w2, gy2, s3, p3, False) if ctx.needs_input_grad[4] else None
         gz1 = ops.conv3d_fwd(gy2, w2, None, k, 1, p, 1)
-        gy1, ga1, gb1 = ops.prelu_backward(y1, gz1, a1, want_bias_grad=ctx.has_bias[0], z=z1)
+        gy1, ga1, gb1 = ops.prelu_backward(y1, gz1, a1, want_bias_grad=ctx.has_bias[0])
         gw1 = _conv_grad_weight(x, w1, gy1, s3, p3, False) if ctx.needs_input_grad[1] else None
         gx = ops.conv3d_fwd(gy1, w1, None, k, 1, p, 1, None, gout) if ctx.needs_input_grad[0] else None
         return gx, gw1, gb1, ga1, gw2, gb2, ga2

@@ -43,9 +43,6 @@ struct FP {
   // written (the residual of an IFBlock unit, `convblock(x) + x`), else to Y (the residual branch of
   // that unit's input gradient)
   const float* addend;
-  // sparse_y: with Z written and no addend, Y is stored only for channels whose slope is <= FS_PRELU_POS
-  // -- for the others fs_prelu_bwd reconstructs y from z (y > 0 <=> z > 0, y = z / slope otherwise)
-  int sparse_y;
 };
 
 // Wt[ci][tap][co] (ci < CinP, co < CoutP; zero outside the real channels)
@@ -248,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
             const float v = acc[m][n][r] + bv[m][r];
             const size_t o = o0 + (size_t)co * yvol;
             if (Zp != nullptr) {
-              if (!p.sparse_y || !(sv[m][r] > FS_PRELU_POS)) Yp[o] = v;
+              Yp[o] = v;
               Zp[o] = (v > 0.f ? v : sv[m][r] * v) + av[r];
             } else {
               Yp[o] = v + av[r];
@@ -290,7 +287,7 @@ extern "C" long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel) {
 }
 
 static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
-                           const float* addend, int sparse_y, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
+                           const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
                            int Ho, int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y); FS_REQUIRE_PTR(ws);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
@@ -309,8 +306,7 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   FP p;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Do; p.Ho = Ho; p.Wo = Wo;
   p.pad = pad;
-  if (sparse_y && (z == nullptr || addend != nullptr)) return FS_ERR_ARG;
-  p.slope = slope; p.Z = z; p.nslope = nslope; p.addend = addend; p.sparse_y = sparse_y;
+  p.slope = slope; p.Z = z; p.nslope = nslope; p.addend = addend;
   int cinp;
   wt_dims(Cin, Cout, kernel, &cinp, &p.CoutP);
   hipStream_t st = (hipStream_t)stream;
@@ -344,7 +340,7 @@ extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, 
                              int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kernel,
                              int stride, int pad, int wmode, fs_stream_t stream) {
   FS_ENTER();
-  return conv3d_fwd_impl(x, w, bias, nullptr, 0, nullptr, 0, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
+  return conv3d_fwd_impl(x, w, bias, nullptr, 0, nullptr, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
                          kernel, stride, pad, wmode, stream);
 }
 
@@ -353,16 +349,16 @@ extern "C" int fs_conv3d_fwd_add(const float* x, const float* w, const float* bi
                                  int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(addend);
-  return conv3d_fwd_impl(x, w, bias, nullptr, 0, addend, 0, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
+  return conv3d_fwd_impl(x, w, bias, nullptr, 0, addend, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
                          kernel, stride, pad, wmode, stream);
 }
 
 extern "C" int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
                                    const float* residual, float* y, float* z, float* ws, int B, int Cin, int Cout,
                                    int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kernel, int stride, int pad,
-                                   int num_prelu_weights, int sparse_y, fs_stream_t stream) {
+                                   int num_prelu_weights, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
-  return conv3d_fwd_impl(x, w, bias, prelu_weight, num_prelu_weights, residual, sparse_y ? 1 : 0, y, z, ws, B, Cin,
-                         Cout, Di, Hi, Wi, Do, Ho, Wo, kernel, stride, pad, 0, stream);
+  return conv3d_fwd_impl(x, w, bias, prelu_weight, num_prelu_weights, residual, y, z, ws, B, Cin, Cout, Di, Hi, Wi,
+                         Do, Ho, Wo, kernel, stride, pad, 0, stream);
 }

@@ -41,7 +41,6 @@ struct TP {
   // optional residual: Y = conv + bias + addend (same shape as Y) -- IFNet's `flow = flow + flow_d`
   const float* addend;
   const float* Ybase;  // = Y (to locate the addend plane of a channel)
-  int sparse_y;        // with Z: store Y only for channels whose slope is <= FS_PRELU_POS (see convfwd.hip)
 };
 
 // tap a (0/1) of output parity p along one axis: input offset d and kernel index k
@@ -76,13 +75,11 @@ __device__ __forceinline__ void store8(float* __restrict__ yc, const float (&v)[
         v0 += arow[0];
         if (x + 1 < p.Wout) v1 += arow[1];
       }
-      if (!(p.sparse_y && zc != nullptr && sl > FS_PRELU_POS)) {
-        if ((p.Wout & 1) == 0) {
-          *reinterpret_cast<float2*>(row) = make_float2(v0, v1);
-        } else {
-          row[0] = v0;
-          if (x + 1 < p.Wout) row[1] = v1;
-        }
+      if ((p.Wout & 1) == 0) {
+        *reinterpret_cast<float2*>(row) = make_float2(v0, v1);
+      } else {
+        row[0] = v0;
+        if (x + 1 < p.Wout) row[1] = v1;
       }
       if (zc != nullptr) {
         float* zrow = zc + (row - yc);
@@ -453,7 +450,7 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
 }
 
 static int conv3d_tr_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
-                          const float* addend, int sparse_y, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di,
+                          const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di,
                           int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
@@ -471,8 +468,7 @@ static int conv3d_tr_impl(const float* x, const float* w, const float* bias, con
   p.Dout = Dout; p.Hout = Hout; p.Wout = Wout;
   p.Dq = (Dout + 1) / 2; p.Hq = (Hout + 1) / 2; p.Wq = (Wout + 1) / 2;
   p.slope = slope; p.Z = z; p.nslope = nslope;
-  if (sparse_y && (z == nullptr || addend != nullptr)) return FS_ERR_ARG;
-  p.addend = addend; p.Ybase = y; p.sparse_y = sparse_y;
+  p.addend = addend; p.Ybase = y;
   hipStream_t st = (hipStream_t)stream;
   if ((long long)B * p.Dq * p.Hq * p.Wq >= (1ll << 31) * 256) return FS_ERR_SHAPE;
   if (Cout <= 6) {
@@ -506,7 +502,7 @@ extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, f
                             int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
                             fs_stream_t stream) {
   FS_ENTER();
-  return conv3d_tr_impl(x, w, bias, nullptr, 0, nullptr, 0, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout,
+  return conv3d_tr_impl(x, w, bias, nullptr, 0, nullptr, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout,
                         stream);
 }
 
@@ -515,16 +511,15 @@ extern "C" int fs_conv3d_tr_add(const float* x, const float* w, const float* bia
                                 int Wout, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(addend);
-  return conv3d_tr_impl(x, w, bias, nullptr, 0, addend, 0, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout,
+  return conv3d_tr_impl(x, w, bias, nullptr, 0, addend, y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout,
                         stream);
 }
 
 extern "C" int fs_conv3d_tr_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
                                   float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi,
-                                  int Dout, int Hout, int Wout, int num_prelu_weights, int sparse_y,
-                                  fs_stream_t stream) {
+                                  int Dout, int Hout, int Wout, int num_prelu_weights, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
-  return conv3d_tr_impl(x, w, bias, prelu_weight, num_prelu_weights, nullptr, sparse_y ? 1 : 0, y, z, ws, B, Cin,
-                        Cout, Di, Hi, Wi, Dout, Hout, Wout, stream);
+  return conv3d_tr_impl(x, w, bias, prelu_weight, num_prelu_weights, nullptr, y, z, ws, B, Cin, Cout, Di, Hi, Wi,
+                        Dout, Hout, Wout, stream);
 }

@@ -12,8 +12,7 @@ namespace {
 
 constexpr int PCH = FS_PRELU_MAX_CHUNKS;  // spatial chunks per (b, c) row, upper bound
 
-__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x_in,
-                                                        const float* __restrict__ z,
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ a,
                                                         float* __restrict__ gx, float* __restrict__ ws,
@@ -24,11 +23,6 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
   const long long row = blockIdx.x / nchunk;
   const int c = (int)(row % C);
   const float slope = a[shared_a ? 0 : c];
-  // sparse-y producers (fs_conv3d_*_prelu with sparse_y) stored y only where the slope is <= FS_PRELU_POS;
-  // elsewhere y is read back from z = prelu(y): same sign, y = z / slope on the negative side
-  const bool from_z = (z != nullptr) && (slope > FS_PRELU_POS);
-  const float* __restrict__ x = from_z ? z : x_in;
-  const float neg_scale = from_z ? 1.0f / slope : 1.0f;
   const long long base = row * (long long)S;
   const int lo = chunk * chunk_len, hi = min(lo + chunk_len, S);
   float acc = 0.f, accb = 0.f;  // accb: sum of grad_x = the bias gradient of the producing convolution
@@ -40,10 +34,10 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
       const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
       const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
       float4 o;
-      o.x = xv.x > 0.f ? gv.x : slope * gv.x; acc += xv.x > 0.f ? 0.f : (xv.x * neg_scale) * gv.x;
-      o.y = xv.y > 0.f ? gv.y : slope * gv.y; acc += xv.y > 0.f ? 0.f : (xv.y * neg_scale) * gv.y;
-      o.z = xv.z > 0.f ? gv.z : slope * gv.z; acc += xv.z > 0.f ? 0.f : (xv.z * neg_scale) * gv.z;
-      o.w = xv.w > 0.f ? gv.w : slope * gv.w; acc += xv.w > 0.f ? 0.f : (xv.w * neg_scale) * gv.w;
+      o.x = xv.x > 0.f ? gv.x : slope * gv.x; acc += xv.x > 0.f ? 0.f : xv.x * gv.x;
+      o.y = xv.y > 0.f ? gv.y : slope * gv.y; acc += xv.y > 0.f ? 0.f : xv.y * gv.y;
+      o.z = xv.z > 0.f ? gv.z : slope * gv.z; acc += xv.z > 0.f ? 0.f : xv.z * gv.z;
+      o.w = xv.w > 0.f ? gv.w : slope * gv.w; acc += xv.w > 0.f ? 0.f : xv.w * gv.w;
       accb += (o.x + o.y) + (o.z + o.w);
       *reinterpret_cast<float4*>(gx + base + i) = o;
     }
@@ -53,7 +47,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
       const float o = xv > 0.f ? gv : slope * gv;
       gx[base + j] = o;
       accb += o;
-      acc += xv > 0.f ? 0.f : (xv * neg_scale) * gv;
+      acc += xv > 0.f ? 0.f : xv * gv;
     }
   } else {
     for (int j = lo + threadIdx.x; j < hi; j += 256) {
@@ -61,7 +55,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
       const float o = xv > 0.f ? gv : slope * gv;
       gx[base + j] = o;
       accb += o;
-      acc += xv > 0.f ? 0.f : (xv * neg_scale) * gv;
+      acc += xv > 0.f ? 0.f : xv * gv;
     }
   }
   __shared__ float red[2][4];
@@ -108,8 +102,8 @@ __global__ __launch_bounds__(256) void prelu_ga_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int fs_prelu_bwd(const float* x, const float* z, const float* grad_out, const float* weight,
-                            float* grad_x, float* grad_weight, float* grad_bias, float* ws, int B, int C, int S,
+extern "C" int fs_prelu_bwd(const float* x, const float* grad_out, const float* weight, float* grad_x,
+                            float* grad_weight, float* grad_bias, float* ws, int B, int C, int S,
                             int num_weights, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(grad_out); FS_REQUIRE_PTR(weight);
@@ -127,7 +121,7 @@ extern "C" int fs_prelu_bwd(const float* x, const float* z, const float* grad_ou
   const int shared_a = (num_weights == 1) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   float* wsb = grad_bias ? ws + (size_t)B * C * PCH : nullptr;
-  hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, z, grad_out, weight,
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, grad_out, weight,
                      grad_x, ws, wsb, C, S, nchunk, chunk_len, shared_a);
   hipLaunchKernelGGL(prelu_ga_kernel, dim3(num_weights + (grad_bias ? C : 0)), dim3(256), 0, st, ws, wsb,
                      grad_weight, grad_bias, B, C, nchunk, num_weights);

@@ -838,15 +838,10 @@ def interpolate3d(x, scale_factor):
 _PRELU_MAX_CHUNKS = 64
 
 
-def prelu_backward(x, gy, weight, want_bias_grad=False, z=None):
+def prelu_backward(x, gy, weight, want_bias_grad=False):
     """fs_prelu_bwd: (grad_x, grad_weight, grad_bias or None) of y = prelu(x, weight) in one pass over
-    [B,C,*]; grad_bias = per-channel sum of grad_x (the producing convolution's bias gradient).
-    `z` = prelu(x) (optional): x is then only read for channels whose slope is <= 1e-6 (sparse-y producers)."""
+    [B,C,*]; grad_bias = per-channel sum of grad_x (the producing convolution's bias gradient)."""
     x = _need_cuda_f32("x", x, x.dim())
-    if z is not None:
-        z = _need_cuda_f32("z", z, x.dim())
-        if z.shape != x.shape:
-            raise ValueError("z %s must have x's shape %s" % (tuple(z.shape), tuple(x.shape)))
     gy = _need_cuda_f32("grad_output", gy, x.dim())
     B, C, S = _flat3(x)
     gx = torch.empty_like(x)
@@ -854,7 +849,7 @@ def prelu_backward(x, gy, weight, want_bias_grad=False, z=None):
     gb = x.new_empty(C) if want_bias_grad else None
     ws = x.new_empty((2 if want_bias_grad else 1) * B * C * _PRELU_MAX_CHUNKS)
     with torch.cuda.device(x.device):
-        _call("fs_prelu_bwd", x.data_ptr(), _ptr(z), gy.data_ptr(), weight.data_ptr(), gx.data_ptr(),
+        _call("fs_prelu_bwd", x.data_ptr(), gy.data_ptr(), weight.data_ptr(), gx.data_ptr(),
               gw.data_ptr(), _ptr(gb), ws.data_ptr(), B, C, S, weight.numel(), _stream(x),
               algo_bytes=12 * x.numel())
     return gx, gw, gb
@@ -958,12 +953,11 @@ def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
     return B * Do * cd(Ho, 8 * r) * cd(Wo, tw) * mg
 
 
-def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=None, sparse_y=False):
+def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=None):
     """fs_conv3d_fwd: y = conv3d(x, W, bias, stride, pad) with W = w (wmode 0, [Cout,Cin,k,k,k]) or the
     flipped transpose of w (wmode 1, w [Cin,Cout,k,k,k]: input gradient of a stride-1 same conv).
     With `prelu_weight` (wmode 0): returns (y, prelu(y) [+ addend]), both written by the convolution's
-    epilogue.  `addend` without `prelu_weight`: y = conv + bias + addend.  `sparse_y` (with `prelu_weight`,
-    no addend): y is only stored where the slope is <= 1e-6; pass z to `prelu_backward` for the rest."""
+    epilogue.  `addend` without `prelu_weight`: y = conv + bias + addend."""
     x = _need_cuda_f32("x", x, 5)
     w = _need_cuda_f32("w", w, 5)
     B, Cin = x.shape[:2]
@@ -1005,8 +999,8 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
         z = torch.empty_like(y)
         _call("fs_conv3d_fwd_prelu", x.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), _ptr(addend),
               y.data_ptr(), z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride),
-              int(pad), a.numel(), 1 if (sparse_y and addend is None) else 0, _stream(x),
-              algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_fwd")
+              int(pad),
+              a.numel(), _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_fwd")
     return y, z
 
 
@@ -1014,7 +1008,7 @@ def conv3d_tr_supported(cout, k, stride, padding):
     return (tuple(k) == (4, 4, 4) and tuple(stride) == (2, 2, 2) and tuple(padding) == (1, 1, 1) and cout <= 32)
 
 
-def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None, sparse_y=False):
+def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
     """fs_conv3d_tr: ConvTranspose3d(4, 2, 1)(x) with weight w [Cin,Cout,4,4,4]; with out_dhw = the
     input extent of a Conv3d(4, 2, 1) layer and w = that layer's weight, its input gradient.
     With `prelu_weight`: returns (y, prelu(y)), both written by the epilogue.  With `addend` (y's shape):
@@ -1057,8 +1051,8 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None, sparse_y
             raise ValueError("prelu_weight must have 1 or %d elements" % Cout)
         z = torch.empty_like(y)
         _call("fs_conv3d_tr_prelu", x.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), y.data_ptr(),
-              z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, a.numel(), 1 if sparse_y else 0,
-              _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_tr")
+              z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, a.numel(), _stream(x),
+              algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_tr")
     return y, z
 
 
