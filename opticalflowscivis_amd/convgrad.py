@@ -14,13 +14,9 @@ below keep the parameters, state_dict keys and initialisation of their `torch.nn
     PReLU backward     -> fs_prelu_bwd    (also emits the producing convolution's bias gradient)
 
 with fused autograd nodes for the patterns IFBlock is made of: `ConvPReLU` (conv + bias + PReLU),
-`res_unit` (`convblock(x) + x`), and heads that accumulate onto the running flow / mask.  Anything
-outside the supported (kernel, stride, padding) set, non-fp32 or CPU tensors fall through to the
-`torch.nn` implementation.
-
-`FLOWSCI_CONV_WRW` selects the stage: `mfma` (default, the kernels above), `gemm` (first replacement:
-im2col + split-K GEMM for the weight gradient with stock torch ops, everything else on MIOpen),
-`miopen` (stock autograd everywhere).
+`res_unit` (`convblock(x) + x`), and heads that accumulate onto the running flow / mask.  Layers outside
+the supported (kernel, stride, padding, size) set and non-fp32 tensors run the `torch.nn` base class
+(ATen); there is no alternative dispatch mode -- scripts/{fwd,tr,wrw}bench.py hold the MIOpen comparisons.
 """
 import os
 
@@ -28,67 +24,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-# mfma: hand-written implicit-GEMM kernel (csrc/convwrw.hip) where the layer shape is supported, else
-# gemm;  gemm: im2col + split-K GEMM with stock torch ops;  miopen: the stock autograd path.
-_MODE = os.environ.get("FLOWSCI_CONV_WRW", "mfma")
-_COL_BYTES_CAP = int(os.environ.get("FLOWSCI_CONV_COL_GB", "24")) << 30  # im2col scratch per chunk
-
 
 def _tuple(v, nd):
     return tuple(v) if isinstance(v, (tuple, list)) else (v,) * nd
-
-
-def _splitk_matmul(G, Col):
-    """G [M, K] @ Col [K, N] with the (huge) K axis split into batches."""
-    M, K = G.shape
-    N = Col.shape[1]
-    S = 1
-    while S < 256 and K % (2 * S) == 0 and K // (2 * S) >= 2048:
-        S *= 2
-    if S == 1:
-        return G @ Col
-    return torch.bmm(G.view(M, S, K // S).transpose(0, 1), Col.view(S, K // S, N)).sum(0)
-
-
-def _wrw_from_patches(src, g, k, stride, padding):
-    """dW[gc, sc, *k] = sum_{b, o} g[b, gc, o] * src_padded[b, sc, o*stride + koff]
-    src [B,Cs,*in], g [B,Cg,*out] with out = floor((in + 2p - k)/stride) + 1 (extra src rows unused)."""
-    nd = src.dim() - 2
-    if _MODE == "mfma" and src.is_cuda and nd == 3:
-        from . import ops
-        if ops.conv3d_wrw_supported(k, stride, padding):
-            return ops.conv3d_wrw(g, src, k[0], stride[0], padding[0])
-    B, Cs = src.shape[:2]
-    Cg = g.shape[1]
-    out = g.shape[2:]
-    pad = []
-    for p in reversed(padding):
-        pad += [p, p]
-    xp = F.pad(src, pad) if any(padding) else src
-    kk = 1
-    for v in k:
-        kk *= v
-    nout = 1
-    for v in out:
-        nout *= v
-    # chunk the batch so that the im2col scratch stays bounded
-    per_sample = nout * Cs * kk * 4
-    bchunk = max(1, min(B, _COL_BYTES_CAP // max(per_sample, 1)))
-    dW = None
-    for b0 in range(0, B, bchunk):
-        xb = xp[b0:b0 + bchunk]
-        v = xb
-        for d in range(nd):
-            v = v.unfold(2 + d, k[d], stride[d])  # [b, Cs, *n_i, *k]
-        # keep exactly the output positions of the convolution
-        v = v[(slice(None), slice(None)) + tuple(slice(0, o) for o in out)]
-        nb = xb.shape[0]
-        perm = (0,) + tuple(range(2, 2 + nd)) + (1,) + tuple(range(2 + nd, 2 + 2 * nd))
-        col = v.permute(perm).reshape(nb * nout, Cs * kk)            # materialises im2col
-        G = g[b0:b0 + bchunk].permute((1, 0) + tuple(range(2, 2 + nd))).reshape(Cg, nb * nout)
-        part = _splitk_matmul(G, col)
-        dW = part if dW is None else dW + part
-    return dW.view((Cg, Cs) + tuple(k))
 
 
 _MIN_WORKGROUPS = int(os.environ.get("FLOWSCI_CONV_FWD_MIN_WG", "0"))
@@ -99,20 +37,22 @@ def _hip_fwd_ok(x, cout, out_dhw, k, stride, padding):
     """Route this convolution through fs_conv3d_fwd?  Supported (k,s) pairs, fp32 on the GPU.  (The
     workgroup threshold is a tuning hook; the kernel picks quarter-size bricks for small layers and
     beats MIOpen on every IFNet-3D shape measured, scripts/fwdbench.py.)"""
-    if _MODE != "mfma" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5:
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5:
         return False
     from . import ops
     if not ops.conv3d_wrw_supported(k, stride, padding):
         return False
+    if not ops.conv3d_fwd_fits(x.shape[2:], out_dhw, k[0]):
+        return False  # beyond the kernel's 32-bit offsets: the torch.nn base class takes the layer
     return ops.conv3d_fwd_workgroups(x.shape[0], cout, out_dhw, k[0]) >= _MIN_WORKGROUPS
 
 
 def _hip_tr_ok(x, cout, k, stride, padding):
     """Route a ConvTranspose3d(4,2,1) forward / Conv3d(4,2,1) input gradient through fs_conv3d_tr?"""
-    if _MODE != "mfma" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5:
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5:
         return False
     from . import ops
-    if not ops.conv3d_tr_supported(cout, k, stride, padding):
+    if not ops.conv3d_tr_supported(cout, k, stride, padding) or not ops.conv3d_tr_fits(x.shape[2:]):
         return False
     return x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4] >= _MIN_TR_POSITIONS
 
@@ -173,11 +113,19 @@ def _conv_grad_input(x, w, gy, stride, padding, transposed):
 
 
 def _conv_grad_weight(x, w, gy, stride, padding, transposed):
+    """dW[gc, sc, *k] = sum_{b, o} g[b, gc, o] * src_padded[b, sc, o*stride + koff] on fs_conv3d_wrw, with
+    (src, g) = (x, gy) for a convolution and (gy, x) for a transposed one (y = conv_transpose(x, w[Cin,Cout,k]):
+    dW[ci,co,k] = sum x[b,ci,i] * gy[b,co,i*s+k-p]).  Unsupported layers: ATen's convolution backward."""
     k = tuple(w.shape[2:])
-    if transposed:
-        # y = conv_transpose(x, w[Cin,Cout,k]):  dW[ci,co,k] = sum x[b,ci,i] * gy[b,co,i*s+k-p]
-        return _wrw_from_patches(gy, x, k, stride, padding)  # [Cin, Cout, *k]
-    return _wrw_from_patches(x, gy, k, stride, padding)
+    nd = x.dim() - 2
+    src, g = (gy, x) if transposed else (x, gy)
+    if nd == 3 and src.is_cuda and src.dtype == torch.float32:
+        from . import ops
+        if ops.conv3d_wrw_supported(k, stride, padding) and ops.conv3d_wrw_fits(src.shape[2:], g.shape[2:]):
+            return ops.conv3d_wrw(g, src, k[0], stride[0], padding[0])
+    return torch.ops.aten.convolution_backward(
+        gy, x, w, None, list(stride), list(padding), [1] * nd, transposed, [0] * nd, 1,
+        [False, True, False])[1]
 
 
 class _ConvFn(torch.autograd.Function):
@@ -264,7 +212,7 @@ class ConvPReLU(nn.Sequential):
 
     def forward(self, x):
         conv, act = self[0], self[1]
-        if (_use_gemm(x) and x.dim() == 5 and x.dtype == torch.float32 and isinstance(conv, (Conv3d, ConvTranspose3d))
+        if (_hip_autograd(x) and x.dim() == 5 and x.dtype == torch.float32 and isinstance(conv, (Conv3d, ConvTranspose3d))
                 and act.weight.numel() in (1, conv.out_channels) and conv.groups == 1
                 and _tuple(conv.dilation, 3) == (1, 1, 1) and getattr(conv, "padding_mode", "zeros") == "zeros"
                 and _tuple(getattr(conv, "output_padding", 0), 3) == (0, 0, 0)):
@@ -308,7 +256,7 @@ class _ResUnitFn(torch.autograd.Function):
 def res_unit(block, x):
     """`block(x) + x` for block = Sequential(ConvPReLU, ConvPReLU) of stride-1 k=3 "same" Conv3d layers;
     the fused node when the HIP path applies, else the plain expression."""
-    ok = (_use_gemm(x) and x.dim() == 5 and x.dtype == torch.float32 and len(block) == 2 and
+    ok = (_hip_autograd(x) and x.dim() == 5 and x.dtype == torch.float32 and len(block) == 2 and
           all(isinstance(m, ConvPReLU) and isinstance(m[0], Conv3d) and isinstance(m[1], nn.PReLU) for m in block))
     if ok:
         for m in block:
@@ -325,13 +273,14 @@ def res_unit(block, x):
     return _ResUnitFn.apply(x, c1.weight, c1.bias, p1.weight, c2.weight, c2.bias, p2.weight)
 
 
-def _use_gemm(x):
-    return _MODE in ("gemm", "mfma") and x.is_cuda and torch.is_grad_enabled()
+def _hip_autograd(x):
+    """Training on the GPU: run the layer as this module's autograd node (HIP kernels forward and backward)."""
+    return x.is_cuda and torch.is_grad_enabled()
 
 
 class Conv3d(nn.Conv3d):
     def forward(self, x):
-        if not _use_gemm(x):
+        if not _hip_autograd(x):
             st, pd, k = _tuple(self.stride, 3), _tuple(self.padding, 3), tuple(self.weight.shape[2:])
             if x.dim() == 5 and self.padding_mode == "zeros" and self.groups == 1 and _tuple(self.dilation, 3) == (1, 1, 1) \
                     and _hip_fwd_ok(x, self.weight.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
@@ -356,13 +305,13 @@ class ConvTranspose3d(nn.ConvTranspose3d):
         if addend is not None:
             if hip and tuple(addend.shape[2:]) == tuple(2 * n for n in x.shape[2:]) and \
                     addend.shape[1] == self.weight.shape[1] and addend.dtype == torch.float32:
-                if _use_gemm(x):
+                if _hip_autograd(x):
                     return _ConvTrAddFn.apply(x, self.weight, self.bias, addend, st, pd)
                 from . import ops
                 return ops.conv3d_tr(x, self.weight.detach(), None if self.bias is None else self.bias.detach(),
                                      None, None, addend)
             return self.forward(x) + addend
-        if not _use_gemm(x):
+        if not _hip_autograd(x):
             if hip:
                 from . import ops  # inference: same kernel, no autograd node
                 return ops.conv3d_tr(x, self.weight.detach(), None if self.bias is None else self.bias.detach())

@@ -922,6 +922,25 @@ def conv3d_wrw_supported(k, stride, padding):
             0 <= padding[0] < k[0])
 
 
+def _vol(dhw):
+    return int(dhw[0]) * int(dhw[1]) * int(dhw[2])
+
+
+# The convolution kernels address one staged channel chunk with 32-bit byte offsets; these predicates
+# mirror the FS_ERR_SHAPE limits of csrc/conv{fwd,tr,wrw}.hip so that callers can route an oversize layer
+# (e.g. the first / last layers of a 512^3 volume) to the torch.nn base class instead of raising.
+def conv3d_fwd_fits(in_dhw, out_dhw, k):
+    return (4 if k == 3 else 2) * _vol(in_dhw) * 4 < (1 << 32) and _vol(out_dhw) < (1 << 31)
+
+
+def conv3d_tr_fits(in_dhw):
+    return 4 * _vol(in_dhw) * 4 < (1 << 32) and 8 * _vol(in_dhw) < (1 << 31)
+
+
+def conv3d_wrw_fits(src_dhw, g_dhw):
+    return 8 * _vol(src_dhw) * 4 < (1 << 32) and 64 * _vol(g_dhw) * 4 < (1 << 32)
+
+
 def conv3d_wrw(g, src, k, stride, pad):
     """dW[Cg, Cs, k,k,k] = sum_{b,o} g[b,:,o] (x) src[b,:,o*stride + koff - pad]  (fs_conv3d_wrw)."""
     g = _need_cuda_f32("g", g, 5)

@@ -51,8 +51,11 @@ class ModelBase:
     def device(self):
         self.flownet.to(self.dev)
 
-    # ---- checkpoints: the reference saves the (DDP-wrapped) state_dict, so its keys carry a
-    # "module." prefix and load_model keeps only such keys (RIFE.py:44-58).  Accept both forms.
+    # ---- checkpoints (Flow-3D/model/RIFE.py:44-64, same in Flow-2D).  The reference's train.py always
+    # DDP-wraps the net (local_rank defaults to 0), so its .pkl files hold a state_dict whose keys carry the
+    # "module." prefix, and its load_model keeps ONLY keys containing "module.".  The on-disk format here is
+    # therefore always the prefixed one -- also from an unwrapped single-GPU model -- so that either side
+    # loads the other's files; the loader accepts both forms.
     def load_model(self, model_name, path, rank=0):
         if rank > 0:
             return
@@ -70,7 +73,10 @@ class ModelBase:
 
     def save_model(self, model_name, path, rank=0):
         if rank == 0:
-            torch.save(self.flownet.state_dict(), '{}/{}'.format(path, model_name))
+            sd = self.flownet.state_dict()
+            if not isinstance(self.flownet, DDP):
+                sd = {"module." + k: v for k, v in sd.items()}
+            torch.save(sd, '{}/{}'.format(path, model_name))
 
     def _set_lr(self, learning_rate):
         if getattr(self, "_in_capture", False):
@@ -185,50 +191,17 @@ class Model3D(ModelBase):
         }
 
 
-# ---- Laplacian pyramid loss of Flow-2D (Flow-2D/model/laplacian.py:10-88): stock PyTorch ops;
-# it is the reference's dominant 2-D loss term but not on the named hot path.
-def _gauss_kernel(channels, device):
-    k = torch.tensor([[1., 4., 6., 4., 1.], [4., 16., 24., 16., 4.], [6., 24., 36., 24., 6.],
-                      [4., 16., 24., 16., 4.], [1., 4., 6., 4., 1.]], device=device) / 256.
-    return k.repeat(channels, 1, 1, 1)
-
-
-def _conv_gauss(img, kernel):
-    return F.conv2d(F.pad(img, (2, 2, 2, 2), mode='reflect'), kernel, groups=img.shape[1])
-
-
-def _lap_upsample(x, kernel):
-    # zero-interleave to twice the size, then 4 * gauss (laplacian.py:24-31)
-    B, C, H, W = x.shape
-    up = x.new_zeros(B, C, 2 * H, 2 * W)
-    up[:, :, ::2, ::2] = x
-    return _conv_gauss(up, 4 * kernel)
-
-
-def _laplacian_pyramid(img, kernel, max_levels):
-    current, pyr = img, []
-    for _ in range(max_levels):
-        down = _conv_gauss(current, kernel)[:, :, ::2, ::2]
-        up = _lap_upsample(down, kernel)
-        h, w = min(current.shape[2], up.shape[2]), min(current.shape[3], up.shape[3])
-        pyr.append(current[:, :, :h, :w] - up[:, :, :h, :w])
-        current = down
-    return pyr
-
-
 class LapLoss(torch.nn.Module):
+    """Flow-2D/model/laplacian.py:76-88: 5-level Laplacian-pyramid L1 loss, the dominant loss term of
+    Flow-2D.  One pyramid of (input - target), two HIP launches per level
+    (csrc/laplacian.hip); CPU tensors raise ValueError like every other op."""
+
     def __init__(self, max_levels=5, channels=1):
         super().__init__()
         self.max_levels, self.channels = max_levels, channels
 
     def forward(self, input, target):
-        if input.is_cuda:
-            # one pyramid of (input - target), two HIP launches per level (csrc/laplacian.hip)
-            return ops.laploss2d(input, target, self.max_levels)
-        k = _gauss_kernel(self.channels, input.device)
-        a = _laplacian_pyramid(input, k, self.max_levels)
-        b = _laplacian_pyramid(target, k, self.max_levels)
-        return sum(F.l1_loss(x, y) for x, y in zip(a, b))
+        return ops.laploss2d(input, target, self.max_levels)
 
 
 _FLOW_GT_DATASETS = ("pipedcylinder2d", "cylinder2d", "FluidSimML2d", "rectangle2d", "lbs2d")

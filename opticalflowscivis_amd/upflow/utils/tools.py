@@ -71,16 +71,9 @@ class tools:
         def __call__(self, flow_f, flow_b, scale=1):
             if self.occ_type != 'for_back_check':
                 raise ValueError('not implemented')  # as in the reference (:567)
-            if flow_f.is_cuda:
-                return ops.occ_check2d(flow_f, flow_b, self.occ_alpha_1, self.occ_alpha_2, scale,
-                                       self.obj_out_all)
-            if self.obj_out_all == 'out':
-                return self.torch_outgoing_occ_check(flow_f), self.torch_outgoing_occ_check(flow_b)
-            occ_1, occ_2 = self._forward_backward_occ_check(flow_f, flow_b, scale)
-            if self.obj_out_all == 'all':
-                return occ_1, occ_2
-            return (self.torch_get_obj_occ_check(occ_1, self.torch_outgoing_occ_check(flow_f)),
-                    self.torch_get_obj_occ_check(occ_2, self.torch_outgoing_occ_check(flow_b)))
+            # one launch; CPU tensors raise ValueError like every other op (no CPU fallback)
+            return ops.occ_check2d(flow_f, flow_b, self.occ_alpha_1, self.occ_alpha_2, scale,
+                                   self.obj_out_all)
 
         def _forward_backward_occ_check(self, flow_fw, flow_bw, scale=1):
             def mag(x):  # length_sq_v0 (:596-601): sum_c |x_c|

@@ -75,7 +75,29 @@ def _occ_stock():
 
 row("occ_check 'obj' stock ops + HIP warps", t(_occ_stock), 24 * npx)
 # §8f.3: Laplacian-pyramid loss at C2 (fwd + bwd), fused vs the stock-op pyramid
-from opticalflowscivis_amd import rife as _rife
+import torch.nn.functional as _F
+
+
+def _stock_gauss(img, kernel):
+    return _F.conv2d(_F.pad(img, (2, 2, 2, 2), mode='reflect'), kernel, groups=img.shape[1])
+
+
+def _stock_pyramid(img, levels):
+    """The stock-op Laplacian pyramid (the comparison arm only; the product has no such path)."""
+    k1 = torch.tensor([1., 4., 6., 4., 1.], device=img.device)
+    kernel = (k1[:, None] * k1[None, :] / 256.).repeat(img.shape[1], 1, 1, 1)
+    cur, pyr = img, []
+    for _ in range(levels):
+        down = _stock_gauss(cur, kernel)[:, :, ::2, ::2]
+        up = cur.new_zeros(down.shape[0], down.shape[1], 2 * down.shape[2], 2 * down.shape[3])
+        up[:, :, ::2, ::2] = down
+        up = _stock_gauss(up, 4 * kernel)
+        h, w = min(cur.shape[2], up.shape[2]), min(cur.shape[3], up.shape[3])
+        pyr.append(cur[:, :, :h, :w] - up[:, :, :h, :w])
+        cur = down
+    return pyr
+
+
 a = torch.rand(16, 1, 160, 224, device=dev, requires_grad=True)
 b = torch.rand(16, 1, 160, 224, device=dev)
 
@@ -86,8 +108,7 @@ def _lap_hip():
 
 
 def _lap_stock():
-    k = _rife._gauss_kernel(1, a.device)
-    pa, pb = _rife._laplacian_pyramid(a, k, 5), _rife._laplacian_pyramid(b, k, 5)
+    pa, pb = _stock_pyramid(a, 5), _stock_pyramid(b, 5)
     loss = sum(torch.nn.functional.l1_loss(x, y) for x, y in zip(pa, pb))
     (g,) = torch.autograd.grad(loss, [a])
     return g

@@ -11,6 +11,7 @@ Usage (each group imports a different reference package layout, so one process p
     python tests/golden/make_golden.py upflow_e2e   # UPFlow_net forward losses / flows / grads
     python tests/golden/make_golden.py rife_next    # Flow-2D LapLoss
     python tests/golden/make_golden.py upflow_next  # occ_check_model, normalize_features
+    python tests/golden/make_golden.py ckpt         # Model.save_model / load_model on-disk format
     python tests/golden/make_golden.py all          # runs the groups above as subprocesses
 
 Third-party modules the reference imports at module scope but that are absent from this
@@ -386,7 +387,59 @@ def upflow_next():
     print("wrote upflow_next.npz", len(store), "arrays")
 
 
-GROUPS = dict(rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
+# ------------------------------------------------------------------------------------------
+def ckpt():
+    """SURVEY §8f.4 second half: the on-disk checkpoint format of Flow-3D / Flow-2D `Model.save_model`
+    (RIFE.py:61-64) -- key list, shapes, dtypes, and the full values of the small tensors -- for the
+    unwrapped model (local_rank = -1) and for the DDP-wrapped one train.py always builds (RIFE.py:33-34;
+    here wrapped on CPU over a one-rank gloo group, because `device_ids=[local_rank]` needs a GPU), plus
+    what the reference's own `load_model` (RIFE.py:44-58) accepts."""
+    import tempfile
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    _install_stubs()
+    nd = int(os.environ.get("CKPT_ND", "3"))
+    sys.path[:0] = [REF + "/Flow-%dD" % nd, REF]
+    import model.RIFE as R
+    import model.warplayer as WL
+    R.device = torch.device("cpu")
+    WL.device = torch.device("cpu")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    store = {}
+    with tempfile.TemporaryDirectory() as d:
+        torch.manual_seed(1234)
+        m = _quiet(R.Model, local_rank=-1)
+        _quiet(m.save_model, "plain.pkl", d)
+        plain = torch.load(os.path.join(d, "plain.pkl"))
+        m.flownet = DDP(m.flownet)  # what Model(local_rank >= 0) does (RIFE.py:33-34)
+        _quiet(m.save_model, "ddp.pkl", d)
+        wrapped = torch.load(os.path.join(d, "ddp.pkl"))
+        store["plain_keys"] = np.array(list(plain.keys()))
+        store["ddp_keys"] = np.array(list(wrapped.keys()))
+        store["shapes"] = np.array(["x".join(str(int(n)) for n in v.shape) for v in wrapped.values()])
+        store["dtypes"] = np.array([str(v.dtype) for v in wrapped.values()])
+        store["sums"] = np.array([float(v.double().sum()) for v in wrapped.values()])
+        small = [k for k, v in wrapped.items() if v.numel() <= 128]
+        store["small_keys"] = np.array(small)
+        for i, k in enumerate(small):
+            store["small_%d" % i] = _np(wrapped[k])
+        # the reference's loader: a DDP-wrapped model loads the DDP file; the plain file is filtered to an
+        # empty dict (keys without "module.") and load_state_dict raises
+        _quiet(m.load_model, "ddp.pkl", d)
+        try:
+            _quiet(m.load_model, "plain.pkl", d)
+            store["ref_loads_plain"] = np.array(1)
+        except Exception:
+            store["ref_loads_plain"] = np.array(0)
+    dist.destroy_process_group()
+    np.savez_compressed(os.path.join(OUT, "ckpt_flow%dd.npz" % nd), **store)
+    print("wrote ckpt_flow%dd.npz:" % nd, len(store["ddp_keys"]), "keys,", len(small), "small tensors; reference "
+          "loads its own unprefixed file:", int(store["ref_loads_plain"]))
+
+
+GROUPS = dict(ckpt=ckpt, rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
               upflow_e2e=upflow_e2e)
 
 if __name__ == "__main__":
@@ -394,6 +447,11 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if which == "all":
         for g in GROUPS:
+            if g == "ckpt":
+                for nd in ("3", "2"):
+                    subprocess.check_call([sys.executable, os.path.abspath(__file__), g],
+                                          env=dict(os.environ, CKPT_ND=nd))
+                continue
             subprocess.check_call([sys.executable, os.path.abspath(__file__), g])
     else:
         GROUPS[which]()
