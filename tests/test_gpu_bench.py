@@ -10,12 +10,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_at_cpu_size"}
 
 
 def test_bench_json_contract():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "32", "--batch", "1", "--steps", "2",
-           "--warmup", "1", "--cpu-size", "16"]
+           "--warmup", "1", "--cpu-size", "16", "32"]
     r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
@@ -34,3 +34,10 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] in ("port", "reference")
     assert cb["value"] > 0 and cb["cores"] >= 1
+    assert [x["size"] for x in cb["samples"]] == [16, 32]  # one bounded sample per --cpu-size edge
+    # the bench line's own parity witness: the GPU model against the oracle on the CPU samples' batches
+    pw = d["parity_at_cpu_size"]
+    assert {"loss_gpu", "loss_oracle", "rel", "tolerance_rel", "sizes"} <= set(pw)
+    assert pw["rel"] <= pw["tolerance_rel"] == 5e-4
+    assert abs(pw["loss_gpu"] - pw["loss_oracle"]) <= 5e-4 * abs(pw["loss_oracle"])
+    assert rf["measured"].startswith("HIP events on the launch stream inside the timed region")

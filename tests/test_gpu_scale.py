@@ -1,0 +1,155 @@
+"""-m gpu: parity at (and towards) the bench scale -- VERDICT r1 "next round" item 1.
+
+* the full Flow-3D train step, product vs CPU oracle, at 128^3 (the size bench.py's cpu_baseline / parity
+  witness runs at) and on the C5 workload (5Jets-like density, 64^3);
+* the IFNet-3D convolution kernels at the REAL layer shapes of the 2 x 256^3 step (conv0a 11 -> 32 with
+  128^3 out, the flow head's last deconv 32 -> 6 with 256^3 out) against MIOpen and against directly
+  evaluated weight-gradient taps;
+* Flow-2D at an extent where IFNet crops its outputs below the input (rife2d_photometric).
+north_star tolerances: losses 5e-4 relative, flow 1e-4 px, interpolation PSNR 0.01 dB."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pair(nd, seed=1234):
+    """(product model, oracle model) with identical seed-`seed` weights."""
+    from oracle.ifnet_ref import ModelRef
+    if nd == 3:
+        from opticalflowscivis_amd.flow3d.model.RIFE import Model
+    else:
+        from opticalflowscivis_amd.flow2d.model.RIFE import Model
+    torch.manual_seed(seed)
+    m = Model(local_rank=-1, device=DEV)
+    torch.manual_seed(seed)
+    o = ModelRef(nd)
+    for (ka, a), (kb, b) in zip(m.flownet.state_dict().items(), o.flownet.state_dict().items()):
+        assert ka == kb and torch.equal(a.cpu(), b), ka  # same seed => same weights on both sides
+    return m, o
+
+
+def _check_step(m, o, data, nd, extra=()):
+    from opticalflowscivis_amd.data import synthetic
+    imgs, gt = data[:, :2].contiguous(), data[:, 2:3].contiguous()
+    if nd == 3:
+        po, oi = o.update(imgs, gt, learning_rate=1e-4, training=True)
+        pp, pi = m.update(imgs.to(DEV), gt.to(DEV), learning_rate=1e-4, training=True)
+    else:
+        po, oi = o.update(imgs, gt, learning_rate=1e-4)
+        pp, pi = m.update(imgs.to(DEV), gt.to(DEV), "droplet2d", learning_rate=1e-4, training=True)
+    torch.cuda.synchronize()
+    for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G") + tuple(extra):
+        a, b = float(pi[k].detach()), float(oi[k].detach())
+        assert abs(a - b) <= 5e-4 * max(abs(b), 1e-6), (k, a, b)
+    fo = oi["flow"].detach()
+    fo = fo[:, :2] if nd == 2 else fo
+    assert pi["flow"].shape == fo.shape
+    assert float((pi["flow"].detach().cpu() - fo).abs().max()) < 1e-4
+    gtc = gt[(slice(None), slice(None)) + tuple(slice(0, n) for n in po.shape[2:])]
+    assert pp.shape == po.shape
+    assert abs(synthetic.psnr(pp.detach().cpu(), gtc) - synthetic.psnr(po.detach(), gtc)) < 0.01
+    # the weights after the AdamW step: per-tensor sums track the oracle's
+    ps = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
+    os_ = np.array([float(p.detach().double().sum()) for p in o.flownet.parameters()])
+    np.testing.assert_allclose(ps, os_, rtol=1e-4, atol=5e-3)
+
+
+def test_flow3d_step_vs_oracle_128():
+    """Droplet-3D, B = 1 at 128^3: every layer runs the full-size kernel instantiations of the bench."""
+    from opticalflowscivis_amd.data import synthetic
+    m, o = _pair(3)
+    _check_step(m, o, synthetic.droplet3d_batch(1, 128, seed=1234), 3)
+
+
+def test_flow3d_step_vs_oracle_jets_c5():
+    """BASELINE config C5's workload (5Jets-like smooth density field), per-GPU batch 2 at 64^3."""
+    from opticalflowscivis_amd.data import synthetic
+    m, o = _pair(3)
+    _check_step(m, o, synthetic.jets3d_batch(2, 64, seed=1234), 3)
+
+
+def test_flow2d_step_vs_oracle_cropped_extent():
+    """H = 146: floor(H/4) % 4 == 0 and H % 4 != 0, so IFNet's outputs are 144 rows and the photometric
+    term bilinearly resizes the frames to the warped extent (Flow-2D/model/RIFE.py:267)."""
+    from opticalflowscivis_amd.data import synthetic
+    m, o = _pair(2)
+    data = synthetic.droplet2d_batch(2, 146, 96, seed=5, radius=(10, 20))
+    _check_step(m, o, data, 2, extra=("loss_photo",))
+
+
+# ---- the convolution kernels at the real layer shapes of the 2 x 256^3 step --------------------------
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+
+
+def _wrw_taps(src, g, k, taps):
+    """dW[:, ci, kz, ky, kx] evaluated directly (fp64 sums of strided slices) for a few (ci, kz, ky, kx):
+    dW[co] = sum_{b,o} g[b,co,o] * src_pad[b,ci,2o + k - 1]   (k4 s2 p1)."""
+    B, Cs, D, H, W = src.shape
+    Do, Ho, Wo = g.shape[2:]
+    out = {}
+    for (ci, kz, ky, kx) in taps:
+        xs = F.pad(src[:, ci:ci + 1], (1, 1, 1, 1, 1, 1))[:, :, kz:kz + 2 * Do:2, ky:ky + 2 * Ho:2, kx:kx + 2 * Wo:2]
+        out[(ci, kz, ky, kx)] = (g.double() * xs.double()).sum(dim=(0, 2, 3, 4))
+    return out
+
+
+def test_conv0a_256_step_shape():
+    """conv0a of the scale-1 blocks: Conv3d(11 -> 32, k4 s2 p1) on [2, 11, 256^3] -> [2, 32, 128^3]:
+    forward vs MIOpen, input gradient (fs_conv3d_tr) vs MIOpen's transposed convolution, weight gradient
+    (fs_conv3d_wrw) vs directly evaluated taps."""
+    from opticalflowscivis_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(2, 11, 256, 256, 256, device=DEV)
+    w = torch.randn(32, 11, 4, 4, 4, device=DEV) / (11 * 64) ** 0.5
+    b = torch.randn(32, device=DEV)
+    y = ops.conv3d_fwd(x, w, b, 4, 2, 1, 0)
+    ref = F.conv3d(x, w, b, 2, 1)
+    assert y.shape == ref.shape == (2, 32, 128, 128, 128)
+    assert _rel(y, ref) < 2e-5
+    del ref
+    gy = torch.randn_like(y)
+    del y
+    gx = ops.conv3d_tr(gy, w, None, x.shape[2:])
+    ref = F.conv_transpose3d(gy, w, None, 2, 1)
+    assert gx.shape == ref.shape == x.shape
+    assert _rel(gx, ref) < 2e-5
+    del gx, ref
+    gw = ops.conv3d_wrw(gy, x, 4, 2, 1)
+    taps = [(0, 0, 0, 0), (10, 3, 3, 3), (5, 1, 2, 0), (7, 2, 0, 3)]
+    for (ci, kz, ky, kx), want in _wrw_taps(x, gy, 4, taps).items():
+        got = gw[:, ci, kz, ky, kx].double()
+        assert float((got - want).abs().max()) < 2e-4 * float(want.abs().max()) + 0.05, (ci, kz, ky, kx)
+
+
+def test_flow_head_256_step_shape():
+    """Last layer of the flow head at scale 1: ConvTranspose3d(32 -> 6, k4 s2 p1) on [2, 32, 128^3] ->
+    [2, 6, 256^3]: forward (fs_conv3d_tr) vs MIOpen, input gradient (fs_conv3d_fwd on grad_out) vs MIOpen's
+    strided convolution, weight gradient vs directly evaluated taps."""
+    from opticalflowscivis_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(2, 32, 128, 128, 128, device=DEV)
+    w = torch.randn(32, 6, 4, 4, 4, device=DEV) / (32 * 8) ** 0.5
+    b = torch.randn(6, device=DEV)
+    y = ops.conv3d_tr(x, w, b)
+    ref = F.conv_transpose3d(x, w, b, 2, 1)
+    assert y.shape == ref.shape == (2, 6, 256, 256, 256)
+    assert _rel(y, ref) < 2e-5
+    del ref
+    gy = torch.randn_like(y)
+    del y
+    gx = ops.conv3d_fwd(gy, w, None, 4, 2, 1, 0)  # the weight read as [out = 32][in = 6]
+    ref = F.conv3d(gy, w, None, 2, 1)
+    assert gx.shape == ref.shape == x.shape
+    assert _rel(gx, ref) < 2e-5
+    del gx, ref
+    gw = ops.conv3d_wrw(x, gy, 4, 2, 1)  # transposed layer: (g, src) = (x, grad_out) -> [32, 6, 4,4,4]
+    assert gw.shape == w.shape
+    taps = [(0, 0, 0, 0), (5, 3, 3, 3), (2, 1, 2, 0), (3, 2, 0, 3)]
+    for (ci, kz, ky, kx), want in _wrw_taps(gy, x, 4, taps).items():
+        got = gw[:, ci, kz, ky, kx].double()
+        assert float((got - want).abs().max()) < 2e-4 * float(want.abs().max()) + 0.05, (ci, kz, ky, kx)

@@ -81,9 +81,21 @@ def test_warp2d_pwc_golden(ops, golden):
     legal = ((o - unm).abs() < OUT_ATOL) | (o.abs() < OUT_ATOL)
     assert bool(legal.all())
     gx, gf = torch.autograd.grad((out * T(g["pwcmask_G"])).sum(), [x, f])
-    assert float(((gx.cpu() - torch.from_numpy(g["pwcmask_gx"])).abs()).max()) < 1.0  # scatter target
     gerr = (gf.cpu() - torch.from_numpy(g["pwcmask_gf"])).abs()
     assert float((gerr * sure).max()) < GRAD_ATOL
+    # grad_in is a scatter: a borderline pixel whose mask flipped adds / removes its four taps, so the
+    # golden total is only comparable after taking those pixels out of the upstream gradient on BOTH
+    # sides.  The mask has no derivative, so with G * sure the two gradients must agree to fp32 noise;
+    # the oracle side is the golden-pinned restatement (tests/test_oracle_golden.py).
+    Gs = torch.from_numpy(g["pwcmask_G"]) * sure
+    xo, fo = xc.clone().requires_grad_(), fc.clone().requires_grad_()
+    gx_ref, gf_ref = torch.autograd.grad((owarps.warp2d_pwc_ref(xo, fo, True) * Gs).sum(), [xo, fo])
+    gx2, gf2 = torch.autograd.grad((ops.warp2d_pwc(x, f, with_mask=True) * Gs.to(DEV)).sum(), [x, f])
+    assert maxerr(gx2, gx_ref) < GRAD_ATOL
+    assert maxerr(gf2, gf_ref) < GRAD_ATOL
+    # and the golden total itself: what differs is bounded by the borderline pixels' own contributions
+    assert float((gx.cpu() - torch.from_numpy(g["pwcmask_gx"])).abs().sum()) <= \
+        float((torch.from_numpy(g["pwcmask_G"]).abs() * (~sure)).sum()) + GRAD_ATOL * gx.numel()
 
 
 def test_warp2d_dilated_golden(ops, golden):
