@@ -69,6 +69,37 @@ int fs_warp3d_pair_bwd(const float* img0, const float* img1, const float* flow6,
                        const float* grad_out0, const float* grad_out1,
                        float* grad_img0, float* grad_img1, float* grad_flow6,
                        int B, int C, const int* in_dhw, int D, int H, int W, fs_stream_t stream);
+/* The same with the gradient that reaches the flow from its OTHER consumers summed in by the launch:
+ * grad_flow6 = d(warps)/d(flow) + grad_flow_add (nullable; may BE grad_flow6 -- in-place accumulation).
+ * An IFNet block's flow feeds the warp, the next block's input and accumulation, and the distillation
+ * term (Flow-3D/model/IFNet.py:190-191, 210-214, 261); autograd would add the warp's share to the others'
+ * in a separate pass over 805 MB tensors. */
+int fs_warp3d_pair_bwd_acc(const float* img0, const float* img1, const float* flow6,
+                           const float* grad_out0, const float* grad_out1,
+                           float* grad_img0, float* grad_img1,
+                           const float* grad_flow_add, float* grad_flow6,
+                           int B, int C, const int* in_dhw, int D, int H, int W, fs_stream_t stream);
+
+/* f1: "upsample flow x scale -> warp" in ONE kernel -- Flow-3D/model/IFNet.py:118
+ *   flow = F.interpolate(flow_d, scale_factor=s, mode="trilinear", align_corners=False) * s   (+ the running
+ *   flow of :213-214) followed by :190-191 warp(img0, flow[:, :3]), warp(img1, flow[:, 3:6]).
+ * delta [B,6,Ds,Hs,Ws] is the head's output at the block's working resolution; prev_flow (nullable),
+ * flow_out, out0, out1 live at factor x that extent (factor 2 or 4).  flow_out = prev_flow + scale *
+ * upsample(delta) is formed per tile in registers, written once (it has three more consumers) and
+ * handed to the warp without a second trip through HBM; values are bit-identical to
+ * fs_upsample3d_scale_add + fs_warp3d_pair_fwd.
+ * bwd: grad_flow_total = d(warps)/d(flow_out) + grad_flow_add (gradient reaching flow_out from its other
+ * consumers; nullable; may alias grad_flow_total) -- also the gradient of prev_flow -- and
+ * grad_delta = scale * adjoint_upsample(grad_flow_total).  ws: B*6*(D*H*Ws + D*Hs*Ws) floats. */
+int fs_upsample_warp3d_pair_fwd(const float* img0, const float* img1, const float* delta,
+                                const float* prev_flow, float* flow_out, float* out0, float* out1,
+                                int B, int C, const int* in_dhw, int Ds, int Hs, int Ws, int factor,
+                                float scale, fs_stream_t stream);
+int fs_upsample_warp3d_pair_bwd(const float* img0, const float* img1, const float* flow6,
+                                const float* grad_out0, const float* grad_out1,
+                                const float* grad_flow_add, float* grad_flow_total, float* grad_delta,
+                                float* ws, int B, int C, const int* in_dhw, int Ds, int Hs, int Ws,
+                                int factor, float scale, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 2-D bilinear backward warps.  in [B,C,H,W], flow [B,2,H,W] (ch0 = x, ch1 = y),
@@ -91,22 +122,28 @@ int fs_warp3d_pair_bwd(const float* img0, const float* img1, const float* flow6,
  */
 enum { FS_WARP2D_RIFE = 0, FS_WARP2D_PWC = 1, FS_WARP2D_PHOTO = 2, FS_WARP2D_DILATED = 3 };
 
+/* H, W = extent of the flow (= of the output).  `in_hw` = {Hin, Win} (HOST pointer to 2 ints) or NULL
+ * when the image has the flow's extent; only FS_WARP2D_RIFE defines the other case (the reference builds
+ * its grid from the flow's shape and its divisors from the input's, warplayer.py:10-20; IFNet-2D hits it
+ * for extents where its blocks return fewer rows than the frames have, e.g. H = 146). */
 int fs_warp2d_fwd(const float* in, const float* flow, const float* start, float* out,
-                  int B, int C, int H, int W, int mode, int with_mask, fs_stream_t stream);
+                  int B, int C, const int* in_hw, int H, int W, int mode, int with_mask,
+                  fs_stream_t stream);
 int fs_warp2d_bwd(const float* in, const float* flow, const float* start,
                   const float* grad_out, float* grad_in, float* grad_flow,
-                  int B, int C, int H, int W, int mode, int with_mask, fs_stream_t stream);
+                  int B, int C, const int* in_hw, int H, int W, int mode, int with_mask,
+                  fs_stream_t stream);
 
 /* Pair form for the IFNet call site (Flow-2D/model/IFNet.py:191-192, 230-231):
  *   warp(img0, flow[:, :2]); warp(img1, flow[:, 2:4])  with flow4 [B,4,H,W] used in place.
  * No mask, no start. */
 int fs_warp2d_pair_fwd(const float* img0, const float* img1, const float* flow4,
                        float* out0, float* out1,
-                       int B, int C, int H, int W, int mode, fs_stream_t stream);
+                       int B, int C, const int* in_hw, int H, int W, int mode, fs_stream_t stream);
 int fs_warp2d_pair_bwd(const float* img0, const float* img1, const float* flow4,
                        const float* grad_out0, const float* grad_out1,
                        float* grad_img0, float* grad_img1, float* grad_flow4,
-                       int B, int C, int H, int W, int mode, fs_stream_t stream);
+                       int B, int C, const int* in_hw, int H, int W, int mode, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * f2. Forward-backward occlusion check + outgoing mask, fused.
@@ -262,6 +299,28 @@ int fs_distill_bwd(const float* merged_i, const float* merged_tea, const float* 
 int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws, int B, int C,
                     int Din, int Hin, int Win, int Dout, int Hout, int Wout,
                     int factor, int upsample, fs_stream_t stream);
+/* grad_in = scale * adjoint(grad_out): the `* scale` of `F.interpolate(flow_d, ...) * scale` (IFNet.py:118)
+ * folded into the last separable pass.  scale != 1 needs upsample = 1 and ws != NULL (FS_ERR_ARG otherwise). */
+int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, float* ws, int B, int C,
+                           int Din, int Hin, int Win, int Dout, int Hout, int Wout,
+                           int factor, int upsample, float scale, fs_stream_t stream);
+
+/* Forward of the down-scaling side (Flow-3D/model/IFNet.py:85, 88):
+ *   out = scale * F.interpolate(in, scale_factor = 1/factor, mode="trilinear", align_corners=False)
+ * in [B,C,Din,Hin,Win] -> out [B,C,Din/factor,...] (floor), factor in {2, 4}; `scale` carries the flow's
+ * `* 1. / scale` (:88).  ATen's arithmetic and summation order (every lambda is 1/2: bit-identical to ATen).  Adjoint: fs_interp3d_bwd
+ * with upsample = 0. */
+int fs_downsample3d_fwd(const float* in, float* out, int B, int C, int Din, int Hin, int Win,
+                        int factor, float scale, fs_stream_t stream);
+
+/* The 2-D pair (Flow-2D/model/IFNet.py:89, 92, 115-116): out = scale * F.interpolate(in, scale_factor =
+ * factor (upsample = 1) or 1/factor (upsample = 0), mode="bilinear", align_corners=False), factor in {2, 4},
+ * in [B,C,Hin,Win] -> out [B,C,Hout,Wout] with out = in*factor or floor(in/factor); ATen's arithmetic.
+ * bwd: grad_in = scale * adjoint(grad_out), a gather per input pixel (no atomics, reproducible). */
+int fs_resize2d_fwd(const float* in, float* out, int B, int C, int Hin, int Win, int Hout, int Wout,
+                    int factor, int upsample, float scale, fs_stream_t stream);
+int fs_resize2d_bwd(const float* grad_out, float* grad_in, int B, int C, int Hin, int Win, int Hout,
+                    int Wout, int factor, int upsample, float scale, fs_stream_t stream);
 
 /* Forward companion for the up-sampling side (Flow-3D/model/IFNet.py:118-119 followed by the
  * accumulation at :213-214 / :228-229):

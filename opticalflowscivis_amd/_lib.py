@@ -30,8 +30,15 @@ SIGNATURES = {
     "fs_warp3d_bwd": [_f32p] * 5 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_warp3d_pair_fwd": [_f32p] * 5 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_warp3d_pair_bwd": [_f32p] * 8 + [_int, _int, _intp, _int, _int, _int, _stream],
-    "fs_warp2d_pair_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
-    "fs_warp2d_pair_bwd": [_f32p] * 8 + [_int] * 5 + [_stream],
+    "fs_warp3d_pair_bwd_acc": [_f32p] * 9 + [_int, _int, _intp, _int, _int, _int, _stream],
+    "fs_upsample_warp3d_pair_fwd": [_f32p] * 7 + [_int, _int, _intp, _int, _int, _int, _int, _float, _stream],
+    "fs_upsample_warp3d_pair_bwd": [_f32p] * 9 + [_int, _int, _intp, _int, _int, _int, _int, _float, _stream],
+    "fs_warp2d_pair_fwd": [_f32p] * 5 + [_int, _int, _intp, _int, _int, _int, _stream],
+    "fs_warp2d_pair_bwd": [_f32p] * 8 + [_int, _int, _intp, _int, _int, _int, _stream],
+    "fs_interp3d_bwd_scaled": [_f32p] * 3 + [_int] * 10 + [_float, _stream],
+    "fs_downsample3d_fwd": [_f32p] * 2 + [_int] * 6 + [_float, _stream],
+    "fs_resize2d_fwd": [_f32p] * 2 + [_int] * 8 + [_float, _stream],
+    "fs_resize2d_bwd": [_f32p] * 2 + [_int] * 8 + [_float, _stream],
     "fs_occ_check2d": [_f32p] * 4 + [_int] * 3 + [_float, _float, _int, _stream],
     "fs_laploss2d_sizes": [_int] * 4 + [_i64p] * 3,
     "fs_laploss2d_fwd": [_f32p] * 5 + [_int] * 4 + [_stream],
@@ -60,14 +67,14 @@ SIGNATURES = {
     "fs_distill_fwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_distill_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_interp3d_bwd": [_f32p] * 3 + [_int] * 10 + [_stream],
-        "fs_prelu_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
+    "fs_prelu_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_corr3d_fwd": [_f32p] * 3 + [_int] * 6 + [_stream],
     "fs_corr3d_bwd": [_f32p] * 5 + [_int] * 6 + [_stream],
     "fs_conv3d_wrw": [_f32p] * 3 + [_int] * 12 + [_stream],
     "fs_wssim_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_wssim_bwd": [_f32p] * 6 + [_int] * 5 + [_stream],
-    "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _stream],
-    "fs_warp2d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
+    "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _intp, _int, _int, _int, _int, _stream],
+    "fs_warp2d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _intp, _int, _int, _int, _int,
                       _stream],
 }
 _RESTYPES = {"fs_error_string": ctypes.c_char_p, "fs_conv3d_fwd_ws_floats": ctypes.c_longlong,

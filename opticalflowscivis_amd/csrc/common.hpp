@@ -43,6 +43,43 @@ __device__ __forceinline__ float clip_border(float x, int size, float* gmul) {
   return x;
 }
 
+// One output row segment of ATen's upsample_trilinear3d (align_corners=False, scale factor given): the N
+// consecutive outputs x_first .. x_first+N-1 of the row whose z / y source rows and lambdas the caller has
+// resolved (s00 = row (z0, y0), s01 = (z0, y0+yp), s10 = (z0+zp, y0), s11 = (z0+zp, y0+yp) of the small
+// volume, Wi its row length, rs = 1 / scale_factor), times `scale`.  ATen's index / lambda arithmetic and
+// summation order, FMA contraction off: shared by fs_upsample3d_scale_add and the fused up-sample + warp
+// kernel so that both write bit-identical flows.
+template <int N>
+__device__ __forceinline__ void trilinear_up_row(const float* __restrict__ s00, const float* __restrict__ s01,
+                                                 const float* __restrict__ s10, const float* __restrict__ s11,
+                                                 float lz0, float lz1, float ly0, float ly1, float rs, int x_first,
+                                                 int Wi, float scale, float (&o)[N]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int x = x_first + i;
+    float sx = rs * ((float)x + 0.5f) - 0.5f;
+    sx = sx < 0.f ? 0.f : sx;
+    const int x0 = (int)sx;
+    const int xp = (x0 < Wi - 1) ? 1 : 0;
+    const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+    const float v = lz0 * (ly0 * (lx0 * s00[x0] + lx1 * s00[x0 + xp]) + ly1 * (lx0 * s01[x0] + lx1 * s01[x0 + xp])) +
+                    lz1 * (ly0 * (lx0 * s10[x0] + lx1 * s10[x0 + xp]) + ly1 * (lx0 * s11[x0] + lx1 * s11[x0 + xp]));
+    o[i] = v * scale;
+  }
+}
+
+// source index i0, "+1 exists" flag and lambdas of one output index along one axis (same arithmetic)
+__device__ __forceinline__ void trilinear_axis(int o, int n_in, float rs, int& i0, int& ip, float& l0, float& l1) {
+#pragma clang fp contract(off)
+  float s = rs * ((float)o + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  ip = (i0 < n_in - 1) ? 1 : 0;
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -14,6 +14,13 @@
 //   integer down-sampling by s: candidates o in [i/s - 1, i/s + 1]        -> NC = 3
 // No atomics, bitwise reproducible.  HBM: reads grad_out once (overlapping windows are L1/L2 hits),
 // writes grad_in once.
+//
+// Forward resizes: `fs_downsample3d_fwd` (IFBlock's input / flow down-scaling,
+// Flow-3D/model/IFNet.py:85,88, with the `* 1/scale` of the flow folded in), `fs_upsample3d_scale_add`
+// (:118-119 with the running-flow accumulation) and the 2-D bilinear pair `fs_resize2d_{fwd,bwd}`
+// (Flow-2D/model/IFNet.py:89,92,115-116) all evaluate ATen's area_pixel_compute_source_index /
+// lambda arithmetic in ATen's summation order with FMA contraction off (down-scaling: every lambda is 1/2 and
+// the result is bit-identical to F.interpolate; up-scaling: within an ulp of ATen's builds, which may contract).
 #include "common.hpp"
 
 namespace {
@@ -143,7 +150,7 @@ template <int NC>
 __global__ __launch_bounds__(256) void interp_axis_adjoint_kernel(const float* __restrict__ g,
                                                                   float* __restrict__ out,
                                                                   long long outer, int n_out, int n_in,
-                                                                  int inner, int s, float rs) {
+                                                                  int inner, int s, float rs, float oscale) {
   const long long total = outer * n_in * inner;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int in_i = (int)(e % inner);
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void interp_axis_adjoint_kernel(const float* _
       const int o = min(max(o0 + k, 0), n_out - 1);
       acc = fmaf(w, col[(long long)o * inner], acc);
     }
-    out[e] = acc;
+    out[e] = acc * oscale;
   }
 }
 
@@ -213,29 +220,16 @@ __global__ __launch_bounds__(256) void upsample3d_scale_add_v4_kernel(const floa
     const long long t = row / p.Ho;
     const int z = (int)(t % p.Do);
     const long long bc = t / p.Do;
-    float sz = p.rs * ((float)z + 0.5f) - 0.5f, sy = p.rs * ((float)y + 0.5f) - 0.5f;
-    sz = sz < 0.f ? 0.f : sz; sy = sy < 0.f ? 0.f : sy;
-    const int z0 = (int)sz, y0 = (int)sy;
-    const int zp = (z0 < p.Di - 1) ? 1 : 0, yp = (y0 < p.Hi - 1) ? 1 : 0;
-    const float lz1 = sz - (float)z0, ly1 = sy - (float)y0;
-    const float lz0 = 1.f - lz1, ly0 = 1.f - ly1;
+    int z0, zp, y0, yp;
+    float lz0, lz1, ly0, ly1;
+    fs::trilinear_axis(z, p.Di, p.rs, z0, zp, lz0, lz1);
+    fs::trilinear_axis(y, p.Hi, p.rs, y0, yp, ly0, ly1);
     const float* s00 = small + bc * nin + ((long long)z0 * p.Hi + y0) * p.Wi;
     const float* s01 = s00 + yp * p.Wi;
     const float* s10 = s00 + (long long)zp * p.Hi * p.Wi;
     const float* s11 = s10 + yp * p.Wi;
     float o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = 4 * x4 + i;
-      float sx = p.rs * ((float)x + 0.5f) - 0.5f;
-      sx = sx < 0.f ? 0.f : sx;
-      const int x0 = (int)sx;
-      const int xp = (x0 < p.Wi - 1) ? 1 : 0;
-      const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-      const float v = lz0 * (ly0 * (lx0 * s00[x0] + lx1 * s00[x0 + xp]) + ly1 * (lx0 * s01[x0] + lx1 * s01[x0 + xp])) +
-                      lz1 * (ly0 * (lx0 * s10[x0] + lx1 * s10[x0 + xp]) + ly1 * (lx0 * s11[x0] + lx1 * s11[x0 + xp]));
-      o[i] = v * scale;
-    }
+    fs::trilinear_up_row<4>(s00, s01, s10, s11, lz0, lz1, ly0, ly1, p.rs, 4 * x4, p.Wi, scale, o);
     float4 r = make_float4(o[0], o[1], o[2], o[3]);
     if (prev) {
       const float4 q = prev[e];
@@ -245,33 +239,102 @@ __global__ __launch_bounds__(256) void upsample3d_scale_add_v4_kernel(const floa
   }
 }
 
+// ---- 2-D bilinear resize (Flow-2D IFBlock) -------------------------------------------------------
+// out[bc, y, x] = scale * bilinear(in) with ATen's upsample_bilinear2d index arithmetic (align_corners=False,
+// scale factor given: source = rs * (dst + 0.5) - 0.5 clamped at 0).  One thread per output pixel.
+__global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                       long long nBC, int Hi, int Wi, int Ho, int Wo, float rs,
+                                                       float scale) {
+#pragma clang fp contract(off)
+  const long long nout = (long long)Ho * Wo, nin = (long long)Hi * Wi;
+  const long long total = nBC * nout;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long bc = e / nout;
+    const int r = (int)(e - bc * nout);
+    const int x = r % Wo, y = r / Wo;
+    float sy = rs * ((float)y + 0.5f) - 0.5f, sx = rs * ((float)x + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int yp = (y0 < Hi - 1) ? 1 : 0, xp = (x0 < Wi - 1) ? 1 : 0;
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* s = in + bc * nin + (long long)y0 * Wi + x0;
+    const int dy = yp * Wi;
+    // upsample_bilinear2d_out_frame: h0lambda * (w0lambda * a + w1lambda * b) + h1lambda * (...)
+    const float v = ly0 * (lx0 * s[0] + lx1 * s[xp]) + ly1 * (lx0 * s[dy] + lx1 * s[dy + xp]);
+    out[e] = (scale == 1.0f) ? v : v * scale;
+  }
+}
+
+// adjoint as a gather: one thread per INPUT pixel sums the output gradients that reference it (weights
+// from the forward's own index arithmetic, axis_w); NC candidates per axis as in interp3d_adjoint_kernel.
+template <int NC>
+__global__ __launch_bounds__(256) void resize2d_adjoint_kernel(const float* __restrict__ gout,
+                                                               float* __restrict__ gin, long long nBC, int Hi,
+                                                               int Wi, int Ho, int Wo, float rs, int up, int s,
+                                                               float scale) {
+  const long long nin = (long long)Hi * Wi, nout = (long long)Ho * Wo;
+  const long long total = nBC * nin;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long bc = e / nin;
+    const int r = (int)(e - bc * nin);
+    const int x = r % Wi, y = r / Wi;
+    const int oy0 = up ? s * y - s / 2 : y / s - 1;
+    const int ox0 = up ? s * x - s / 2 : x / s - 1;
+    float wy[NC], wx[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      wy[k] = axis_w(oy0 + k, y, Hi, Ho, rs);
+      wx[k] = axis_w(ox0 + k, x, Wi, Wo, rs);
+    }
+    const float* g = gout + bc * nout;
+    float acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < NC; ++b) {
+      if (wy[b] == 0.f) continue;
+      const float* row = g + (long long)(oy0 + b) * Wo;
+      float rowsum = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int ox = min(max(ox0 + c, 0), Wo - 1);  // weight is 0 where the index was clamped
+        rowsum = fmaf(wx[c], row[ox], rowsum);
+      }
+      acc = fmaf(wy[b], rowsum, acc);
+    }
+    gin[e] = acc * scale;
+  }
+}
+
 unsigned grid_for(long long total) {
   const long long want = (total + 255) / 256;
   return (unsigned)(want < (1 << 20) ? want : (1 << 20));
 }
 
 template <int NC>
-void up_adjoint_separable(const float* gout, float* gin, float* ws, const IP& p, hipStream_t st) {
+void up_adjoint_separable(const float* gout, float* gin, float* ws, const IP& p, hipStream_t st, float oscale) {
   const long long nbc = p.nBC;
   float* t1 = ws;                                              // [BC, Do, Ho, Wi]
   float* t2 = ws + nbc * p.Do * p.Ho * p.Wi;                   // [BC, Do, Hi, Wi]
   long long tot = nbc * p.Do * p.Ho * p.Wi;
   hipLaunchKernelGGL(interp_axis_adjoint_kernel<NC>, dim3(grid_for(tot)), dim3(256), 0, st, gout, t1,
-                     nbc * p.Do * p.Ho, p.Wo, p.Wi, 1, p.s, p.rs);
+                     nbc * p.Do * p.Ho, p.Wo, p.Wi, 1, p.s, p.rs, 1.0f);
   tot = nbc * p.Do * p.Hi * p.Wi;
   hipLaunchKernelGGL(interp_axis_adjoint_kernel<NC>, dim3(grid_for(tot)), dim3(256), 0, st, t1, t2,
-                     nbc * p.Do, p.Ho, p.Hi, p.Wi, p.s, p.rs);
+                     nbc * p.Do, p.Ho, p.Hi, p.Wi, p.s, p.rs, 1.0f);
   tot = nbc * p.Di * p.Hi * p.Wi;
   hipLaunchKernelGGL(interp_axis_adjoint_kernel<NC>, dim3(grid_for(tot)), dim3(256), 0, st, t2, gin, nbc,
-                     p.Do, p.Di, p.Hi * p.Wi, p.s, p.rs);
+                     p.Do, p.Di, p.Hi * p.Wi, p.s, p.rs, oscale);
 }
 
 }  // namespace
 
-extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws, int B, int C, int Din,
-                               int Hin, int Win, int Dout, int Hout, int Wout, int factor, int upsample,
-                               fs_stream_t stream) {
+// grad_in = scale * adjoint(grad_out) for the up-sampling direction with a workspace (the separable form,
+// `scale` applied by its last pass); every other form requires scale == 1.
+extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, float* ws, int B, int C, int Din,
+                                      int Hin, int Win, int Dout, int Hout, int Wout, int factor, int upsample,
+                                      float scale, fs_stream_t stream) {
   FS_ENTER();
+  if (scale != 1.0f && !(upsample && ws != nullptr)) return FS_ERR_ARG;
   FS_REQUIRE_PTR(grad_out); FS_REQUIRE_PTR(grad_in);
   if (B < 1 || C < 1 || Din < 1 || Hin < 1 || Win < 1 || Dout < 1 || Hout < 1 || Wout < 1)
     return FS_ERR_SHAPE;
@@ -304,8 +367,8 @@ extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws,
       hipLaunchKernelGGL(interp3d_adjoint_kernel<3>, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
                          grad_in, p);
   } else if (ws != nullptr) {
-    if (factor == 2) up_adjoint_separable<4>(grad_out, grad_in, ws, p, st);
-    else up_adjoint_separable<8>(grad_out, grad_in, ws, p, st);
+    if (factor == 2) up_adjoint_separable<4>(grad_out, grad_in, ws, p, st, scale);
+    else up_adjoint_separable<8>(grad_out, grad_in, ws, p, st, scale);
   } else if (factor == 2) {
     hipLaunchKernelGGL(interp3d_adjoint_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
                        grad_in, p);
@@ -315,6 +378,13 @@ extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws,
   }
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+
+extern "C" int fs_interp3d_bwd(const float* grad_out, float* grad_in, float* ws, int B, int C, int Din,
+                               int Hin, int Win, int Dout, int Hout, int Wout, int factor, int upsample,
+                               fs_stream_t stream) {
+  return fs_interp3d_bwd_scaled(grad_out, grad_in, ws, B, C, Din, Hin, Win, Dout, Hout, Wout, factor, upsample,
+                                1.0f, stream);
 }
 
 extern "C" int fs_upsample3d_scale_add(const float* small, const float* prev, float* out, int B, int C, int Din,
@@ -336,6 +406,81 @@ extern "C" int fs_upsample3d_scale_add(const float* small, const float* prev, fl
   else
     hipLaunchKernelGGL(upsample3d_scale_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, small,
                        prev, out, p, scale);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// out = scale * F.interpolate(in, scale_factor=1/factor, mode="trilinear", align_corners=False): the generic
+// ATen-order kernel with the source-index scale `factor`; output extent floor(in / factor).
+extern "C" int fs_downsample3d_fwd(const float* in, float* out, int B, int C, int Din, int Hin, int Win,
+                                   int factor, float scale, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(out);
+  if (B < 1 || C < 1 || Din < 1 || Hin < 1 || Win < 1) return FS_ERR_SHAPE;
+  if (factor != 2 && factor != 4) return FS_ERR_ARG;
+  if (Din / factor < 1 || Hin / factor < 1 || Win / factor < 1) return FS_ERR_SHAPE;
+  if ((long long)Din * Hin * Win >= (1ll << 31)) return FS_ERR_SHAPE;
+  IP p;
+  p.Di = Din; p.Hi = Hin; p.Wi = Win;
+  p.Do = Din / factor; p.Ho = Hin / factor; p.Wo = Win / factor;
+  p.up = 0; p.s = factor; p.rs = (float)factor;
+  p.nBC = (long long)B * C;
+  const long long total = p.nBC * p.Do * p.Ho * p.Wo;
+  if ((p.Wo & 3) == 0 && ((uintptr_t)out & 15) == 0)
+    hipLaunchKernelGGL(upsample3d_scale_add_v4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                       in, (const float4*)nullptr, (float4*)out, p, scale);
+  else
+    hipLaunchKernelGGL(upsample3d_scale_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                       (const float*)nullptr, out, p, scale);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+static int resize2d_dims(int Hin, int Win, int Hout, int Wout, int factor, int upsample) {
+  if (factor != 2 && factor != 4) return FS_ERR_ARG;
+  if (upsample) return (Hout == Hin * factor && Wout == Win * factor) ? FS_OK : FS_ERR_SHAPE;
+  return (Hout == Hin / factor && Wout == Win / factor && Hout >= 1 && Wout >= 1) ? FS_OK : FS_ERR_SHAPE;
+}
+
+// out = scale * F.interpolate(in, scale_factor = factor or 1/factor, mode="bilinear", align_corners=False)
+extern "C" int fs_resize2d_fwd(const float* in, float* out, int B, int C, int Hin, int Win, int Hout, int Wout,
+                               int factor, int upsample, float scale, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(out);
+  if (B < 1 || C < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) return FS_ERR_SHAPE;
+  const int rc = resize2d_dims(Hin, Win, Hout, Wout, factor, upsample);
+  if (rc != FS_OK) return rc;
+  if ((long long)Hin * Win >= (1ll << 31) || (long long)Hout * Wout >= (1ll << 31)) return FS_ERR_SHAPE;
+  const float rs = upsample ? 1.0f / (float)factor : (float)factor;
+  const long long total = (long long)B * C * Hout * Wout;
+  hipLaunchKernelGGL(resize2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     (long long)B * C, Hin, Win, Hout, Wout, rs, scale);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// grad_in = scale * adjoint(grad_out) of the resize above (gather, no atomics)
+extern "C" int fs_resize2d_bwd(const float* grad_out, float* grad_in, int B, int C, int Hin, int Win, int Hout,
+                               int Wout, int factor, int upsample, float scale, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(grad_out); FS_REQUIRE_PTR(grad_in);
+  if (B < 1 || C < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) return FS_ERR_SHAPE;
+  const int rc = resize2d_dims(Hin, Win, Hout, Wout, factor, upsample);
+  if (rc != FS_OK) return rc;
+  if ((long long)Hin * Win >= (1ll << 31) || (long long)Hout * Wout >= (1ll << 31)) return FS_ERR_SHAPE;
+  const float rs = upsample ? 1.0f / (float)factor : (float)factor;
+  const long long nbc = (long long)B * C, total = nbc * Hin * Win;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid_for(total)), b(256);
+  if (!upsample)
+    hipLaunchKernelGGL(resize2d_adjoint_kernel<3>, g, b, 0, st, grad_out, grad_in, nbc, Hin, Win, Hout, Wout, rs, 0,
+                       factor, scale);
+  else if (factor == 2)
+    hipLaunchKernelGGL(resize2d_adjoint_kernel<4>, g, b, 0, st, grad_out, grad_in, nbc, Hin, Win, Hout, Wout, rs, 1,
+                       factor, scale);
+  else
+    hipLaunchKernelGGL(resize2d_adjoint_kernel<8>, g, b, 0, st, grad_out, grad_in, nbc, Hin, Win, Hout, Wout, rs, 1,
+                       factor, scale);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

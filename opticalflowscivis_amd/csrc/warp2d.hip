@@ -17,8 +17,10 @@
 namespace {
 
 struct W2P {
-  int B, C, H, W;
-  float stepH, stepW, sH, sW;  // RIFE: linspace steps and (n-1)/2
+  int B, C, H, W;              // extent of the flow == of the output
+  int Hi, Wi;                  // extent of the sampled image (RIFE only may differ: the reference builds the
+                               // grid from the flow's shape and normalises by the input's, warplayer.py:10-20)
+  float stepH, stepW, sH, sW;  // RIFE: linspace steps over the FLOW dims and (n-1)/2 of the INPUT dims
   float dW, dH;                // PWC: max(W-1,1), max(H-1,1)
   float fW, fH;                // PHOTO: float(2/W), float(2/H)
   int flowC;                   // channels of the flow tensor: 2 (single) or 4 (IFNet pair)
@@ -45,13 +47,13 @@ __device__ __forceinline__ Samp2 w2_sample(const W2P& p, int b, int x, int y, fl
   if (MODE == FS_WARP2D_RIFE) {
     const float gx = fs::linspace_pm1(x, p.W, p.stepW) + u / p.sW;  // warplayer.py:12,18
     const float gy = fs::linspace_pm1(y, p.H, p.stepH) + v / p.sH;  // warplayer.py:14,19
-    ix = ((gx + 1.0f) / 2.0f) * (float)(p.W - 1);
-    iy = ((gy + 1.0f) / 2.0f) * (float)(p.H - 1);
+    ix = ((gx + 1.0f) / 2.0f) * (float)(p.Wi - 1);
+    iy = ((gy + 1.0f) / 2.0f) * (float)(p.Hi - 1);
     float cx, cy;
-    ix = fs::clip_border(ix, p.W, &cx);
-    iy = fs::clip_border(iy, p.H, &cy);
-    s.mx = cx * ((float)(p.W - 1) / 2.0f) / p.sW;
-    s.my = cy * ((float)(p.H - 1) / 2.0f) / p.sH;
+    ix = fs::clip_border(ix, p.Wi, &cx);
+    iy = fs::clip_border(iy, p.Hi, &cy);
+    s.mx = cx * ((float)(p.Wi - 1) / 2.0f) / p.sW;
+    s.my = cy * ((float)(p.Hi - 1) / 2.0f) / p.sH;
   } else if (MODE == FS_WARP2D_PWC) {
     const float vx = 2.0f * ((float)x + u) / p.dW - 1.0f;  // pwc_modules.py:199-200
     const float vy = 2.0f * ((float)y + v) / p.dH - 1.0f;
@@ -76,22 +78,22 @@ __device__ __forceinline__ Samp2 w2_sample(const W2P& p, int b, int x, int y, fl
   }
   // keep the float->int conversion defined for wild flows; outside [-2, size+1] every
   // corner is out of range (zeros modes) or clamps to the same edge (DILATED)
-  const float fx = fminf(fmaxf(ix, -2.0f), (float)p.W + 1.0f);
-  const float fy = fminf(fmaxf(iy, -2.0f), (float)p.H + 1.0f);
+  const float fx = fminf(fmaxf(ix, -2.0f), (float)p.Wi + 1.0f);
+  const float fy = fminf(fmaxf(iy, -2.0f), (float)p.Hi + 1.0f);
   const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
   const int x1 = x0 + 1, y1 = y0 + 1;
   if (MODE == FS_WARP2D_DILATED) {
-    s.x0 = min(max(x0, 0), p.W - 1); s.x1 = min(max(x1, 0), p.W - 1);
-    s.y0 = min(max(y0, 0), p.H - 1); s.y1 = min(max(y1, 0), p.H - 1);
+    s.x0 = min(max(x0, 0), p.Wi - 1); s.x1 = min(max(x1, 0), p.Wi - 1);
+    s.y0 = min(max(y0, 0), p.Hi - 1); s.y1 = min(max(y1, 0), p.Hi - 1);
     s.v00 = s.v10 = s.v01 = s.v11 = 1;
     s.ax = ix - (float)s.x0; s.bx = (float)s.x1 - ix;  // tools.py:504-507 (clamped corners)
     s.ay = iy - (float)s.y0; s.by = (float)s.y1 - iy;
   } else {
-    const int x0ok = (x0 >= 0 && x0 < p.W), x1ok = (x1 >= 0 && x1 < p.W);
-    const int y0ok = (y0 >= 0 && y0 < p.H), y1ok = (y1 >= 0 && y1 < p.H);
+    const int x0ok = (x0 >= 0 && x0 < p.Wi), x1ok = (x1 >= 0 && x1 < p.Wi);
+    const int y0ok = (y0 >= 0 && y0 < p.Hi), y1ok = (y1 >= 0 && y1 < p.Hi);
     s.v00 = x0ok & y0ok; s.v10 = x1ok & y0ok; s.v01 = x0ok & y1ok; s.v11 = x1ok & y1ok;
-    s.x0 = min(max(x0, 0), p.W - 1); s.x1 = min(max(x1, 0), p.W - 1);
-    s.y0 = min(max(y0, 0), p.H - 1); s.y1 = min(max(y1, 0), p.H - 1);
+    s.x0 = min(max(x0, 0), p.Wi - 1); s.x1 = min(max(x1, 0), p.Wi - 1);
+    s.y0 = min(max(y0, 0), p.Hi - 1); s.y1 = min(max(y1, 0), p.Hi - 1);
     s.ax = ix - (float)x0; s.bx = (float)x1 - ix;
     s.ay = iy - (float)y0; s.by = (float)y1 - iy;
   }
@@ -124,11 +126,11 @@ __global__ __launch_bounds__(256) void warp2d_fwd_kernel(W2Fwd io, const float* 
     const float* fb = flow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
     const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
     const float mk = MASK ? w2_mask(s) : 1.0f;
-    const int o00 = s.y0 * p.W + s.x0, o10 = s.y0 * p.W + s.x1;
-    const int o01 = s.y1 * p.W + s.x0, o11 = s.y1 * p.W + s.x1;
+    const int o00 = s.y0 * p.Wi + s.x0, o10 = s.y0 * p.Wi + s.x1;
+    const int o01 = s.y1 * p.Wi + s.x0, o11 = s.y1 * p.Wi + s.x1;
     for (int c = 0; c < p.C; ++c) {
 #pragma clang fp contract(off)
-      const float* ic = in + ((size_t)b * p.C + c) * HW;
+      const float* ic = in + ((size_t)b * p.C + c) * ((size_t)p.Hi * p.Wi);
       const float q00 = s.v00 ? ic[o00] : 0.f, q10 = s.v10 ? ic[o10] : 0.f;
       const float q01 = s.v01 ? ic[o01] : 0.f, q11 = s.v11 ? ic[o11] : 0.f;
       float acc;
@@ -162,12 +164,12 @@ __global__ __launch_bounds__(256) void warp2d_bwd_kernel(W2Bwd io, const float* 
     const float* fb = flow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
     const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
     const float mk = MASK ? w2_mask(s) : 1.0f;
-    const int o00 = s.y0 * p.W + s.x0, o10 = s.y0 * p.W + s.x1;
-    const int o01 = s.y1 * p.W + s.x0, o11 = s.y1 * p.W + s.x1;
+    const int o00 = s.y0 * p.Wi + s.x0, o10 = s.y0 * p.Wi + s.x1;
+    const int o01 = s.y1 * p.Wi + s.x0, o11 = s.y1 * p.Wi + s.x1;
     float gx = 0.f, gy = 0.f;
     for (int c = 0; c < p.C; ++c) {
-      const size_t pl = ((size_t)b * p.C + c) * HW;
-      const float g = gout[pl + r] * mk;
+      const size_t pl = ((size_t)b * p.C + c) * ((size_t)p.Hi * p.Wi);
+      const float g = gout[((size_t)b * p.C + c) * HW + r] * mk;
       const float* ic = in + pl;
       const float q00 = s.v00 ? ic[o00] : 0.f, q10 = s.v10 ? ic[o10] : 0.f;
       const float q01 = s.v01 ? ic[o01] : 0.f, q11 = s.v11 ? ic[o11] : 0.f;
@@ -265,15 +267,17 @@ __global__ __launch_bounds__(256) void occ_check2d_kernel(const float* __restric
   }
 }
 
-int make_params(W2P& p, int B, int C, int H, int W, int mode) {
-  if (B < 1 || C < 1 || H < 1 || W < 1) return FS_ERR_SHAPE;
-  if (mode == FS_WARP2D_RIFE && (H < 2 || W < 2)) return FS_ERR_SHAPE;  // (dim-1)/2 divisor
-  if ((long long)H * W >= (1ll << 31)) return FS_ERR_SHAPE;
-  p.B = B; p.C = C; p.H = H; p.W = W;
+int make_params(W2P& p, int B, int C, int H, int W, int mode, const int* in_hw = nullptr) {
+  const int Hi = in_hw ? in_hw[0] : H, Wi = in_hw ? in_hw[1] : W;
+  if (B < 1 || C < 1 || H < 1 || W < 1 || Hi < 1 || Wi < 1) return FS_ERR_SHAPE;
+  if ((Hi != H || Wi != W) && mode != FS_WARP2D_RIFE) return FS_ERR_ARG;  // only RIFE defines it
+  if (mode == FS_WARP2D_RIFE && (H < 2 || W < 2 || Hi < 2 || Wi < 2)) return FS_ERR_SHAPE;  // (dim-1)/2 divisor
+  if ((long long)H * W >= (1ll << 31) || (long long)Hi * Wi >= (1ll << 31)) return FS_ERR_SHAPE;
+  p.B = B; p.C = C; p.H = H; p.W = W; p.Hi = Hi; p.Wi = Wi;
   p.stepH = 2.0f / (float)(H - 1);
   p.stepW = 2.0f / (float)(W - 1);
-  p.sH = ((float)H - 1.0f) / 2.0f;
-  p.sW = ((float)W - 1.0f) / 2.0f;
+  p.sH = ((float)Hi - 1.0f) / 2.0f;
+  p.sW = ((float)Wi - 1.0f) / 2.0f;
   p.dW = (float)(W - 1 > 1 ? W - 1 : 1);
   p.dH = (float)(H - 1 > 1 ? H - 1 : 1);
   p.fW = (float)(2.0 / (double)W);  // python float 2/w, then FloatTensor (RIFE.py:258)
@@ -347,14 +351,14 @@ int check_mode(int mode, int with_mask, const float* start) {
 }  // namespace
 
 extern "C" int fs_warp2d_fwd(const float* in, const float* flow, const float* start, float* out,
-                             int B, int C, int H, int W, int mode, int with_mask,
+                             int B, int C, const int* in_hw, int H, int W, int mode, int with_mask,
                              fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(out);
   int rc = check_mode(mode, with_mask, start);
   if (rc != FS_OK) return rc;
   W2P p;
-  rc = make_params(p, B, C, H, W, mode);
+  rc = make_params(p, B, C, H, W, mode, in_hw);
   if (rc != FS_OK) return rc;
   W2Fwd io = {{in, nullptr}, {out, nullptr}};
   return dispatch_fwd(io, 1, flow, start, p, mode, with_mask, (hipStream_t)stream);
@@ -362,29 +366,29 @@ extern "C" int fs_warp2d_fwd(const float* in, const float* flow, const float* st
 
 extern "C" int fs_warp2d_bwd(const float* in, const float* flow, const float* start,
                              const float* grad_out, float* grad_in, float* grad_flow, int B, int C,
-                             int H, int W, int mode, int with_mask, fs_stream_t stream) {
+                             const int* in_hw, int H, int W, int mode, int with_mask, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(flow); FS_REQUIRE_PTR(grad_out);
   if (grad_in == nullptr && grad_flow == nullptr) return FS_ERR_NULLPTR;
   int rc = check_mode(mode, with_mask, start);
   if (rc != FS_OK) return rc;
   W2P p;
-  rc = make_params(p, B, C, H, W, mode);
+  rc = make_params(p, B, C, H, W, mode, in_hw);
   if (rc != FS_OK) return rc;
   W2Bwd io = {{in, nullptr}, {grad_out, nullptr}, {grad_in, nullptr}};
   return dispatch_bwd(io, 1, flow, start, grad_flow, p, mode, with_mask, (hipStream_t)stream);
 }
 
 extern "C" int fs_warp2d_pair_fwd(const float* img0, const float* img1, const float* flow4,
-                                  float* out0, float* out1, int B, int C, int H, int W, int mode,
-                                  fs_stream_t stream) {
+                                  float* out0, float* out1, int B, int C, const int* in_hw, int H, int W,
+                                  int mode, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow4);
   FS_REQUIRE_PTR(out0); FS_REQUIRE_PTR(out1);
   int rc = check_mode(mode, 0, nullptr);
   if (rc != FS_OK) return rc;
   W2P p;
-  rc = make_params(p, B, C, H, W, mode);
+  rc = make_params(p, B, C, H, W, mode, in_hw);
   if (rc != FS_OK) return rc;
   W2Fwd io = {{img0, img1}, {out0, out1}};
   return dispatch_fwd(io, 2, flow4, nullptr, p, mode, 0, (hipStream_t)stream);
@@ -392,8 +396,8 @@ extern "C" int fs_warp2d_pair_fwd(const float* img0, const float* img1, const fl
 
 extern "C" int fs_warp2d_pair_bwd(const float* img0, const float* img1, const float* flow4,
                                   const float* grad_out0, const float* grad_out1, float* grad_img0,
-                                  float* grad_img1, float* grad_flow4, int B, int C, int H, int W,
-                                  int mode, fs_stream_t stream) {
+                                  float* grad_img1, float* grad_flow4, int B, int C, const int* in_hw, int H,
+                                  int W, int mode, fs_stream_t stream) {
   FS_ENTER();
   FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow4);
   FS_REQUIRE_PTR(grad_out0); FS_REQUIRE_PTR(grad_out1);
@@ -402,7 +406,7 @@ extern "C" int fs_warp2d_pair_bwd(const float* img0, const float* img1, const fl
   int rc = check_mode(mode, 0, nullptr);
   if (rc != FS_OK) return rc;
   W2P p;
-  rc = make_params(p, B, C, H, W, mode);
+  rc = make_params(p, B, C, H, W, mode, in_hw);
   if (rc != FS_OK) return rc;
   W2Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
   return dispatch_bwd(io, 2, flow4, nullptr, grad_flow4, p, mode, 0, (hipStream_t)stream);

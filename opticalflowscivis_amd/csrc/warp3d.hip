@@ -56,6 +56,18 @@ struct W3P {
 struct W3Fwd { const float* in[2]; float* out[2]; };
 struct W3Bwd { const float* in[2]; const float* gout[2]; float* gin[2]; };
 
+// Fused "flow = prev + scale * trilinear_upsample(delta)" producer of the forward kernel (SURVEY §8f.1,
+// Flow-3D/model/IFNet.py:118 followed by :190-191): the flow tile of a slice is formed in registers from
+// the low-resolution 6-channel delta, written ONCE to `fout` (the accumulated flow has three more
+// consumers) and handed to the warp through the same LDS transpose -- the warp never re-reads it from HBM.
+struct UpP {
+  const float* small;  // [B, 6, Ds, Hs, Ws] head output at the block's working resolution
+  const float* prev;   // [B, 6, D, H, W] running flow, or nullptr (block 0)
+  float* fout;         // [B, 6, D, H, W] accumulated flow
+  int Ds, Hs, Ws;
+  float rs, scale;     // 1 / factor, flow scale (= factor)
+};
+
 // The kernels are VALU-issue-bound once HBM traffic is at the algorithmic minimum (measured:
 // FETCH/WRITE_SIZE == algorithmic bytes, SQ_ACTIVE_INST_VALU ~ 90 % of the kernel's cycles at
 // ~180 VALU instructions per voxel), so the per-voxel instruction count is the budget:
@@ -185,6 +197,53 @@ struct Mover {
       }
     }
   }
+  // flow plane of slice d formed from channel volume `sv` of the low-resolution delta:
+  // prev + scale * trilinear_up(delta), arithmetic of fs_upsample3d_scale_add (bit-identical), stored to
+  // `oplane` and kept in registers in the layout `load` produces
+  __device__ static __forceinline__ void produce(const float* __restrict__ sv, const float* __restrict__ pplane,
+                                                 float* __restrict__ oplane, const W3P& p, const UpP& u, int d,
+                                                 int h0, int w0, elem (&r)[PASSES]) {
+    const int t = threadIdx.x, col = t % LPR, row0 = t / LPR;
+    int z0, zp;
+    float lz0, lz1;
+    fs::trilinear_axis(d, u.Ds, u.rs, z0, zp, lz0, lz1);
+    const float* sz0 = sv + (size_t)z0 * u.Hs * u.Ws;
+    const float* sz1 = sz0 + (size_t)zp * u.Hs * u.Ws;
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+      const int hq = h0 + row0 + it * RP;
+      const int h = min(hq, p.H - 1);
+      int y0, yp;
+      float ly0, ly1;
+      fs::trilinear_axis(h, u.Hs, u.rs, y0, yp, ly0, ly1);
+      const float* s00 = sz0 + (size_t)y0 * u.Ws;
+      const float* s01 = s00 + yp * u.Ws;
+      const float* s10 = sz1 + (size_t)y0 * u.Ws;
+      const float* s11 = s10 + yp * u.Ws;
+      if (VEC) {
+        const int wq = w0 + 4 * col;
+        const int w = min(wq, p.W - 4);
+        float o[4];
+        fs::trilinear_up_row<4>(s00, s01, s10, s11, lz0, lz1, ly0, ly1, u.rs, w, u.Ws, u.scale, o);
+        float4 v = make_float4(o[0], o[1], o[2], o[3]);
+        if (pplane != nullptr) {
+          const float4 q = *reinterpret_cast<const float4*>(pplane + (size_t)h * p.W + w);
+          v.x = q.x + v.x; v.y = q.y + v.y; v.z = q.z + v.z; v.w = q.w + v.w;
+        }
+        if (hq < p.H && wq < p.W) *reinterpret_cast<float4*>(oplane + (size_t)h * p.W + w) = v;
+        *reinterpret_cast<float4*>(&r[it]) = v;
+      } else {
+        const int wq = w0 + col;
+        const int w = min(wq, p.W - 1);
+        float o[1];
+        fs::trilinear_up_row<1>(s00, s01, s10, s11, lz0, lz1, ly0, ly1, u.rs, w, u.Ws, u.scale, o);
+        float v = o[0];
+        if (pplane != nullptr) v = pplane[(size_t)h * p.W + w] + v;
+        if (hq < p.H && wq < p.W) oplane[(size_t)h * p.W + w] = v;
+        *reinterpret_cast<float*>(&r[it]) = v;
+      }
+    }
+  }
   // registers -> transposed LDS tile
   __device__ static __forceinline__ void to_lds(float (*tile)[LDH], const elem (&r)[PASSES]) {
     const int t = threadIdx.x, col = t % LPR, row0 = t / LPR;
@@ -200,9 +259,10 @@ struct Mover {
       }
     }
   }
-  // transposed LDS tile -> global plane (guarded)
-  __device__ static __forceinline__ void store(float* __restrict__ plane, const W3P& p, int h0, int w0,
-                                               const float (*tile)[LDH]) {
+  // transposed LDS tile (+ the same positions of `add`, when given) -> global plane (guarded).  `add`
+  // may be the plane itself: every element is read and then written by the same thread.
+  __device__ static __forceinline__ void store(float* plane, const W3P& p, int h0, int w0,
+                                               const float (*tile)[LDH], const float* add = nullptr) {
     const int t = threadIdx.x, col = t % LPR, row0 = t / LPR;
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
@@ -214,18 +274,23 @@ struct Mover {
           float4 v;
           v.x = tile[4 * col + 0][hh]; v.y = tile[4 * col + 1][hh];
           v.z = tile[4 * col + 2][hh]; v.w = tile[4 * col + 3][hh];
+          if (add != nullptr) {
+            const float4 a = *reinterpret_cast<const float4*>(add + (size_t)h * p.W + w);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
           *reinterpret_cast<float4*>(plane + (size_t)h * p.W + w) = v;
         }
       } else {
         const int w = w0 + col;
-        if (h < p.H && w < p.W) plane[(size_t)h * p.W + w] = tile[col][hh];
+        if (h < p.H && w < p.W)
+          plane[(size_t)h * p.W + w] = tile[col][hh] + (add != nullptr ? add[(size_t)h * p.W + w] : 0.f);
       }
     }
   }
 };
 
-template <int NT, bool VEC>
-__global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* __restrict__ flow,
+template <int NT, bool VEC, bool UPS>
+__global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* __restrict__ flow, UpP u,
                                                         W3P p) {
   using M = Mover<NT, VEC>;
   constexpr int NW = TW / (NT / 64);  // voxels per thread and slice in the h-major phase
@@ -239,7 +304,8 @@ __global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* _
   const int HW = p.H * p.W;
   const size_t vol = (size_t)p.D * HW;
   const size_t ivol = (size_t)p.Di * p.Hi * p.Wi;
-  const float* fb = flow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol;
+  const size_t fch = (size_t)b * p.flowC + 3 * blockIdx.y;  // first flow channel of this pair member
+  const float* fb = UPS ? nullptr : flow + fch * vol;
   const int dEnd = min(d0 + p.dc, p.D);
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -247,10 +313,22 @@ __global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* _
   const float lin_h = fs::linspace_pm1(h, p.H, p.stepH);
 
   typename M::elem r0[M::PASSES], r1[M::PASSES], r2[M::PASSES];
-  {
-    const float* f = fb + (size_t)d0 * HW;
-    M::load(f, p, h0, w0, r0); M::load(f + vol, p, h0, w0, r1); M::load(f + 2 * vol, p, h0, w0, r2);
-  }
+  // the three flow planes of slice d: loaded (plain warp) or formed from the low-resolution delta (UPS)
+  auto flow_tiles = [&](int d) {
+    if (UPS) {
+      const size_t svol = (size_t)u.Ds * u.Hs * u.Ws;
+      const float* sv = u.small + fch * svol;
+      const float* pp = u.prev ? u.prev + fch * vol + (size_t)d * HW : nullptr;
+      float* op = u.fout + fch * vol + (size_t)d * HW;
+      M::produce(sv, pp, op, p, u, d, h0, w0, r0);
+      M::produce(sv + svol, pp ? pp + vol : nullptr, op + vol, p, u, d, h0, w0, r1);
+      M::produce(sv + 2 * svol, pp ? pp + 2 * vol : nullptr, op + 2 * vol, p, u, d, h0, w0, r2);
+    } else {
+      const float* f = fb + (size_t)d * HW;
+      M::load(f, p, h0, w0, r0); M::load(f + vol, p, h0, w0, r1); M::load(f + 2 * vol, p, h0, w0, r2);
+    }
+  };
+  flow_tiles(d0);
   for (int d = d0; d < dEnd; ++d) {
     // phase 1: flow tile of this slice (already in registers) -> LDS
     M::to_lds(sF[0], r0); M::to_lds(sF[1], r1); M::to_lds(sF[2], r2);
@@ -273,8 +351,7 @@ __global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* _
       __syncthreads();
       if (c + 1 == p.C && d + 1 < dEnd) {
         // next slice's flow tile: in flight during the store phase and the next LDS hand-over
-        const float* f = fb + (size_t)(d + 1) * HW;
-        M::load(f, p, h0, w0, r0); M::load(f + vol, p, h0, w0, r1); M::load(f + 2 * vol, p, h0, w0, r2);
+        flow_tiles(d + 1);
       }
       // phase 3: lanes on w, coalesced store
       M::store(out + ((size_t)b * p.C + c) * vol + (size_t)d * HW, p, h0, w0, sO);
@@ -287,7 +364,7 @@ __global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* _
 
 template <int NT, bool VEC, bool WITH_GIN>
 __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* __restrict__ flow,
-                                                        float* __restrict__ gflow, W3P p) {
+                                                        float* gflow, const float* gadd, W3P p) {
   using M = Mover<NT, VEC>;
   constexpr int NW = TW / (NT / 64);
   const float* __restrict__ in = io.in[blockIdx.y];
@@ -303,6 +380,8 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
   const size_t ivol = (size_t)p.Di * p.Hi * p.Wi;
   const float* fb = flow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol;
   float* gfb = gflow ? gflow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol : nullptr;
+  // gradient reaching the flow from its other consumers, summed into the stored tile (may alias gflow)
+  const float* gab = (gflow && gadd) ? gadd + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol : nullptr;
   const int dEnd = min(d0 + p.dc, p.D);
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -393,8 +472,9 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
     }
     if (gfb != nullptr) {
       float* g = gfb + (size_t)d * HW;
-      M::store(g, p, h0, w0, sF[0]); M::store(g + vol, p, h0, w0, sF[1]);
-      M::store(g + 2 * vol, p, h0, w0, sF[2]);
+      const float* a = gab ? gab + (size_t)d * HW : nullptr;
+      M::store(g, p, h0, w0, sF[0], a); M::store(g + vol, p, h0, w0, sF[1], a ? a + vol : nullptr);
+      M::store(g + 2 * vol, p, h0, w0, sF[2], a ? a + 2 * vol : nullptr);
     }
     __syncthreads();  // stores have read sF before the next slice's flow overwrites it
   }
@@ -432,38 +512,45 @@ bool vec_ok(const W3P& p, const void* a, const void* b, const void* c, const voi
   return (p.W % 4 == 0) && al(a) && al(b) && al(c) && al(d);
 }
 
-int launch_fwd(const W3Fwd& io, int npair, const float* flow, W3P& p, fs_stream_t stream) {
+int launch_fwd(const W3Fwd& io, int npair, const float* flow, const UpP* up, W3P& p, fs_stream_t stream) {
   const unsigned grid = (unsigned)((long long)p.B * p.nDC * p.tilesH * p.tilesW);
   p.flowC = 3 * npair;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = vec_ok(p, flow, io.out[0], io.out[1], nullptr);
   const dim3 g(grid, npair);
   // measured at 2 x 256^3: forward is fastest with 8 waves per workgroup (4 voxels per thread,
   // 32 waves/CU), backward with 4 waves (8 voxels per thread: more gathers in flight per wave)
-  if (vec) hipLaunchKernelGGL((warp3d_fwd_kernel<512, true>), g, dim3(512), 0, st, io, flow, p);
-  else hipLaunchKernelGGL((warp3d_fwd_kernel<512, false>), g, dim3(512), 0, st, io, flow, p);
+  if (up != nullptr) {
+    const bool vec = vec_ok(p, up->prev, up->fout, io.out[0], io.out[1]);
+    if (vec) hipLaunchKernelGGL((warp3d_fwd_kernel<512, true, true>), g, dim3(512), 0, st, io, flow, *up, p);
+    else hipLaunchKernelGGL((warp3d_fwd_kernel<512, false, true>), g, dim3(512), 0, st, io, flow, *up, p);
+  } else {
+    const UpP none = {};
+    const bool vec = vec_ok(p, flow, io.out[0], io.out[1], nullptr);
+    if (vec) hipLaunchKernelGGL((warp3d_fwd_kernel<512, true, false>), g, dim3(512), 0, st, io, flow, none, p);
+    else hipLaunchKernelGGL((warp3d_fwd_kernel<512, false, false>), g, dim3(512), 0, st, io, flow, none, p);
+  }
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
 template <int NT, bool VEC>
 void launch_bwd_t(const W3Bwd& io, const dim3& g, bool with_gin, const float* flow, float* gflow,
-                  const W3P& p, hipStream_t st) {
+                  const float* gadd, const W3P& p, hipStream_t st) {
   if (with_gin)
-    hipLaunchKernelGGL((warp3d_bwd_kernel<NT, VEC, true>), g, dim3(NT), 0, st, io, flow, gflow, p);
+    hipLaunchKernelGGL((warp3d_bwd_kernel<NT, VEC, true>), g, dim3(NT), 0, st, io, flow, gflow, gadd, p);
   else
-    hipLaunchKernelGGL((warp3d_bwd_kernel<NT, VEC, false>), g, dim3(NT), 0, st, io, flow, gflow, p);
+    hipLaunchKernelGGL((warp3d_bwd_kernel<NT, VEC, false>), g, dim3(NT), 0, st, io, flow, gflow, gadd, p);
 }
 
-int launch_bwd(const W3Bwd& io, int npair, bool with_gin, const float* flow, float* gflow, W3P& p,
-               fs_stream_t stream) {
+int launch_bwd(const W3Bwd& io, int npair, bool with_gin, const float* flow, float* gflow, const float* gadd,
+               W3P& p, fs_stream_t stream) {
   const unsigned grid = (unsigned)((long long)p.B * p.nDC * p.tilesH * p.tilesW);
   p.flowC = 3 * npair;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = vec_ok(p, flow, gflow, io.gout[0], io.gout[1]);
+  const bool vec = vec_ok(p, flow, gflow, io.gout[0], io.gout[1]) && vec_ok(p, gadd, nullptr, nullptr, nullptr);
   const dim3 g(grid, npair);
-  if (vec) launch_bwd_t<256, true>(io, g, with_gin, flow, gflow, p, st);
-  else launch_bwd_t<256, false>(io, g, with_gin, flow, gflow, p, st);
+  if (vec) launch_bwd_t<256, true>(io, g, with_gin, flow, gflow, gadd, p, st);
+  else launch_bwd_t<256, false>(io, g, with_gin, flow, gflow, gadd, p, st);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -478,7 +565,7 @@ extern "C" int fs_warp3d_fwd(const float* in, const float* flow, float* out, int
   const int rc = make_params(p, B, C, in_dhw, D, H, W);
   if (rc != FS_OK) return rc;
   W3Fwd io = {{in, nullptr}, {out, nullptr}};
-  return launch_fwd(io, 1, flow, p, stream);
+  return launch_fwd(io, 1, flow, nullptr, p, stream);
 }
 
 extern "C" int fs_warp3d_bwd(const float* in, const float* flow, const float* grad_out,
@@ -491,7 +578,7 @@ extern "C" int fs_warp3d_bwd(const float* in, const float* flow, const float* gr
   const int rc = make_params(p, B, C, in_dhw, D, H, W);
   if (rc != FS_OK) return rc;
   W3Bwd io = {{in, nullptr}, {grad_out, nullptr}, {grad_in, nullptr}};
-  return launch_bwd(io, 1, grad_in != nullptr, flow, grad_flow, p, stream);
+  return launch_bwd(io, 1, grad_in != nullptr, flow, grad_flow, nullptr, p, stream);
 }
 
 extern "C" int fs_warp3d_pair_fwd(const float* img0, const float* img1, const float* flow6,
@@ -504,7 +591,7 @@ extern "C" int fs_warp3d_pair_fwd(const float* img0, const float* img1, const fl
   const int rc = make_params(p, B, C, in_dhw, D, H, W);
   if (rc != FS_OK) return rc;
   W3Fwd io = {{img0, img1}, {out0, out1}};
-  return launch_fwd(io, 2, flow6, p, stream);
+  return launch_fwd(io, 2, flow6, nullptr, p, stream);
 }
 
 extern "C" int fs_warp3d_pair_bwd(const float* img0, const float* img1, const float* flow6,
@@ -520,5 +607,70 @@ extern "C" int fs_warp3d_pair_bwd(const float* img0, const float* img1, const fl
   const int rc = make_params(p, B, C, in_dhw, D, H, W);
   if (rc != FS_OK) return rc;
   W3Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
-  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6, p, stream);
+  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6, nullptr, p, stream);
+}
+
+// fs_warp3d_pair_bwd with the gradient that reaches the flow from its OTHER consumers (`grad_flow_add`,
+// nullable, [B,6,D,H,W]) summed into grad_flow6 by the same launch: the flow of an IFNet block feeds the
+// warp, the next block's input, the next block's accumulation and the distillation term, and autograd would
+// otherwise add the warp's gradient to the others in a separate 2.4 GB pass.  grad_flow_add may BE grad_flow6
+// (in-place accumulation).
+extern "C" int fs_warp3d_pair_bwd_acc(const float* img0, const float* img1, const float* flow6,
+                                      const float* grad_out0, const float* grad_out1, float* grad_img0,
+                                      float* grad_img1, const float* grad_flow_add, float* grad_flow6, int B, int C,
+                                      const int* in_dhw, int D, int H, int W, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow6);
+  FS_REQUIRE_PTR(grad_out0); FS_REQUIRE_PTR(grad_out1); FS_REQUIRE_PTR(grad_flow6);
+  if ((grad_img0 == nullptr) != (grad_img1 == nullptr)) return FS_ERR_NULLPTR;
+  W3P p;
+  const int rc = make_params(p, B, C, in_dhw, D, H, W);
+  if (rc != FS_OK) return rc;
+  W3Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
+  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6, grad_flow_add, p, stream);
+}
+
+// "upsample flow x scale -> warp" in one kernel.  flow_out = prev_flow + scale *
+// trilinear_upsample(delta, factor) (prev_flow nullable), out0 = warp(img0, flow_out[:, :3]),
+// out1 = warp(img1, flow_out[:, 3:6]); delta [B,6,Ds,Hs,Ws], everything else at factor x that extent.
+extern "C" int fs_upsample_warp3d_pair_fwd(const float* img0, const float* img1, const float* delta,
+                                           const float* prev_flow, float* flow_out, float* out0, float* out1,
+                                           int B, int C, const int* in_dhw, int Ds, int Hs, int Ws, int factor,
+                                           float scale, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(delta); FS_REQUIRE_PTR(flow_out);
+  FS_REQUIRE_PTR(out0); FS_REQUIRE_PTR(out1);
+  if (factor != 2 && factor != 4) return FS_ERR_ARG;
+  if (Ds < 1 || Hs < 1 || Ws < 1) return FS_ERR_SHAPE;
+  if ((long long)Ds * Hs * Ws * factor * factor * factor >= (1ll << 31)) return FS_ERR_SHAPE;
+  W3P p;
+  const int rc = make_params(p, B, C, in_dhw, Ds * factor, Hs * factor, Ws * factor);
+  if (rc != FS_OK) return rc;
+  UpP u = {delta, prev_flow, flow_out, Ds, Hs, Ws, 1.0f / (float)factor, scale};
+  W3Fwd io = {{img0, img1}, {out0, out1}};
+  return launch_fwd(io, 2, nullptr, &u, p, stream);
+}
+
+extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, float* ws, int B, int C, int Din,
+                                      int Hin, int Win, int Dout, int Hout, int Wout, int factor, int upsample,
+                                      float scale, fs_stream_t stream);
+
+// Backward of the fused node: grad_flow_total = d(warps)/d(flow) + grad_flow_add (the gradient reaching
+// flow_out from its other consumers, nullable; may alias grad_flow_total) -- which is also the gradient of
+// prev_flow -- and grad_delta = scale * adjoint_upsample(grad_flow_total).  ws: B*6*(D*H*Ws + D*Hs*Ws) floats.
+extern "C" int fs_upsample_warp3d_pair_bwd(const float* img0, const float* img1, const float* flow6,
+                                           const float* grad_out0, const float* grad_out1,
+                                           const float* grad_flow_add, float* grad_flow_total, float* grad_delta,
+                                           float* ws, int B, int C, const int* in_dhw, int Ds, int Hs, int Ws,
+                                           int factor, float scale, fs_stream_t stream) {
+  FS_REQUIRE_PTR(grad_delta); FS_REQUIRE_PTR(ws);
+  if (factor != 2 && factor != 4) return FS_ERR_ARG;
+  if (Ds < 1 || Hs < 1 || Ws < 1) return FS_ERR_SHAPE;
+  if ((long long)Ds * Hs * Ws * factor * factor * factor >= (1ll << 31)) return FS_ERR_SHAPE;
+  const int D = Ds * factor, H = Hs * factor, W = Ws * factor;
+  int rc = fs_warp3d_pair_bwd_acc(img0, img1, flow6, grad_out0, grad_out1, nullptr, nullptr, grad_flow_add,
+                                  grad_flow_total, B, C, in_dhw, D, H, W, stream);
+  if (rc != FS_OK) return rc;
+  return fs_interp3d_bwd_scaled(grad_flow_total, grad_delta, ws, B, 6, Ds, Hs, Ws, D, H, W, factor, 1, scale,
+                                stream);
 }

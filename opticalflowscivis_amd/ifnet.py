@@ -47,15 +47,17 @@ def _head(nd, c, cout):
                  _DECONV[nd](c // 2, cout, 4, 2, 1))
 
 
-def _resize(t, factor, mode):
+def _resize(t, factor, mode, mul=1.0):
+    """mul * F.interpolate(t, scale_factor=factor, mode, align_corners=False) on the HIP resize kernels
+    (csrc/interp.hip: ATen's arithmetic forward, gather-form adjoint backward; `mul` -- the flow's
+    `* scale` / `* 1/scale` of IFBlock.forward -- folded into the same pass)."""
     if factor == 1:
         # scale_factor=1 with align_corners=False reproduces its input exactly (source index ==
         # destination index, weights (1, 0)); the reference still launches it.  Skip the pass.
-        return t
+        return t if mul == 1.0 else t * mul
     if mode == "trilinear":
-        return ops.interpolate3d(t, factor)  # ATen forward, HIP gather backward (no atomics)
-    return F.interpolate(t, scale_factor=factor, mode=mode, align_corners=False,
-                         recompute_scale_factor=False)
+        return ops.interpolate3d(t, factor, mul)
+    return ops.interpolate2d(t, factor, mul)
 
 
 def _min_spatial(a, b):
@@ -85,10 +87,14 @@ class IFBlock(nn.Module):
         self.conv2 = _head(nd, c, 1)       # blend-mask logit
 
     def forward(self, x, flow, scale, flow_base=None, mask_base=None, accumulate=False):
-        """Returns (flow_delta, mask_delta) as the reference's IFBlock does.  With `accumulate=True`
-        returns (flow_base + flow_delta, mask_base + mask_delta, True) when the sums can be formed inside
-        the producing kernels (3-D, GPU, delta and base of equal extent; a base may be None = zero), else
-        (flow_delta, mask_delta, False)."""
+        """Returns (flow_delta, mask_delta) as the reference's IFBlock does.  With `accumulate=True` returns
+        (flow, mask, kind):
+          "sum"    -- flow_base + flow_delta, mask_base + mask_delta, formed inside the producing kernels
+                      (3-D, GPU, scale 1, delta and base of equal extent; a base may be None = zero);
+          "lowres" -- scales 2 / 4: `flow` is the flow head's output at the block's working resolution (the
+                      caller fuses its up-sampling, the accumulation onto flow_base and the two warps into
+                      one launch, ops.upsample_warp_pair), `mask` is mask_base + upsample(mask_delta);
+          "delta"  -- (flow_delta, mask_delta) at full resolution, nothing accumulated."""
         mode = _INTERP[self.nd]
         if isinstance(x, (tuple, list)):
             # the caller's pieces (img0, img1, warped, mask, ...): at scale 1 they are concatenated with
@@ -101,7 +107,7 @@ class IFBlock(nn.Module):
             x = _resize(x, 1. / scale, mode)
         if flow is not None:
             if scale != 1:
-                flow = _resize(flow, 1. / scale, mode) * 1. / scale
+                flow = _resize(flow, 1. / scale, mode, 1. / scale)
             x = torch.cat((x, flow), 1)
         x = self.conv0(x)
         res = convgrad.res_unit if self.nd == 3 else (lambda blk, t: blk(t) + t)
@@ -113,16 +119,15 @@ class IFBlock(nn.Module):
             full = tuple(4 * scale * n for n in x.shape[2:])  # two stride-2 deconvs, then x scale
             if all(b is None or tuple(b.shape[2:]) == full for b in (flow_base, mask_base)):
                 if scale == 1:
-                    return self.conv1(x, flow_base), self.conv2(x, mask_base), True
-                # prev + scale * upsample(delta) in one pass (csrc/interp.hip)
-                return (ops.upsample3d_scale_add(self.conv1(x), flow_base, scale, float(scale)),
-                        ops.upsample3d_scale_add(self.conv2(x), mask_base, scale, 1.0), True)
+                    return self.conv1(x, flow_base), self.conv2(x, mask_base), "sum"
+                # mask: prev + upsample(delta) in one pass (csrc/interp.hip); flow: left to the caller
+                return self.conv1(x), ops.upsample3d_scale_add(self.conv2(x), mask_base, scale, 1.0), "lowres"
         flow = self.conv1(x)
         mask = self.conv2(x)
         if scale != 1:
-            flow = _resize(flow, scale, mode) * scale
+            flow = _resize(flow, scale, mode, scale)
             mask = _resize(mask, scale, mode)
-        return (flow, mask, False) if accumulate else (flow, mask)
+        return (flow, mask, "delta") if accumulate else (flow, mask)
 
 
 class IFNet(nn.Module):
@@ -159,15 +164,28 @@ class IFNet(nn.Module):
                 img0, img1 = _crop(img0, sp), _crop(img1, sp)
                 warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
                 mask, flow = _crop(mask, sp), _crop(flow, sp)
-                flow_d, mask_d, summed = stu[i]((img0, img1, warped_img0, warped_img1, mask),
-                                                flow, scale[i], flow, mask, accumulate=True)
-                if summed:  # flow + flow_d, mask + mask_d formed inside the producing kernels
-                    flow, mask = flow_d, mask_d
-                else:
-                    flow = flow + _crop(flow_d, img0.shape[2:])
-                    mask = mask + _crop(mask_d, img0.shape[2:])
+                flow_d, mask_d, kind = stu[i]((img0, img1, warped_img0, warped_img1, mask),
+                                              flow, scale[i], flow, mask, accumulate=True)
             else:
-                flow, mask, _ = stu[i](torch.cat((img0, img1), 1), None, scale[i], accumulate=True)
+                flow_d, mask_d, kind = stu[i](torch.cat((img0, img1), 1), None, scale[i], accumulate=True)
+            warped = None
+            if kind == "lowres":
+                full = tuple(scale[i] * n for n in flow_d.shape[2:])
+                if all(f <= n for f, n in zip(full, img0.shape[2:])):
+                    # §8f.1: up-sample x scale, accumulate onto the running flow and warp both frames in ONE
+                    # launch (no crop can follow: the flow is not larger than the frames)
+                    flow, w0, w1 = ops.upsample_warp_pair(img0, img1, flow_d, flow, scale[i])
+                    warped = (w0, w1)
+                else:
+                    flow = ops.upsample3d_scale_add(flow_d, flow, scale[i], float(scale[i]))
+                mask = mask_d
+            elif kind == "sum":  # flow + flow_d, mask + mask_d formed inside the producing kernels
+                flow, mask = flow_d, mask_d
+            elif flow is not None:
+                flow = flow + _crop(flow_d, img0.shape[2:])
+                mask = mask + _crop(mask_d, img0.shape[2:])
+            else:
+                flow, mask = flow_d, mask_d
             if self.nd == 2:
                 flow, mask = _crop(flow, img0.shape[2:]), _crop(mask, img0.shape[2:])
             sp = _min_spatial(img0, warped_img0)
@@ -175,9 +193,17 @@ class IFNet(nn.Module):
                 flow, mask = _crop(flow, sp), _crop(mask, sp)
             img0, img1 = _crop(img0, sp), _crop(img1, sp)
             mask_logits.append(mask)
+            # hot path: both backward warps of this block in one HIP launch.  In 3-D the launch also
+            # hands the flow on to its other consumers (next block, distillation), so that their summed
+            # gradient is folded into the warp's backward launch instead of a separate autograd add.
+            if warped is None:
+                if self.nd == 3:
+                    w0, w1, flow = ops.warp_pair_acc(img0, img1, flow)
+                    warped = (w0, w1)
+                else:
+                    warped = ops.warp_pair(img0, img1, flow)
+            warped_img0, warped_img1 = warped
             flow_list.append(flow)
-            # hot path: both backward warps of this block in one HIP launch
-            warped_img0, warped_img1 = ops.warp_pair(img0, img1, flow)
             merged.append((warped_img0, warped_img1))
 
         if gt.shape[1] == 1:
@@ -185,9 +211,9 @@ class IFNet(nn.Module):
             img0, img1 = _crop(img0, sp), _crop(img1, sp)
             warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
             mask, flow, gt = _crop(mask, sp), _crop(flow, sp), _crop(gt, sp)
-            flow_d, mask_d, summed = self.block_tea(
+            flow_d, mask_d, kind = self.block_tea(
                 (img0, img1, warped_img0, warped_img1, mask, gt), flow, 1, flow, mask, accumulate=True)
-            if summed:
+            if kind == "sum":
                 flow_teacher, mask_teacher = flow_d, mask_d
             else:
                 flow_teacher, mask_teacher = flow + _crop(flow_d, sp), mask + _crop(mask_d, sp)

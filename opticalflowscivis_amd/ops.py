@@ -141,13 +141,23 @@ def warp3d(tenInput, tenFlow):
 # --------------------------------------------------------------------------------------------
 # 2-D warps: a1, a5, a6, a7, a11
 # --------------------------------------------------------------------------------------------
+def _in_hw(inp, flow):
+    """Host int[2] with the sampled image's extent, or None when it equals the flow's."""
+    if tuple(inp.shape[2:]) == tuple(flow.shape[2:]):
+        return None
+    return (ctypes.c_int * 2)(*inp.shape[2:])
+
+
 class _Warp2D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp, flow, start, mode, with_mask):
         inp = _need_cuda_f32("input", inp, 4)
         flow = _need_cuda_f32("flow", flow, 4)
-        B, C, H, W = inp.shape
-        if tuple(flow.shape) != (B, 2, H, W):
+        B, C = inp.shape[:2]
+        H, W = flow.shape[2:]  # the output takes the flow's extent
+        same = tuple(flow.shape[2:]) == tuple(inp.shape[2:])
+        if flow.shape[0] != B or flow.shape[1] != 2 or not (same or mode == WARP2D_RIFE):
+            # only the RIFE warp defines input extent != flow extent (Flow-2D/model/warplayer.py:10-20)
             raise ValueError("flow must be [B,2,H,W] matching input %s, got %s" %
                              (tuple(inp.shape), tuple(flow.shape)))
         if inp.device != flow.device:
@@ -156,11 +166,10 @@ class _Warp2D(torch.autograd.Function):
             start = _need_cuda_f32("start", start.reshape(start.shape[0], 2), 2)
             if start.shape[0] != B:
                 raise ValueError("start must be [B,2,1,1]")
-        out = torch.empty_like(inp)
+        out = inp.new_empty((B, C, H, W))
         with torch.cuda.device(inp.device):
             _call("fs_warp2d_fwd", inp.data_ptr(), flow.data_ptr(), _ptr(start),
-                                                out.data_ptr(), B, C, H, W, mode, int(with_mask),
-                                                _stream(inp))
+                  out.data_ptr(), B, C, _in_hw(inp, flow), H, W, mode, int(with_mask), _stream(inp))
         ctx.save_for_backward(inp, flow, start)
         ctx.mode, ctx.with_mask = mode, int(with_mask)
         return out
@@ -172,14 +181,14 @@ class _Warp2D(torch.autograd.Function):
         if not (need_in or need_flow):
             return None, None, None, None, None
         gout = gout.contiguous()
-        B, C, H, W = inp.shape
+        B, C = inp.shape[:2]
+        H, W = flow.shape[2:]
         gin = torch.zeros_like(inp) if need_in else None
         gflow = torch.empty_like(flow) if need_flow else None
         with torch.cuda.device(inp.device):
             _call("fs_warp2d_bwd", inp.data_ptr(), flow.data_ptr(), _ptr(start),
-                                                gout.data_ptr(), _ptr(gin), _ptr(gflow),
-                                                B, C, H, W, ctx.mode, ctx.with_mask,
-                                                _stream(inp))
+                  gout.data_ptr(), _ptr(gin), _ptr(gflow), B, C, _in_hw(inp, flow), H, W, ctx.mode,
+                  ctx.with_mask, _stream(inp))
         return gin, gflow, None, None, None
 
 
@@ -190,7 +199,7 @@ def _empty2d(x, flow):
 def warp2d(tenInput, tenFlow):
     """a1: Flow-2D/model/warplayer.py:7-26 (border pad, align_corners=True)."""
     if _empty2d(tenInput, tenFlow):
-        return _empty_like_graph(tenInput.shape, tenInput, tenFlow)
+        return _empty_like_graph(tuple(tenInput.shape[:2]) + tuple(tenFlow.shape[2:]), tenInput, tenFlow)
     return _Warp2D.apply(tenInput, tenFlow, None, WARP2D_RIFE, 0)
 
 
@@ -235,39 +244,81 @@ def warp2d_dilated(I, flow, start=None):
 # IFNet call site: both frames warped by the two halves of one flow tensor, one launch
 # (Flow-3D/model/IFNet.py:190-191, Flow-2D/model/IFNet.py:191-192)
 # --------------------------------------------------------------------------------------------
+def _check_pair(img0, img1, flow):
+    nd = flow.dim() - 2
+    if nd not in (2, 3):
+        raise ValueError("flow must be [B,4,H,W] or [B,6,D,H,W], got %s" % (tuple(flow.shape),))
+    img0 = _need_cuda_f32("img0", img0, nd + 2)
+    img1 = _need_cuda_f32("img1", img1, nd + 2)
+    flow = _need_cuda_f32("flow", flow, nd + 2)
+    if img0.shape != img1.shape:
+        raise ValueError("img0 %s and img1 %s differ" % (tuple(img0.shape), tuple(img1.shape)))
+    if flow.shape[0] != img0.shape[0] or flow.shape[1] != 2 * nd:
+        raise ValueError("flow %s does not match the images %s" %
+                         (tuple(flow.shape), tuple(img0.shape)))
+    if not (img0.device == img1.device == flow.device):
+        raise ValueError("operands are on different devices")
+    return img0, img1, flow, nd
+
+
+def _pair_forward(img0, img1, flow, nd):
+    oshape = tuple(img0.shape[:2]) + tuple(flow.shape[2:])  # the warps take the flow's extent
+    out0, out1 = img0.new_empty(oshape), img1.new_empty(oshape)
+    B, C = img0.shape[:2]
+    with torch.cuda.device(flow.device):
+        if nd == 3:
+            D, H, W = flow.shape[2:]
+            _call("fs_warp3d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
+                  out0.data_ptr(), out1.data_ptr(), B, C, _in_dhw(img0, flow), D, H, W,
+                  _stream(flow), algo_bytes=4 * flow.numel() + 8 * out0.numel() * 2)
+        else:
+            H, W = flow.shape[2:]
+            _call("fs_warp2d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
+                  out0.data_ptr(), out1.data_ptr(), B, C, _in_hw(img0, flow), H, W,
+                  WARP2D_RIFE, _stream(flow))
+    return out0, out1
+
+
+def _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow, gflow_add=None):
+    """(grad_img0, grad_img1, grad_flow); `gflow_add` (3-D only): the gradient reaching the flow from its
+    other consumers, summed into grad_flow by the same launch (in place: the result IS gflow_add's buffer
+    when that tensor is contiguous and owned by this call)."""
+    g0, g1 = g0.contiguous(), g1.contiguous()
+    gi0 = torch.zeros_like(img0) if need_img else None
+    gi1 = torch.zeros_like(img1) if need_img else None
+    B, C = img0.shape[:2]
+    gflow = None
+    with torch.cuda.device(flow.device):
+        if flow.dim() == 5:
+            D, H, W = flow.shape[2:]
+            nb = 8 * flow.numel() + 8 * g0.numel() * 2 + (8 * img0.numel() if need_img else 0)
+            if gflow_add is not None:
+                gflow_add = _need_cuda_f32("grad_flow", gflow_add, 5)
+                gflow = torch.empty_like(flow)
+                _call("fs_warp3d_pair_bwd_acc", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
+                      g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), gflow_add.data_ptr(), gflow.data_ptr(),
+                      B, C, _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb + 4 * flow.numel())
+            else:
+                gflow = torch.empty_like(flow) if need_flow else None
+                _call("fs_warp3d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
+                      g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), _ptr(gflow), B, C,
+                      _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb)
+        else:
+            H, W = flow.shape[2:]
+            gflow = torch.empty_like(flow) if need_flow else None
+            _call("fs_warp2d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
+                  g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), _ptr(gflow), B, C,
+                  _in_hw(img0, flow), H, W, WARP2D_RIFE, _stream(flow))
+            if gflow_add is not None and gflow is not None:
+                gflow = gflow + gflow_add
+    return gi0, gi1, gflow
+
+
 class _WarpPair(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img0, img1, flow):
-        nd = flow.dim() - 2
-        if nd not in (2, 3):
-            raise ValueError("flow must be [B,4,H,W] or [B,6,D,H,W], got %s" % (tuple(flow.shape),))
-        img0 = _need_cuda_f32("img0", img0, nd + 2)
-        img1 = _need_cuda_f32("img1", img1, nd + 2)
-        flow = _need_cuda_f32("flow", flow, nd + 2)
-        if img0.shape != img1.shape:
-            raise ValueError("img0 %s and img1 %s differ" % (tuple(img0.shape), tuple(img1.shape)))
-        if flow.shape[0] != img0.shape[0] or flow.shape[1] != 2 * nd:
-            raise ValueError("flow %s does not match the images %s" %
-                             (tuple(flow.shape), tuple(img0.shape)))
-        if nd == 2 and flow.shape[2:] != img0.shape[2:]:
-            raise ValueError("2-D flow %s and images %s must have the same extent" %
-                             (tuple(flow.shape), tuple(img0.shape)))
-        if not (img0.device == img1.device == flow.device):
-            raise ValueError("operands are on different devices")
-        oshape = tuple(img0.shape[:2]) + tuple(flow.shape[2:])
-        out0, out1 = img0.new_empty(oshape), img1.new_empty(oshape)
-        with torch.cuda.device(flow.device):
-            if nd == 3:
-                B, C = img0.shape[:2]
-                D, H, W = flow.shape[2:]
-                _call("fs_warp3d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
-                      out0.data_ptr(), out1.data_ptr(), B, C, _in_dhw(img0, flow), D, H, W,
-                      _stream(flow), algo_bytes=4 * flow.numel() + 8 * out0.numel() * 2)
-            else:
-                B, C, H, W = img0.shape
-                _call("fs_warp2d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
-                                                out0.data_ptr(), out1.data_ptr(), B, C, H, W,
-                                                WARP2D_RIFE, _stream(flow))
+        img0, img1, flow, nd = _check_pair(img0, img1, flow)
+        out0, out1 = _pair_forward(img0, img1, flow, nd)
         ctx.save_for_backward(img0, img1, flow)
         return out0, out1
 
@@ -278,23 +329,39 @@ class _WarpPair(torch.autograd.Function):
         need_flow = ctx.needs_input_grad[2]
         if not (need_img or need_flow):
             return None, None, None
-        g0, g1 = g0.contiguous(), g1.contiguous()
-        gi0 = torch.zeros_like(img0) if need_img else None
-        gi1 = torch.zeros_like(img1) if need_img else None
-        gflow = torch.empty_like(flow) if need_flow else None
-        with torch.cuda.device(flow.device):
-            if flow.dim() == 5:
-                B, C = img0.shape[:2]
-                D, H, W = flow.shape[2:]
-                _call("fs_warp3d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
-                      g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), _ptr(gflow), B, C,
-                      _in_dhw(img0, flow), D, H, W, _stream(flow),
-                      algo_bytes=8 * flow.numel() + 8 * g0.numel() * 2 + (8 * img0.numel() if need_img else 0))
-            else:
-                B, C, H, W = img0.shape
-                _call("fs_warp2d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
-                                                g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1),
-                                                _ptr(gflow), B, C, H, W, WARP2D_RIFE, _stream(flow))
+        gi0, gi1, gflow = _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow)
+        return (gi0 if ctx.needs_input_grad[0] else None, gi1 if ctx.needs_input_grad[1] else None,
+                gflow)
+
+
+class _WarpPairAcc(torch.autograd.Function):
+    """(w0, w1, flow_out) with flow_out an alias of `flow`: the caller hands flow_out (not flow) to the
+    flow's other consumers, so autograd delivers THEIR summed gradient to this node, and the warp's
+    backward launch adds it to its own result (fs_warp3d_pair_bwd_acc) instead of autograd running a
+    separate add over the full-size flow."""
+
+    @staticmethod
+    def forward(ctx, img0, img1, flow):
+        img0, img1, flow_c, nd = _check_pair(img0, img1, flow)
+        out0, out1 = _pair_forward(img0, img1, flow_c, nd)
+        ctx.save_for_backward(img0, img1, flow_c)
+        ctx.set_materialize_grads(False)
+        return out0, out1, flow_c.view_as(flow_c)
+
+    @staticmethod
+    def backward(ctx, g0, g1, gflow_out):
+        img0, img1, flow = ctx.saved_tensors
+        need_img = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_flow = ctx.needs_input_grad[2]
+        if not (need_img or need_flow):
+            return None, None, None
+        if g0 is None and g1 is None:
+            return None, None, (gflow_out if need_flow else None)
+        oshape = tuple(img0.shape[:2]) + tuple(flow.shape[2:])
+        g0 = flow.new_zeros(oshape) if g0 is None else g0
+        g1 = flow.new_zeros(oshape) if g1 is None else g1
+        gi0, gi1, gflow = _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow,
+                                         gflow_out if need_flow else None)
         return (gi0 if ctx.needs_input_grad[0] else None, gi1 if ctx.needs_input_grad[1] else None,
                 gflow)
 
@@ -305,6 +372,82 @@ def warp_pair(img0, img1, flow):
         shape = (0, img0.shape[1]) + tuple(flow.shape[2:])
         return _empty_like_graph(shape, img0, flow), _empty_like_graph(shape, img1, flow)
     return _WarpPair.apply(img0, img1, flow)
+
+
+def warp_pair_acc(img0, img1, flow):
+    """warp_pair that also returns the flow for its OTHER consumers: (w0, w1, flow_out).  Use flow_out
+    downstream instead of `flow`; the gradient arriving there is folded into the warp's backward launch."""
+    if img0.shape[0] == 0 and img1.shape[0] == 0 and flow.shape[0] == 0 and flow.dim() in (4, 5):
+        return warp_pair(img0, img1, flow) + (flow,)
+    return _WarpPairAcc.apply(img0, img1, flow)
+
+
+class _UpsampleWarpPair(torch.autograd.Function):
+    """flow = prev + scale * trilinear_upsample(delta, factor); (w0, w1) = warp pair with that
+    flow -- one kernel forward (fs_upsample_warp3d_pair_fwd), and backward one warp launch that folds in the
+    gradient reaching `flow` from its other consumers plus the separable up-sampling adjoint."""
+
+    @staticmethod
+    def forward(ctx, img0, img1, delta, prev, factor, scale):
+        delta = _need_cuda_f32("delta", delta, 5)
+        img0 = _need_cuda_f32("img0", img0, 5)
+        img1 = _need_cuda_f32("img1", img1, 5)
+        B, C = img0.shape[:2]
+        if delta.shape[0] != B or delta.shape[1] != 6 or img0.shape != img1.shape:
+            raise ValueError("delta must be [B,6,d,h,w] for images %s / %s, got %s" %
+                             (tuple(img0.shape), tuple(img1.shape), tuple(delta.shape)))
+        Ds, Hs, Ws = delta.shape[2:]
+        full = (B, 6, Ds * factor, Hs * factor, Ws * factor)
+        if prev is not None:
+            prev = _need_cuda_f32("prev", prev, 5)
+            if tuple(prev.shape) != full:
+                raise ValueError("prev %s must have the up-sampled shape %s" % (tuple(prev.shape), full))
+        flow = delta.new_empty(full)
+        out0, out1 = img0.new_empty((B, C) + full[2:]), img0.new_empty((B, C) + full[2:])
+        with torch.cuda.device(delta.device):
+            _call("fs_upsample_warp3d_pair_fwd", img0.data_ptr(), img1.data_ptr(), delta.data_ptr(), _ptr(prev),
+                  flow.data_ptr(), out0.data_ptr(), out1.data_ptr(), B, C, _in_dhw(img0, flow), Ds, Hs, Ws,
+                  int(factor), float(scale), _stream(delta),
+                  algo_bytes=4 * (delta.numel() + flow.numel() * (2 if prev is not None else 1)) + 8 * out0.numel() * 2)
+        ctx.save_for_backward(img0, img1, flow)
+        ctx.cfg = (tuple(delta.shape), int(factor), float(scale), prev is not None)
+        ctx.set_materialize_grads(False)
+        return flow, out0, out1
+
+    @staticmethod
+    def backward(ctx, gflow_out, g0, g1):
+        img0, img1, flow = ctx.saved_tensors
+        dshape, factor, scale, has_prev = ctx.cfg
+        need_delta, need_prev = ctx.needs_input_grad[2], has_prev and ctx.needs_input_grad[3]
+        if not (need_delta or need_prev):
+            return (None,) * 6
+        B, C = img0.shape[:2]
+        Ds, Hs, Ws = dshape[2:]
+        D, H, W = flow.shape[2:]
+        if g0 is None and g1 is None and gflow_out is None:
+            return (None,) * 6
+        oshape = (B, C, D, H, W)
+        g0 = flow.new_zeros(oshape) if g0 is None else g0.contiguous()
+        g1 = flow.new_zeros(oshape) if g1 is None else g1.contiguous()
+        gadd = None if gflow_out is None else _need_cuda_f32("grad_flow", gflow_out, 5)
+        gtot = torch.empty_like(flow)
+        gdelta = flow.new_empty(dshape)
+        ws = flow.new_empty(B * 6 * (D * H * Ws + D * Hs * Ws))
+        with torch.cuda.device(flow.device):
+            _call("fs_upsample_warp3d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(), g0.data_ptr(),
+                  g1.data_ptr(), _ptr(gadd), gtot.data_ptr(), gdelta.data_ptr(), ws.data_ptr(), B, C,
+                  _in_dhw(img0, flow), Ds, Hs, Ws, factor, scale, _stream(flow),
+                  algo_bytes=8 * flow.numel() + 8 * g0.numel() * 2 + (4 * flow.numel() if gadd is not None else 0)
+                  + 4 * (flow.numel() + gdelta.numel()))
+        return None, None, (gdelta if need_delta else None), (gtot if need_prev else None), None, None
+
+
+def upsample_warp_pair(img0, img1, delta, prev, factor, scale=None):
+    """(flow, w0, w1) with flow = prev + scale * F.interpolate(delta, scale_factor=factor, trilinear,
+    align_corners=False) (prev may be None; scale defaults to factor, Flow-3D/model/IFNet.py:118) and
+    (w0, w1) = warp_pair(img0, img1, flow): IFBlock's flow up-scaling, the running-flow accumulation and the
+    two backward warps in one launch."""
+    return _UpsampleWarpPair.apply(img0, img1, delta, prev, int(factor), float(factor if scale is None else scale))
 
 
 # --------------------------------------------------------------------------------------------
@@ -766,26 +909,46 @@ def laploss2d(inp, target, max_levels=5):
 
 
 class _Interp3D(torch.autograd.Function):
+    """mul * F.interpolate(x, scale_factor = factor or 1/factor, trilinear, align_corners=False): HIP forward
+    (ATen's arithmetic, bit-identical) and gather-form HIP backward."""
+
     @staticmethod
-    def forward(ctx, x, factor, up):
-        sf = float(factor) if up else 1.0 / factor
-        y = torch.nn.functional.interpolate(x, scale_factor=sf, mode="trilinear", align_corners=False,
-                                            recompute_scale_factor=False)
-        ctx.cfg = (tuple(x.shape), int(factor), bool(up))
+    def forward(ctx, x, factor, up, mul):
+        x = _need_cuda_f32("x", x, 5)
+        B, C, Di, Hi, Wi = x.shape
+        with torch.cuda.device(x.device):
+            if up:
+                y = x.new_empty((B, C, Di * factor, Hi * factor, Wi * factor))
+                _call("fs_upsample3d_scale_add", x.data_ptr(), 0, y.data_ptr(), B, C, Di, Hi, Wi, int(factor),
+                      float(mul), _stream(x), algo_bytes=4 * (x.numel() + y.numel()))
+            else:
+                if min(Di, Hi, Wi) // factor < 1:
+                    raise ValueError("input %s is too small to be down-sampled by %d" % (tuple(x.shape), factor))
+                y = x.new_empty((B, C, Di // factor, Hi // factor, Wi // factor))
+                _call("fs_downsample3d_fwd", x.data_ptr(), y.data_ptr(), B, C, Di, Hi, Wi, int(factor), float(mul),
+                      _stream(x), algo_bytes=4 * (x.numel() + y.numel()))
+        ctx.cfg = (tuple(x.shape), int(factor), bool(up), float(mul))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        shape, factor, up = ctx.cfg
+        shape, factor, up, mul = ctx.cfg
         gy = _need_cuda_f32("grad_output", gy, 5)
         gx = gy.new_empty(shape)
         B, C, Di, Hi, Wi = shape
         Do, Ho, Wo = gy.shape[2:]
         ws = gy.new_empty(B * C * (Do * Ho * Wi + Do * Hi * Wi)) if up else None
         with torch.cuda.device(gy.device):
-            _call("fs_interp3d_bwd", gy.data_ptr(), gx.data_ptr(), _ptr(ws), B, C, Di, Hi, Wi, Do, Ho, Wo,
-                  factor, 1 if up else 0, _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()))
-        return gx, None, None
+            if up:
+                _call("fs_interp3d_bwd_scaled", gy.data_ptr(), gx.data_ptr(), ws.data_ptr(), B, C, Di, Hi, Wi, Do,
+                      Ho, Wo, factor, 1, mul, _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()),
+                      record_as="fs_interp3d_bwd")
+            else:
+                _call("fs_interp3d_bwd", gy.data_ptr(), gx.data_ptr(), 0, B, C, Di, Hi, Wi, Do, Ho, Wo,
+                      factor, 0, _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()))
+                if mul != 1.0:
+                    gx.mul_(mul)
+        return gx, None, None, None
 
 
 class _UpsampleScaleAdd(torch.autograd.Function):
@@ -817,10 +980,9 @@ class _UpsampleScaleAdd(torch.autograd.Function):
             Do, Ho, Wo = gout.shape[2:]
             ws = gout.new_empty(B * C * (Do * Ho * Wi + Do * Hi * Wi))
             with torch.cuda.device(gout.device):
-                _call("fs_interp3d_bwd", gout.data_ptr(), gs.data_ptr(), ws.data_ptr(), B, C, Di, Hi, Wi, Do, Ho,
-                      Wo, factor, 1, _stream(gout), algo_bytes=4 * (gout.numel() + gs.numel()))
-            if scale != 1.0:
-                gs.mul_(scale)
+                _call("fs_interp3d_bwd_scaled", gout.data_ptr(), gs.data_ptr(), ws.data_ptr(), B, C, Di, Hi, Wi, Do,
+                      Ho, Wo, factor, 1, scale, _stream(gout), algo_bytes=4 * (gout.numel() + gs.numel()),
+                      record_as="fs_interp3d_bwd")
         gp = gout if (has_prev and ctx.needs_input_grad[1]) else None
         return gs, gp, None, None
 
@@ -831,17 +993,67 @@ def upsample3d_scale_add(small, prev, factor, scale=1.0):
     return _UpsampleScaleAdd.apply(small, prev, int(factor), float(scale))
 
 
-def interpolate3d(x, scale_factor):
-    """F.interpolate(x, scale_factor, mode="trilinear", align_corners=False) for the IFBlock factors
-    (4, 2, 1/2, 1/4): ATen forward, HIP gather backward.  Other factors: stock autograd."""
+def _int_factor(scale_factor):
     for f in (2, 4):
-        if scale_factor == f or scale_factor == 1.0 / f:
-            up = scale_factor > 1
-            ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
-            if ok:
-                return _Interp3D.apply(x.contiguous(), f, up)
-    return torch.nn.functional.interpolate(x, scale_factor=scale_factor, mode="trilinear",
-                                           align_corners=False, recompute_scale_factor=False)
+        if scale_factor == f:
+            return f, True
+        if scale_factor == 1.0 / f:
+            return f, False
+    return None, None
+
+
+def interpolate3d(x, scale_factor, mul=1.0):
+    """mul * F.interpolate(x, scale_factor, mode="trilinear", align_corners=False) for the IFBlock factors
+    (4, 2, 1/2, 1/4) on the HIP kernels (forward and backward); other factors / dtypes: stock autograd."""
+    f, up = _int_factor(scale_factor)
+    if f is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and \
+            (up or min(x.shape[2:]) // f >= 1):
+        return _Interp3D.apply(x, f, up, float(mul))
+    y = torch.nn.functional.interpolate(x, scale_factor=scale_factor, mode="trilinear",
+                                        align_corners=False, recompute_scale_factor=False)
+    return y if mul == 1.0 else y * mul
+
+
+class _Interp2D(torch.autograd.Function):
+    """mul * F.interpolate(x, scale_factor = factor or 1/factor, bilinear, align_corners=False) of the 2-D
+    IFBlock (Flow-2D/model/IFNet.py:89, 92, 115-116): fs_resize2d_fwd / fs_resize2d_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, factor, up, mul):
+        x = _need_cuda_f32("x", x, 4)
+        B, C, Hi, Wi = x.shape
+        Ho, Wo = (Hi * factor, Wi * factor) if up else (Hi // factor, Wi // factor)
+        if min(Ho, Wo) < 1:
+            raise ValueError("input %s is too small to be down-sampled by %d" % (tuple(x.shape), factor))
+        y = x.new_empty((B, C, Ho, Wo))
+        with torch.cuda.device(x.device):
+            _call("fs_resize2d_fwd", x.data_ptr(), y.data_ptr(), B, C, Hi, Wi, Ho, Wo, int(factor), int(up),
+                  float(mul), _stream(x), algo_bytes=4 * (x.numel() + y.numel()))
+        ctx.cfg = (tuple(x.shape), int(factor), bool(up), float(mul))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, factor, up, mul = ctx.cfg
+        gy = _need_cuda_f32("grad_output", gy, 4)
+        B, C, Hi, Wi = shape
+        gx = gy.new_empty(shape)
+        with torch.cuda.device(gy.device):
+            _call("fs_resize2d_bwd", gy.data_ptr(), gx.data_ptr(), B, C, Hi, Wi, gy.shape[2], gy.shape[3], factor,
+                  int(up), mul, _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()))
+        return gx, None, None, None
+
+
+def interpolate2d(x, scale_factor, mul=1.0):
+    """mul * F.interpolate(x, scale_factor, mode="bilinear", align_corners=False) for the IFBlock factors on
+    the HIP kernels; other factors / dtypes: stock autograd."""
+    f, up = _int_factor(scale_factor)
+    if f is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and \
+            (up or min(x.shape[2:]) // f >= 1):
+        return _Interp2D.apply(x, f, up, float(mul))
+    y = torch.nn.functional.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=False,
+                                        recompute_scale_factor=False)
+    return y if mul == 1.0 else y * mul
 
 
 # --------------------------------------------------------------------------------------------

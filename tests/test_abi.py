@@ -35,7 +35,7 @@ def test_null_and_shape_errors_without_gpu():
     lib = _lib.lib()
     assert lib.fs_warp3d_fwd(None, None, None, 1, 1, None, 8, 8, 8, None) == 1      # NULLPTR
     assert lib.fs_warp3d_fwd(1, 1, 1, 1, 1, None, 1, 8, 8, None) == 2               # SHAPE (D < 2)
-    assert lib.fs_warp2d_fwd(1, 1, None, 1, 1, 1, 8, 8, 7, 0, None) == 3            # ARG (mode)
+    assert lib.fs_warp2d_fwd(1, 1, None, 1, 1, 1, None, 8, 8, 7, 0, None) == 3            # ARG (mode)
     assert lib.fs_corr2d_fwd(1, 1, 1, 1, 1, 8, 8, 5, None) == 3                     # ARG (md > 4)
     assert lib.fs_census_dist_fwd(1, 1, 1, 1, 8, 8, 2, None) == 3                   # ARG (md != 3)
     with pytest.raises(_lib.FlowsciKernelError):

@@ -15,7 +15,7 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def test_bench_json_contract():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "32", "--batch", "1", "--steps", "2",
-           "--warmup", "1", "--cpu-size", "16", "32"]
+           "--warmup", "1", "--cpu-size", "32", "48"]
     r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
@@ -34,7 +34,7 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] in ("port", "reference")
     assert cb["value"] > 0 and cb["cores"] >= 1
-    assert [x["size"] for x in cb["samples"]] == [16, 32]  # one bounded sample per --cpu-size edge
+    assert [x["size"] for x in cb["samples"]] == [32, 48]  # one bounded sample per --cpu-size edge
     # the bench line's own parity witness: the GPU model against the oracle on the CPU samples' batches
     pw = d["parity_at_cpu_size"]
     assert {"loss_gpu", "loss_oracle", "rel", "tolerance_rel", "sizes"} <= set(pw)
