@@ -201,6 +201,27 @@ int fs_corr2d_norm_bwd(const float* f1, const float* f2, const float* stats1, co
                        const float* grad_out, float* grad_n1, float* grad_n2,
                        int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
 
+/* Both directions of one pyramid level in ONE launch (UPFlow/model/upflow.py:649 and :652 correlate
+ * (x1, x2_warp) and (x2, x1_warp) at every level): set a = (f1a, f2a) -> outa, set b = (f1b, f2b) -> outb,
+ * identical shapes.  `stats` (nullable) = [4][B*C][2] (mean, rstd) tables of (f1a, f2a, f1b, f2b) as
+ * fs_plane_moments4 writes them: the normalize_features-folded variant; with it, the bwd gradients are
+ * w.r.t. the NORMALISED maps (chain them with fs_plane_norm_bwd4; a NULL grad_f skips that tensor).
+ * The five levels of a step cannot share a launch: level l's features are warped with the flow estimated at
+ * level l-1 (upflow.py:621-633). */
+int fs_corr2d_pair_fwd(const float* f1a, const float* f2a, const float* f1b, const float* f2b,
+                       const float* stats, float* outa, float* outb,
+                       int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
+int fs_corr2d_pair_bwd(const float* f1a, const float* f2a, const float* f1b, const float* f2b,
+                       const float* stats, const float* grad_outa, const float* grad_outb,
+                       float* grad_f1a, float* grad_f2a, float* grad_f1b, float* grad_f2b,
+                       int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
+int fs_plane_moments4(const float* fa, const float* fb, const float* fc, const float* fd, float* stats,
+                      int planes, int S, fs_stream_t stream);
+int fs_plane_norm_bwd4(const float* fa, const float* fb, const float* fc, const float* fd,
+                       const float* stats, const float* grad_na, const float* grad_nb,
+                       const float* grad_nc, const float* grad_nd, float* grad_fa, float* grad_fb,
+                       float* grad_fc, float* grad_fd, int planes, int S, fs_stream_t stream);
+
 /* 3-D correlation: NEW capability named by BASELINE.json (config 4); the reference has no 3-D cost
  * volume, so this generalises the 2-D layer above (dz-major, then dy, dx; channel mean; zero pad):
  *   f1, f2 [B,C,D,H,W] -> out [B,(2md+1)^3,D,H,W].  Pinned to the reference only through D = 1.

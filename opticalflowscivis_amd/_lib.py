@@ -56,6 +56,10 @@ SIGNATURES = {
     "fs_plane_norm_bwd": [_f32p] * 4 + [_int] * 2 + [_stream],
     "fs_corr2d_norm_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_corr2d_norm_bwd": [_f32p] * 7 + [_int] * 5 + [_stream],
+    "fs_corr2d_pair_fwd": [_f32p] * 7 + [_int] * 5 + [_stream],
+    "fs_corr2d_pair_bwd": [_f32p] * 11 + [_int] * 5 + [_stream],
+    "fs_plane_moments4": [_f32p] * 5 + [_int] * 2 + [_stream],
+    "fs_plane_norm_bwd4": [_f32p] * 13 + [_int] * 2 + [_stream],
     "fs_corr2d_fwd": [_f32p] * 3 + [_int] * 5 + [_stream],
     "fs_corr2d_bwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_robust_sum": [_f32p] * 5 + [_int] * 7 + [_float, _float, _stream],

@@ -197,18 +197,65 @@ struct Mover {
       }
     }
   }
-  // flow plane of slice d formed from channel volume `sv` of the low-resolution delta:
-  // prev + scale * trilinear_up(delta), arithmetic of fs_upsample3d_scale_add (bit-identical), stored to
-  // `oplane` and kept in registers in the layout `load` produces
-  __device__ static __forceinline__ void produce(const float* __restrict__ sv, const float* __restrict__ pplane,
-                                                 float* __restrict__ oplane, const W3P& p, const UpP& u, int d,
-                                                 int h0, int w0, elem (&r)[PASSES]) {
+  // ---- fused up-sampling producer ----------------------------------------------------------------------
+  // The flow plane of slice d is prev + scale * trilinear_up(delta) with the arithmetic of
+  // fs_upsample3d_scale_add (bit-identical).  The low-resolution source brick of the workgroup's whole
+  // 4-slice tile (<= 4 x 34 x 18 voxels per channel at factor 2, 2 x 18 x 10 at factor 4) is staged in LDS
+  // ONCE (`up_stage`); per slice, `up_prefetch` issues the running flow's float4 loads where the plain warp
+  // issues its flow loads (they land under the store phase and the barrier) and `up_finish` blends the 8
+  // corners from LDS, adds, writes the accumulated flow once and leaves the tile in registers in the layout
+  // `load` produces.
+  static constexpr int PZ = 4, PY = TH / 2 + 2, PX = TW / 2 + 2, PXP = PX + 1;
+  typedef float Brick[PZ][PY][PXP];
+
+  __device__ static __forceinline__ int up_i0(int o, int n_in, float rs) {
+    int i0, ip;
+    float l0, l1;
+    fs::trilinear_axis(o, n_in, rs, i0, ip, l0, l1);
+    return i0;
+  }
+
+  // stage channels c0..c0+2 of the delta (volumes sv + k * svol) around the tile (d0.., h0.., w0..)
+  __device__ static __forceinline__ void up_stage(Brick* sS, const float* __restrict__ sv, size_t svol,
+                                                  const W3P& p, const UpP& u, int d0, int h0, int w0) {
+    const int bz = up_i0(d0, u.Ds, u.rs), by = up_i0(min(h0, p.H - 1), u.Hs, u.rs),
+              bx = up_i0(min(w0, p.W - 1), u.Ws, u.rs);
+    for (int i = threadIdx.x; i < 3 * PZ * PY * PX; i += NT) {
+      const int c = i / (PZ * PY * PX), r1 = i - c * (PZ * PY * PX);
+      const int z = r1 / (PY * PX), r2 = r1 - z * (PY * PX);
+      const int y = r2 / PX, x = r2 - y * PX;
+      const int gz = min(bz + z, u.Ds - 1), gy = min(by + y, u.Hs - 1), gx = min(bx + x, u.Ws - 1);
+      sS[c][z][y][x] = sv[(size_t)c * svol + ((size_t)gz * u.Hs + gy) * u.Ws + gx];
+    }
+  }
+
+  __device__ static __forceinline__ void up_prefetch(const float* __restrict__ pplane, const W3P& p, int h0,
+                                                     int w0, elem (&q)[PASSES]) {
     const int t = threadIdx.x, col = t % LPR, row0 = t / LPR;
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+      const int h = min(h0 + row0 + it * RP, p.H - 1);
+      if (VEC) {
+        const int w = min(w0 + 4 * col, p.W - 4);
+        *reinterpret_cast<float4*>(&q[it]) = *reinterpret_cast<const float4*>(pplane + (size_t)h * p.W + w);
+      } else {
+        const int w = min(w0 + col, p.W - 1);
+        *reinterpret_cast<float*>(&q[it]) = pplane[(size_t)h * p.W + w];
+      }
+    }
+  }
+
+  __device__ static __forceinline__ void up_finish(const Brick& sb, bool has_prev, float* __restrict__ oplane,
+                                                   const W3P& p, const UpP& u, int d0, int d, int h0, int w0,
+                                                   const elem (&q)[PASSES], elem (&r)[PASSES]) {
+#pragma clang fp contract(off)
+    const int t = threadIdx.x, col = t % LPR, row0 = t / LPR;
+    const int bz = up_i0(d0, u.Ds, u.rs), by = up_i0(min(h0, p.H - 1), u.Hs, u.rs),
+              bx = up_i0(min(w0, p.W - 1), u.Ws, u.rs);
     int z0, zp;
     float lz0, lz1;
     fs::trilinear_axis(d, u.Ds, u.rs, z0, zp, lz0, lz1);
-    const float* sz0 = sv + (size_t)z0 * u.Hs * u.Ws;
-    const float* sz1 = sz0 + (size_t)zp * u.Hs * u.Ws;
+    const int za = z0 - bz, zb = za + zp;
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
       const int hq = h0 + row0 + it * RP;
@@ -216,29 +263,36 @@ struct Mover {
       int y0, yp;
       float ly0, ly1;
       fs::trilinear_axis(h, u.Hs, u.rs, y0, yp, ly0, ly1);
-      const float* s00 = sz0 + (size_t)y0 * u.Ws;
-      const float* s01 = s00 + yp * u.Ws;
-      const float* s10 = sz1 + (size_t)y0 * u.Ws;
-      const float* s11 = s10 + yp * u.Ws;
+      const int ya = y0 - by, yb = ya + yp;
+      const float* s00 = &sb[za][ya][0];
+      const float* s01 = &sb[za][yb][0];
+      const float* s10 = &sb[zb][ya][0];
+      const float* s11 = &sb[zb][yb][0];
+      const int wq = VEC ? w0 + 4 * col : w0 + col;
+      const int w = VEC ? min(wq, p.W - 4) : min(wq, p.W - 1);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < (VEC ? 4 : 1); ++i) {
+        int x0, xp;
+        float lx0, lx1;
+        fs::trilinear_axis(w + i, u.Ws, u.rs, x0, xp, lx0, lx1);
+        const int a = x0 - bx, b = a + xp;  // brick column j holds source column min(bx + j, Ws - 1)
+        // upsample_trilinear3d_out_frame's expression (trilinear_up_row in common.hpp)
+        const float v = lz0 * (ly0 * (lx0 * s00[a] + lx1 * s00[b]) + ly1 * (lx0 * s01[a] + lx1 * s01[b])) +
+                        lz1 * (ly0 * (lx0 * s10[a] + lx1 * s10[b]) + ly1 * (lx0 * s11[a] + lx1 * s11[b]));
+        o[i] = v * u.scale;
+      }
       if (VEC) {
-        const int wq = w0 + 4 * col;
-        const int w = min(wq, p.W - 4);
-        float o[4];
-        fs::trilinear_up_row<4>(s00, s01, s10, s11, lz0, lz1, ly0, ly1, u.rs, w, u.Ws, u.scale, o);
         float4 v = make_float4(o[0], o[1], o[2], o[3]);
-        if (pplane != nullptr) {
-          const float4 q = *reinterpret_cast<const float4*>(pplane + (size_t)h * p.W + w);
-          v.x = q.x + v.x; v.y = q.y + v.y; v.z = q.z + v.z; v.w = q.w + v.w;
+        if (has_prev) {
+          const float4 pq = *reinterpret_cast<const float4*>(&q[it]);
+          v.x = pq.x + v.x; v.y = pq.y + v.y; v.z = pq.z + v.z; v.w = pq.w + v.w;
         }
         if (hq < p.H && wq < p.W) *reinterpret_cast<float4*>(oplane + (size_t)h * p.W + w) = v;
         *reinterpret_cast<float4*>(&r[it]) = v;
       } else {
-        const int wq = w0 + col;
-        const int w = min(wq, p.W - 1);
-        float o[1];
-        fs::trilinear_up_row<1>(s00, s01, s10, s11, lz0, lz1, ly0, ly1, u.rs, w, u.Ws, u.scale, o);
         float v = o[0];
-        if (pplane != nullptr) v = pplane[(size_t)h * p.W + w] + v;
+        if (has_prev) v = *reinterpret_cast<const float*>(&q[it]) + v;
         if (hq < p.H && wq < p.W) oplane[(size_t)h * p.W + w] = v;
         *reinterpret_cast<float*>(&r[it]) = v;
       }
@@ -289,8 +343,9 @@ struct Mover {
   }
 };
 
+// (UPS: two 512-thread workgroups per CU = 4 waves per SIMD, i.e. <= 128 VGPRs, like the plain kernel)
 template <int NT, bool VEC, bool UPS>
-__global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* __restrict__ flow, UpP u,
+__global__ __launch_bounds__(NT, UPS ? 4 : 1) void warp3d_fwd_kernel(W3Fwd io, const float* __restrict__ flow, UpP u,
                                                         W3P p) {
   using M = Mover<NT, VEC>;
   constexpr int NW = TW / (NT / 64);  // voxels per thread and slice in the h-major phase
@@ -313,23 +368,37 @@ __global__ __launch_bounds__(NT) void warp3d_fwd_kernel(W3Fwd io, const float* _
   const float lin_h = fs::linspace_pm1(h, p.H, p.stepH);
 
   typename M::elem r0[M::PASSES], r1[M::PASSES], r2[M::PASSES];
-  // the three flow planes of slice d: loaded (plain warp) or formed from the low-resolution delta (UPS)
+  typename M::elem q0[M::PASSES], q1[M::PASSES], q2[M::PASSES];  // UPS: the running flow's tile (dead otherwise)
+  __shared__ typename M::Brick sS[UPS ? 3 : 1];
+  if constexpr (UPS) {
+    const size_t svol = (size_t)u.Ds * u.Hs * u.Ws;
+    M::up_stage(sS, u.small + fch * svol, svol, p, u, d0, h0, w0);
+    __syncthreads();
+  }
+  // the three flow planes of slice d: loads issued here -- of the flow itself (plain warp) or of the running
+  // flow (UPS; blended with the up-sampled delta by up_tiles at the top of the slice's iteration)
   auto flow_tiles = [&](int d) {
-    if (UPS) {
-      const size_t svol = (size_t)u.Ds * u.Hs * u.Ws;
-      const float* sv = u.small + fch * svol;
-      const float* pp = u.prev ? u.prev + fch * vol + (size_t)d * HW : nullptr;
-      float* op = u.fout + fch * vol + (size_t)d * HW;
-      M::produce(sv, pp, op, p, u, d, h0, w0, r0);
-      M::produce(sv + svol, pp ? pp + vol : nullptr, op + vol, p, u, d, h0, w0, r1);
-      M::produce(sv + 2 * svol, pp ? pp + 2 * vol : nullptr, op + 2 * vol, p, u, d, h0, w0, r2);
+    if constexpr (UPS) {
+      if (u.prev != nullptr) {
+        const float* pp = u.prev + fch * vol + (size_t)d * HW;
+        M::up_prefetch(pp, p, h0, w0, q0); M::up_prefetch(pp + vol, p, h0, w0, q1);
+        M::up_prefetch(pp + 2 * vol, p, h0, w0, q2);
+      }
     } else {
       const float* f = fb + (size_t)d * HW;
       M::load(f, p, h0, w0, r0); M::load(f + vol, p, h0, w0, r1); M::load(f + 2 * vol, p, h0, w0, r2);
     }
   };
+  auto up_tiles = [&](int d) {
+    float* op = u.fout + fch * vol + (size_t)d * HW;
+    const bool hp = u.prev != nullptr;
+    M::up_finish(sS[0], hp, op, p, u, d0, d, h0, w0, q0, r0);
+    M::up_finish(sS[UPS ? 1 : 0], hp, op + vol, p, u, d0, d, h0, w0, q1, r1);
+    M::up_finish(sS[UPS ? 2 : 0], hp, op + 2 * vol, p, u, d0, d, h0, w0, q2, r2);
+  };
   flow_tiles(d0);
   for (int d = d0; d < dEnd; ++d) {
+    if constexpr (UPS) up_tiles(d);  // blend the loaded corners, write the accumulated flow, fill r0..r2
     // phase 1: flow tile of this slice (already in registers) -> LDS
     M::to_lds(sF[0], r0); M::to_lds(sF[1], r1); M::to_lds(sF[2], r2);
     __syncthreads();

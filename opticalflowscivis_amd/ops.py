@@ -599,6 +599,69 @@ def corr2d_normalized(f1, f2, max_displacement=4):
     return _Corr2DNorm.apply(f1, f2, int(max_displacement))
 
 
+class _Corr2DPair(torch.autograd.Function):
+    """Both directions of one UPFlow pyramid level (upflow.py:649, 652) in one launch each way:
+    (corr(f1a, f2a), corr(f1b, f2b)); with `normalize` the per-(b,c)-plane normalisation of
+    normalize_features (upflow.py:96-138) is folded into the tile loads (§8f.4) and the four moment /
+    adjoint passes run as one launch each."""
+
+    @staticmethod
+    def forward(ctx, f1a, f2a, f1b, f2b, md, normalize):
+        ts = [_need_cuda_f32(n, t, 4) for n, t in (("f1a", f1a), ("f2a", f2a), ("f1b", f1b), ("f2b", f2b))]
+        f1a, f2a, f1b, f2b = ts
+        if not (f1a.shape == f2a.shape == f1b.shape == f2b.shape):
+            raise ValueError("the four feature maps must share one shape, got %s" % ([tuple(t.shape) for t in ts],))
+        B, C, H, W = f1a.shape
+        nd = 2 * md + 1
+        outa, outb = f1a.new_empty(B, nd * nd, H, W), f1a.new_empty(B, nd * nd, H, W)
+        stats = None
+        with torch.cuda.device(f1a.device):
+            s = _stream(f1a)
+            if normalize:
+                if H * W < 2:
+                    raise ValueError("per-plane variance needs at least two pixels")
+                stats = f1a.new_empty(4, B * C, 2)
+                _call("fs_plane_moments4", f1a.data_ptr(), f2a.data_ptr(), f1b.data_ptr(), f2b.data_ptr(),
+                      stats.data_ptr(), B * C, H * W, s, algo_bytes=16 * f1a.numel(), record_as="fs_plane_moments")
+            _call("fs_corr2d_pair_fwd", f1a.data_ptr(), f2a.data_ptr(), f1b.data_ptr(), f2b.data_ptr(), _ptr(stats),
+                  outa.data_ptr(), outb.data_ptr(), B, C, H, W, md, s,
+                  algo_bytes=8 * (2 * f1a.numel() + outa.numel()), algo_flops=4 * outa.numel() * C)
+        ctx.save_for_backward(f1a, f2a, f1b, f2b, stats)
+        ctx.md = md
+        return outa, outb
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        f1a, f2a, f1b, f2b, stats = ctx.saved_tensors
+        need = ctx.needs_input_grad[:4]
+        if not any(need):
+            return (None,) * 6
+        B, C, H, W = f1a.shape
+        nd = 2 * ctx.md + 1
+        ga = torch.zeros(B, nd * nd, H, W, device=f1a.device) if ga is None else _need_cuda_f32("grad_output", ga, 4)
+        gb = torch.zeros_like(ga) if gb is None else _need_cuda_f32("grad_output", gb, 4)
+        gn = [torch.empty_like(f1a) if n else None for n in need]
+        with torch.cuda.device(f1a.device):
+            s = _stream(f1a)
+            _call("fs_corr2d_pair_bwd", f1a.data_ptr(), f2a.data_ptr(), f1b.data_ptr(), f2b.data_ptr(), _ptr(stats),
+                  ga.data_ptr(), gb.data_ptr(), _ptr(gn[0]), _ptr(gn[1]), _ptr(gn[2]), _ptr(gn[3]), B, C, H, W,
+                  ctx.md, s, algo_bytes=8 * (2 * f1a.numel() + ga.numel()) + 4 * sum(f1a.numel() for n in need if n),
+                  algo_flops=4 * ga.numel() * C * sum(1 for n in need[:2] if n))
+            if stats is None:
+                return tuple(gn) + (None, None)
+            gf = [torch.empty_like(f1a) if n else None for n in need]
+            _call("fs_plane_norm_bwd4", f1a.data_ptr(), f2a.data_ptr(), f1b.data_ptr(), f2b.data_ptr(),
+                  stats.data_ptr(), _ptr(gn[0]), _ptr(gn[1]), _ptr(gn[2]), _ptr(gn[3]), _ptr(gf[0]), _ptr(gf[1]),
+                  _ptr(gf[2]), _ptr(gf[3]), B * C, H * W, s, algo_bytes=12 * f1a.numel() * sum(1 for n in need if n),
+                  record_as="fs_plane_norm_bwd")
+        return tuple(gf) + (None, None)
+
+
+def corr2d_pair(f1a, f2a, f1b, f2b, max_displacement=4, normalize=False):
+    """(corr2d(f1a, f2a), corr2d(f1b, f2b)) -- or their corr2d_normalized forms -- in one launch per pass."""
+    return _Corr2DPair.apply(f1a, f2a, f1b, f2b, int(max_displacement), bool(normalize))
+
+
 # --------------------------------------------------------------------------------------------
 # a9/a10: robust penalty + masked reduction (UPFlow/utils/loss.py:17-48, upflow.py:267-289)
 # --------------------------------------------------------------------------------------------

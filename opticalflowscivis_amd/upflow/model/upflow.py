@@ -311,8 +311,9 @@ class UPFlow_net(tools.abstract_model):
                 and not conf.norm_moments_across_images and feature_1.is_cuda):
             # §8f.4: per-plane normalisation folded into the cost-volume kernels' tile loads (the
             # normalised maps feed nothing else, upflow.py:635-652)
-            out_corr_1 = ops.corr2d_normalized(feature_1, feature_2_warp, 4)
-            out_corr_2 = ops.corr2d_normalized(feature_2, feature_1_warp, 4)
+            # both directions of the level in one launch per pass (moments, cost volume, and their adjoints)
+            out_corr_1, out_corr_2 = ops.corr2d_pair(feature_1, feature_2_warp, feature_2, feature_1_warp, 4,
+                                                     normalize=True)
         else:
             if conf.if_norm_before_cost_volume:
                 kw = dict(normalize=True, center=True,

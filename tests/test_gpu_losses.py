@@ -40,8 +40,13 @@ def test_corr2d_golden(ops, golden):
         assert float((g2.cpu() - torch.from_numpy(g[pre + "g2"])).abs().max()) < 2e-5
 
 
+# (the tiled LDS kernels above 512 pixels per sample, the direct kernels with 1 / 2 / 4 / 8 channel slices
+# per output below: the C3 pyramid shapes at a small and at the full batch, odd channel counts, md 1..4)
 @pytest.mark.parametrize("shape,md", [((2, 32, 38, 113), 4), ((3, 196, 3, 8), 4), ((1, 7, 19, 57), 4),
-                                      ((2, 5, 9, 40), 2), ((1, 3, 11, 33), 3), ((1, 4, 6, 6), 1)])
+                                      ((2, 5, 9, 40), 2), ((1, 3, 11, 33), 3), ((1, 4, 6, 6), 1),
+                                      ((32, 196, 3, 8), 4), ((32, 128, 5, 15), 4), ((2, 96, 10, 29), 4),
+                                      ((1, 50, 5, 15), 4), ((1, 27, 3, 8), 2), ((2, 64, 19, 57), 4),
+                                      ((1, 9, 40, 33), 4)])
 def test_corr2d_vs_oracle(ops, shape, md):
     g = torch.Generator().manual_seed(shape[1] * 31 + md)
     f1, f2 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
@@ -61,6 +66,29 @@ def test_corr2d_vs_oracle(ops, shape, md):
     out2 = ops.corr2d(c2, f2.to(DEV), md)
     (g1b,) = torch.autograd.grad((out2 * G.to(DEV)).sum(), [c2])
     assert torch.equal(g1b, g1)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 10, 29), (3, 32, 38, 113), (2, 128, 5, 15)])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_corr2d_pair_is_two_single_launches(ops, shape, normalize):
+    """Both directions of a pyramid level in one launch (upflow.py:649, 652) == the two single-direction ops,
+    outputs bit for bit, gradients bit for bit (same kernels, same per-output summation order); also when only
+    some of the four inputs need a gradient."""
+    g = torch.Generator().manual_seed(shape[1] + 7)
+    ts = [(1.3 * torch.randn(shape, generator=g) + 0.4).to(DEV) for _ in range(4)]
+    single = ops.corr2d_normalized if normalize else ops.corr2d
+    a = [t.clone().requires_grad_() for t in ts]
+    b = [t.clone().requires_grad_() for t in ts]
+    oa, ob = ops.corr2d_pair(a[0], a[1], a[2], a[3], 4, normalize=normalize)
+    ra, rb = single(b[0], b[1], 4), single(b[2], b[3], 4)
+    assert torch.equal(oa, ra) and torch.equal(ob, rb)
+    Ga, Gb = torch.randn(oa.shape, generator=g).to(DEV), torch.randn(ob.shape, generator=g).to(DEV)
+    gp = torch.autograd.grad((oa * Ga).sum() + (ob * Gb).sum(), a, retain_graph=True)
+    gs = torch.autograd.grad((ra * Ga).sum() + (rb * Gb).sum(), b)
+    for x, y in zip(gp, gs):
+        assert torch.equal(x, y)
+    (g1,) = torch.autograd.grad((ob * Gb).sum(), [a[3]])  # one set, one operand
+    assert torch.equal(g1, gs[3])
 
 
 def test_correlation_cuda_dropin(ops):

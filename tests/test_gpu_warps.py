@@ -220,8 +220,10 @@ def test_operand_validation(ops):
         ops.warp3d(x.double(), torch.zeros(1, 3, 8, 8, 8, device=DEV))
     with pytest.raises(ValueError):
         ops.warp3d(x.cpu(), torch.zeros(1, 3, 8, 8, 8))
+    with pytest.raises(ValueError):  # batch mismatch (a different EXTENT is legal for the RIFE warp only)
+        ops.warp2d(torch.rand(1, 1, 8, 8, device=DEV), torch.zeros(2, 2, 8, 8, device=DEV))
     with pytest.raises(ValueError):
-        ops.warp2d(torch.rand(1, 1, 8, 8, device=DEV), torch.zeros(1, 2, 8, 9, device=DEV))
+        ops.warp2d_pwc(torch.rand(1, 1, 8, 8, device=DEV), torch.zeros(1, 2, 8, 9, device=DEV), with_mask=True)
 
 
 def test_wild_flows_do_not_fault(ops):
