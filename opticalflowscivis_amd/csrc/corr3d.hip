@@ -11,96 +11,107 @@
 // oracle/corr.py::corr3d_closed.  The (2md+1)^3-channel output makes this a coarse-pyramid-level op
 // (md = 4: 729 channels).
 //
-// Design = corr2d per (z, dz) plane pair: forward, one workgroup = (8x32-pixel tile of slice z) x
-// (displacement plane dz), 2md+1 waves = dy rows, lane = 4 consecutive x, channels streamed through
-// LDS in chunks of 8.  Backward, thread = voxel, loops dz with its (2md+1)^2 upstream values of that
-// plane in registers and 8 channel accumulators; grad_f2 through the transposed-displacement
-// identity; no atomics.
+// Forward: one workgroup = one 8x32-pixel tile of slice z for ALL (2md+1)^3 displacements: the f1 tile of
+// every channel is staged in LDS once (C <= 32 / C <= 64: 1 KB per channel), then the kernel loops over the 2md+1
+// displacement planes dz; per plane, 2md+1 waves = dy rows, lane = 4 consecutive x (4 x (2md+1)
+// accumulators), the f2 search window of plane z+dz streamed through LDS in chunks of 8 channels, and the
+// plane's (2md+1)^2 output channels written before the next dz starts.  (Round 1 launched one workgroup per
+// (z, dz) pair, which re-staged the f1 tile 2md+1 times.)  C > 64 re-stages f1 per chunk.
+// Algorithmic HBM bytes: 4 (2C + (2md+1)^3) per voxel -- the (2md+1)^3-channel output dominates (729 of the
+// 793 floats per voxel at C = 32, md = 4): the kernel is bound by its output stream.
+// Backward, thread = voxel, loops dz with its (2md+1)^2 upstream values of that plane in registers and 8
+// channel accumulators; grad_f2 through the transposed-displacement identity; no atomics.
 #include "common.hpp"
 
 namespace {
 
 constexpr int TY = 8, TX = 32, CC = 8;
 
-template <int MD>
+// C1: channels of the f1 tile kept resident in LDS (32 / 64; 0 = re-staged per chunk)
+template <int MD, int C1>
 __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr3d_fwd_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out, int C, int D,
     int H, int W) {
   constexpr int ND = 2 * MD + 1;
   constexpr int SR = TY + 2 * MD, SCOLS = TX + 2 * MD, SW = (SCOLS + 3) / 4 * 4, NT = 64 * ND;
   __shared__ __attribute__((aligned(16))) float s2[CC][SR][SW];
-  __shared__ __attribute__((aligned(16))) float s1[CC][TY][TX];
+  constexpr bool RESIDENT = C1 > 0;
+  __shared__ __attribute__((aligned(16))) float s1[RESIDENT ? C1 : CC][TY][TX];
 
-  int bz = blockIdx.z;
-  const int dzi = bz % ND; bz /= ND;
-  const int z = bz % D;
-  const int b = bz / D;
-  const int z2 = z + dzi - MD;
+  const int z = blockIdx.z % D;
+  const int b = blockIdx.z / D;
   const int y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
   const int t = threadIdx.x, lane = t & 63, dy = t >> 6;
   const int qy = lane >> 3, qx = (lane & 7) * 4;
   const size_t HW = (size_t)H * W, vol = (size_t)D * HW;
   const float* f1b = f1 + (size_t)b * C * vol + (size_t)z * HW;
-  const float* f2b = f2 + (size_t)b * C * vol + (size_t)(z2 < 0 ? 0 : (z2 >= D ? D - 1 : z2)) * HW;
-  const bool zin = (z2 >= 0 && z2 < D);
+  const int y = y0 + qy;
+  const float fC = (float)C;
 
-  float acc[4][ND];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < ND; ++j) acc[i][j] = 0.f;
+  auto stage_f1 = [&](int c0, int nch) {  // channels c0 .. c0+nch-1 -> s1[0 .. nch-1] (zeros past C / the image)
+    for (int i = t; i < nch * TY * TX; i += NT) {
+      const int c = i / (TY * TX), rem = i - c * (TY * TX);
+      const int r = rem / TX, col = rem - r * TX;
+      const int gy = y0 + r, gx = x0 + col;
+      float v = 0.f;
+      if (c0 + c < C && gy < H && gx < W) v = f1b[(size_t)(c0 + c) * vol + (size_t)gy * W + gx];
+      s1[c][r][col] = v;
+    }
+  };
+  if (RESIDENT) stage_f1(0, (C + CC - 1) / CC * CC);  // visible after the first barrier below
 
-  if (zin) {
-    for (int c0 = 0; c0 < C; c0 += CC) {
-      for (int i = t; i < CC * SR * SCOLS; i += NT) {
-        const int c = i / (SR * SCOLS), rem = i - c * (SR * SCOLS);
-        const int r = rem / SCOLS, col = rem - r * SCOLS;
-        const int gy = y0 + r - MD, gx = x0 + col - MD;
-        float v = 0.f;
-        if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
-          v = f2b[(size_t)(c0 + c) * vol + (size_t)gy * W + gx];
-        s2[c][r][col] = v;
-      }
-      for (int i = t; i < CC * TY * TX; i += NT) {
-        const int c = i / (TY * TX), rem = i - c * (TY * TX);
-        const int r = rem / TX, col = rem - r * TX;
-        const int gy = y0 + r, gx = x0 + col;
-        float v = 0.f;
-        if (c0 + c < C && gy < H && gx < W) v = f1b[(size_t)(c0 + c) * vol + (size_t)gy * W + gx];
-        s1[c][r][col] = v;
-      }
-      __syncthreads();
+  for (int dzi = 0; dzi < ND; ++dzi) {
+    const int z2 = z + dzi - MD;
+    float acc[4][ND];
 #pragma unroll
-      for (int c = 0; c < CC; ++c) {
-        const float4 a = *reinterpret_cast<const float4*>(&s1[c][qy][qx]);
-        float row[4 + 2 * MD + 3];
-        const float* rp = &s2[c][qy + dy][qx];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < (4 + 2 * MD + 3) / 4; ++k) {
-          const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
-          row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+      for (int j = 0; j < ND; ++j) acc[i][j] = 0.f;
+    if (z2 >= 0 && z2 < D) {  // uniform per block; outside: the plane's channels are zero
+      const float* f2b = f2 + (size_t)b * C * vol + (size_t)z2 * HW;
+      for (int c0 = 0; c0 < C; c0 += CC) {
+        for (int i = t; i < CC * SR * SCOLS; i += NT) {
+          const int c = i / (SR * SCOLS), rem = i - c * (SR * SCOLS);
+          const int r = rem / SCOLS, col = rem - r * SCOLS;
+          const int gy = y0 + r - MD, gx = x0 + col - MD;
+          float v = 0.f;
+          if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = f2b[(size_t)(c0 + c) * vol + (size_t)gy * W + gx];
+          s2[c][r][col] = v;
         }
-        const float av[4] = {a.x, a.y, a.z, a.w};
+        if (!RESIDENT) stage_f1(c0, CC);
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int c = 0; c < CC; ++c) {
+          const float4 a = *reinterpret_cast<const float4*>(&s1[RESIDENT ? c0 + c : c][qy][qx]);
+          float row[4 + 2 * MD + 3];
+          const float* rp = &s2[c][qy + dy][qx];
 #pragma unroll
-          for (int j = 0; j < ND; ++j) acc[i][j] = fmaf(av[i], row[i + j], acc[i][j]);
+          for (int k = 0; k < (4 + 2 * MD + 3) / 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
+            row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+          }
+          const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc[i][j] = fmaf(av[i], row[i + j], acc[i][j]);
+        }
+        __syncthreads();
       }
-      __syncthreads();
+    }
+    if (y < H) {
+      // channel = (dzi*ND + dy)*ND + dx
+      float* ob = out + (((size_t)b * ND * ND * ND + ((size_t)dzi * ND + dy) * ND) * D + z) * HW + (size_t)y * W;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int x = x0 + qx + i;
+          if (x < W) ob[(size_t)j * vol + x] = acc[i][j] / fC;
+        }
     }
   }
-  const int y = y0 + qy;
-  if (y >= H) return;
-  const float fC = (float)C;
-  // channel = (dzi*ND + dy)*ND + dx
-  float* ob = out + (((size_t)b * ND * ND * ND + ((size_t)dzi * ND + dy) * ND) * D + z) * HW + (size_t)y * W;
-#pragma unroll
-  for (int j = 0; j < ND; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = x0 + qx + i;
-      if (x < W) ob[(size_t)j * vol + x] = acc[i][j] / fC;
-    }
 }
 
 // grad[c, p] = (1/C) sum_d g(d, p) * other[c, p + d]; blockIdx.z < B*D: (gout, f2) -> grad_f1,
@@ -187,7 +198,7 @@ int check_shape(int B, int C, int D, int H, int W, int md) {
   if (B < 1 || C < 1 || D < 1 || H < 1 || W < 1) return FS_ERR_SHAPE;
   if (md < 1 || md > 4) return FS_ERR_ARG;
   const long long nd = 2 * md + 1;
-  if (2ll * B * D * nd > 65535 || fs::cdiv(H, TY) > 65535) return FS_ERR_SHAPE;
+  if (2ll * B * D > 65535 || fs::cdiv(H, TY) > 65535) return FS_ERR_SHAPE;
   if (nd * nd * nd * D * H * W >= (1ll << 40)) return FS_ERR_SHAPE;
   return FS_OK;
 }
@@ -197,8 +208,13 @@ int launch(const float* f1, const float* f2, const float* gout, float* out, floa
            int C, int D, int H, int W, bool bwd, hipStream_t st) {
   constexpr int ND = 2 * MD + 1;
   if (!bwd) {
-    dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), B * D * ND);
-    hipLaunchKernelGGL(corr3d_fwd_kernel<MD>, grid, dim3(64 * ND), 0, st, f1, f2, out, C, D, H, W);
+    dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), B * D);
+    if (C <= 32)
+      hipLaunchKernelGGL((corr3d_fwd_kernel<MD, 32>), grid, dim3(64 * ND), 0, st, f1, f2, out, C, D, H, W);
+    else if (C <= 64)
+      hipLaunchKernelGGL((corr3d_fwd_kernel<MD, 64>), grid, dim3(64 * ND), 0, st, f1, f2, out, C, D, H, W);
+    else
+      hipLaunchKernelGGL((corr3d_fwd_kernel<MD, 0>), grid, dim3(64 * ND), 0, st, f1, f2, out, C, D, H, W);
   } else {
     dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), 2 * B * D);
     hipLaunchKernelGGL(corr3d_bwd_kernel<MD>, grid, dim3(256), 0, st, f1, f2, gout, g1, g2, B, C, D, H, W);
