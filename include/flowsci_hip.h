@@ -374,6 +374,21 @@ int fs_laploss2d_fwd(const float* input, const float* target, float* sgn, float*
 int fs_laploss2d_bwd(const float* sgn, const float* grad_loss, float* ws, float* grad_diff,
                      int N, int H, int W, int levels, fs_stream_t stream);
 
+/* f3, second half: the 3-D Laplacian-pyramid L1 loss.  PARITY UNPINNED: Flow-3D/model/laplacian.py:37-91 is
+ * dead code in the reference (commented out of Model.update, Flow-3D/model/RIFE.py:126,132) whose conv_gauss
+ * (:44-58) ignores its kernel, round-trips through scipy.ndimage.gaussian_filter on the CPU over all five
+ * axes and detaches the result.  Built here: the 3-D analogue of the 2-D loss above -- filtered = G3(reflect
+ * pad 2)(cur) with G3 = g (x) g (x) g, g = [1,4,6,4,1]/16; down = filtered[::2,::2,::2]; up = (8 G3)(reflect
+ * pad 2)(zero-interleave(down)) (the reference's `x_up * 8`, laplacian.py:41); pyr = cur - up; loss =
+ * sum_l mean |pyr_l(input) - pyr_l(target)|.  Same buffer protocol as fs_laploss2d_*; input, target
+ * [N,D,H,W] (N = B*C); every level needs extent >= 3 per axis. */
+int fs_laploss3d_sizes(int N, int D, int H, int W, int levels, long long* sgn_floats,
+                       long long* ws_fwd_floats, long long* ws_bwd_floats);
+int fs_laploss3d_fwd(const float* input, const float* target, float* sgn, float* ws, float* loss,
+                     int N, int D, int H, int W, int levels, fs_stream_t stream);
+int fs_laploss3d_bwd(const float* sgn, const float* grad_loss, float* ws, float* grad_diff,
+                     int N, int D, int H, int W, int levels, fs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Forward pass of the IFNet-3D convolutions as an implicit GEMM on the fp32 matrix cores
  * (companion of fs_conv3d_wrw; `conv()` / IFBlock.conv0 / convblock in Flow-3D/model/IFNet.py:13-29,

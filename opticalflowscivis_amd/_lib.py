@@ -43,6 +43,9 @@ SIGNATURES = {
     "fs_laploss2d_sizes": [_int] * 4 + [_i64p] * 3,
     "fs_laploss2d_fwd": [_f32p] * 5 + [_int] * 4 + [_stream],
     "fs_laploss2d_bwd": [_f32p] * 4 + [_int] * 4 + [_stream],
+    "fs_laploss3d_sizes": [_int] * 5 + [_i64p] * 3,
+    "fs_laploss3d_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
+    "fs_laploss3d_bwd": [_f32p] * 4 + [_int] * 5 + [_stream],
     "fs_conv3d_fwd_ws_floats": [_int] * 3,
     "fs_conv3d_fwd": [_f32p] * 5 + [_int] * 13 + [_stream],
     "fs_upsample3d_scale_add": [_f32p] * 3 + [_int] * 6 + [_float, _stream],

@@ -19,8 +19,10 @@
 // (z, dz) pair, which re-staged the f1 tile 2md+1 times.)  C > 64 re-stages f1 per chunk.
 // Algorithmic HBM bytes: 4 (2C + (2md+1)^3) per voxel -- the (2md+1)^3-channel output dominates (729 of the
 // 793 floats per voxel at C = 32, md = 4): the kernel is bound by its output stream.
-// Backward, thread = voxel, loops dz with its (2md+1)^2 upstream values of that plane in registers and 8
-// channel accumulators; grad_f2 through the transposed-displacement identity; no atomics.
+// Backward, thread = voxel: per group of 16 channels (16 accumulators in registers) it loops dz with the
+// (2md+1)^2 upstream values of that plane in registers -- every upstream value is read once per 16 channels
+// (round 1: once per 8) -- and the other map's plane staged through LDS in chunks of 8 channels; grad_f2
+// through the transposed-displacement identity; no atomics.  Algorithmic bytes 4 (4C + (2md+1)^3) per voxel.
 #include "common.hpp"
 
 namespace {
@@ -60,6 +62,30 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr3d_fwd_kernel(
   };
   if (RESIDENT) stage_f1(0, (C + CC - 1) / CC * CC);  // visible after the first barrier below
 
+  // f2 window staging: chunk- and plane-invariant in-plane offsets resolved once; a chunk's loads are issued
+  // back to back, branch-free, into registers, the next chunk's under the current chunk's FMA phase
+  // (corr2d.hip's staging)
+  constexpr int N2 = CC * SR * SCOLS, IT2 = (N2 + NT - 1) / NT;
+  int off2[IT2];  // in-plane offset, -1: outside the image
+#pragma unroll
+  for (int it = 0; it < IT2; ++it) {
+    const int i = t + NT * it;
+    const int rem = i % (SR * SCOLS);
+    const int r = rem / SCOLS, col = rem - r * SCOLS;
+    const int gy = y0 + r - MD, gx = x0 + col - MD;
+    off2[it] = (i < N2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+  }
+  float r2[IT2];
+  auto fetch = [&](const float* f2b, int c0) {
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {
+      const int c = c0 + (t + NT * it) / (SR * SCOLS);
+      const bool ok = off2[it] >= 0 && c < C;
+      const float v = f2b[ok ? (size_t)c * vol + off2[it] : 0];
+      r2[it] = ok ? v : 0.f;
+    }
+  };
+
   for (int dzi = 0; dzi < ND; ++dzi) {
     const int z2 = z + dzi - MD;
     float acc[4][ND];
@@ -69,18 +95,17 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr3d_fwd_kernel(
       for (int j = 0; j < ND; ++j) acc[i][j] = 0.f;
     if (z2 >= 0 && z2 < D) {  // uniform per block; outside: the plane's channels are zero
       const float* f2b = f2 + (size_t)b * C * vol + (size_t)z2 * HW;
+      fetch(f2b, 0);
       for (int c0 = 0; c0 < C; c0 += CC) {
-        for (int i = t; i < CC * SR * SCOLS; i += NT) {
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+          const int i = t + NT * it;
           const int c = i / (SR * SCOLS), rem = i - c * (SR * SCOLS);
-          const int r = rem / SCOLS, col = rem - r * SCOLS;
-          const int gy = y0 + r - MD, gx = x0 + col - MD;
-          float v = 0.f;
-          if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = f2b[(size_t)(c0 + c) * vol + (size_t)gy * W + gx];
-          s2[c][r][col] = v;
+          if (i < N2) s2[c][rem / SCOLS][rem % SCOLS] = r2[it];
         }
         if (!RESIDENT) stage_f1(c0, CC);
         __syncthreads();
+        if (c0 + CC < C) fetch(f2b, c0 + CC);
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
           const float4 a = *reinterpret_cast<const float4*>(&s1[RESIDENT ? c0 + c : c][qy][qx]);
@@ -115,8 +140,10 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr3d_fwd_kernel(
 }
 
 // grad[c, p] = (1/C) sum_d g(d, p) * other[c, p + d]; blockIdx.z < B*D: (gout, f2) -> grad_f1,
-// else (gout transposed on the fly, f1) -> grad_f2.
-template <int MD>
+// else (gout transposed on the fly, f1) -> grad_f2.  Thread = voxel.  Loop order: channel group (CG = 16
+// accumulators in registers) > displacement plane dz (its (2md+1)^2 upstream values loaded ONCE per group,
+// branch-free) > chunks of 8 channels of the other map's plane z+dz staged in LDS.
+template <int MD, int CG>
 __global__ __launch_bounds__(256) void corr3d_bwd_kernel(const float* __restrict__ f1,
                                                          const float* __restrict__ f2,
                                                          const float* __restrict__ gout,
@@ -124,14 +151,15 @@ __global__ __launch_bounds__(256) void corr3d_bwd_kernel(const float* __restrict
                                                          int B, int C, int D, int H, int W) {
   constexpr int ND = 2 * MD + 1;
   constexpr int SR = TY + 2 * MD, SW = TX + 2 * MD;
+  constexpr int NS = CC * SR * SW, ITS = (NS + 255) / 256;
   __shared__ float s[CC][SR][SW];
   int bz = blockIdx.z;
   const bool second = bz >= B * D;
   if (second) bz -= B * D;
   const int z = bz % D, b = bz / D;
-  float* grad = second ? g2 : g1;
+  float* __restrict__ grad = second ? g2 : g1;
   if (grad == nullptr) return;
-  const float* other = second ? f1 : f2;
+  const float* __restrict__ other = second ? f1 : f2;
   const int y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
   const int t = threadIdx.x, py = t / TX, px = t % TX;
   const int y = y0 + py, x = x0 + px;
@@ -141,10 +169,20 @@ __global__ __launch_bounds__(256) void corr3d_bwd_kernel(const float* __restrict
   const float* ob = other + (size_t)b * C * vol;
   const float fC = (float)C;
 
-  for (int c0 = 0; c0 < C; c0 += CC) {
-    float acc[CC];
+  int offs[ITS];  // in-plane offset of the staged elements, -1: outside the image
 #pragma unroll
-    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+  for (int it = 0; it < ITS; ++it) {
+    const int i = t + 256 * it;
+    const int rem = i % (SR * SW);
+    const int r = rem / SW, col = rem - r * SW;
+    const int gy = y0 + r - MD, gx = x0 + col - MD;
+    offs[it] = (i < NS && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+  }
+
+  for (int cg = 0; cg < C; cg += CG) {
+    float acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = 0.f;
     for (int k = 0; k < ND; ++k) {       // displacement plane dz = k - MD
       const int zz = z + k - MD;
       if (zz < 0 || zz >= D) continue;  // uniform per block
@@ -153,44 +191,56 @@ __global__ __launch_bounds__(256) void corr3d_bwd_kernel(const float* __restrict
       for (int j = 0; j < ND; ++j)
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-          float v = 0.f;
-          if (live) {
-            if (!second) {
-              v = gb[((size_t)((k * ND + j) * ND + i) * D + z) * HW + (size_t)y * W + x];
-            } else {  // gT[d, q] = g[-d, q + d]
-              const int yy = y + (j - MD), xx = x + (i - MD);
-              if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-                v = gb[((size_t)(((ND - 1 - k) * ND + (ND - 1 - j)) * ND + (ND - 1 - i)) * D + zz) * HW +
-                       (size_t)yy * W + xx];
-            }
+          // 32-bit element offsets inside one sample's upstream tensor (check_shape bounds it): one address
+          // register per load in flight instead of two
+          unsigned idx;
+          bool ok = live;
+          if (!second) {
+            idx = ((unsigned)((k * ND + j) * ND + i) * D + z) * (unsigned)HW + (unsigned)(y * W + x);
+          } else {  // gT[d, q] = g[-d, q + d]
+            const int yy = y + (j - MD), xx = x + (i - MD);
+            ok = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            idx = ((unsigned)(((ND - 1 - k) * ND + (ND - 1 - j)) * ND + (ND - 1 - i)) * D + zz) * (unsigned)HW +
+                  (unsigned)(yy * W + xx);
           }
-          g[j][i] = v;
+          const float v = gb[ok ? idx : 0u];
+          g[j][i] = ok ? v : 0.f;
         }
-      for (int i = t; i < CC * SR * SW; i += 256) {
-        const int c = i / (SR * SW), rem = i - c * (SR * SW);
-        const int r = rem / SW, col = rem - r * SW;
-        const int gy = y0 + r - MD, gx = x0 + col - MD;
-        float v = 0.f;
-        if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
-          v = ob[(size_t)(c0 + c) * vol + (size_t)zz * HW + (size_t)gy * W + gx];
-        s[c][r][col] = v;
+      const float* op = ob + (size_t)zz * HW;
+#pragma unroll
+      for (int cc = 0; cc < CG; cc += CC) {
+        const int c0 = cg + cc;
+        if (c0 >= C) break;  // uniform
+        float rs[ITS];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int c = c0 + (t + 256 * it) / (SR * SW);
+          const bool ok = offs[it] >= 0 && c < C;
+          const float v = op[ok ? (size_t)c * vol + offs[it] : 0];
+          rs[it] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int i = t + 256 * it;
+          if (i < NS) (&s[0][0][0])[i] = rs[it];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+          float a = acc[cc + c];
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+#pragma unroll
+            for (int i = 0; i < ND; ++i) a = fmaf(g[j][i], s[c][py + j][px + i], a);
+          acc[cc + c] = a;
+        }
+        __syncthreads();
       }
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < CC; ++c) {
-        float a = acc[c];
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-#pragma unroll
-          for (int i = 0; i < ND; ++i) a = fmaf(g[j][i], s[c][py + j][px + i], a);
-        acc[c] = a;
-      }
-      __syncthreads();
     }
     if (live)
 #pragma unroll
-      for (int c = 0; c < CC; ++c)
-        if (c0 + c < C) grad[((size_t)b * C + c0 + c) * vol + (size_t)z * HW + (size_t)y * W + x] = acc[c] / fC;
+      for (int c = 0; c < CG; ++c)
+        if (cg + c < C) grad[((size_t)b * C + cg + c) * vol + (size_t)z * HW + (size_t)y * W + x] = acc[c] / fC;
   }
 }
 
@@ -199,7 +249,7 @@ int check_shape(int B, int C, int D, int H, int W, int md) {
   if (md < 1 || md > 4) return FS_ERR_ARG;
   const long long nd = 2 * md + 1;
   if (2ll * B * D > 65535 || fs::cdiv(H, TY) > 65535) return FS_ERR_SHAPE;
-  if (nd * nd * nd * D * H * W >= (1ll << 40)) return FS_ERR_SHAPE;
+  if (nd * nd * nd * D * H * W >= (1ll << 30)) return FS_ERR_SHAPE;  // 32-bit offsets inside one sample's cost volume
   return FS_OK;
 }
 
@@ -217,7 +267,7 @@ int launch(const float* f1, const float* f2, const float* gout, float* out, floa
       hipLaunchKernelGGL((corr3d_fwd_kernel<MD, 0>), grid, dim3(64 * ND), 0, st, f1, f2, out, C, D, H, W);
   } else {
     dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), 2 * B * D);
-    hipLaunchKernelGGL(corr3d_bwd_kernel<MD>, grid, dim3(256), 0, st, f1, f2, gout, g1, g2, B, C, D, H, W);
+    hipLaunchKernelGGL((corr3d_bwd_kernel<MD, 8>), grid, dim3(256), 0, st, f1, f2, gout, g1, g2, B, C, D, H, W);
   }
   FS_LAUNCH_CHECK();
   return FS_OK;

@@ -155,6 +155,10 @@ class Model3D(ModelBase):
     """Flow-3D/model/RIFE.py:18-275."""
     nd = 3
 
+    def __init__(self, local_rank=-1, arbitrary=False, device=None):
+        super().__init__(local_rank, arbitrary, device)
+        self.lap = LapLoss()  # constructed by the reference too (RIFE.py:30); see update(lap_loss=...)
+
     def inference(self, img0, img1, scale_list=(4, 2, 1), TTA=False, timestep=0.5):
         imgs = torch.cat((img0, img1), 1)
         flow, mask, merged, _, _, _ = self.flownet(imgs, scale_list, timestep=timestep)
@@ -162,7 +166,10 @@ class Model3D(ModelBase):
             raise NotImplementedError("TTA is 'not implemented' in the reference too (RIFE.py:76)")
         return merged[2], flow, mask
 
-    def update(self, imgs, gt, learning_rate=0, mul=1, training=True, flow_gt=None):
+    def update(self, imgs, gt, learning_rate=0, mul=1, training=True, flow_gt=None, lap_loss=False):
+        """`lap_loss=True` swaps the two L1 terms for the Laplacian-pyramid loss the reference has commented
+        out (RIFE.py:126, 133: `(self.lap(merged[2], gt)).mean()`), computed by the 3-D pyramid kernels; the
+        default is the reference's active path."""
         self._set_lr(learning_rate)
         if training:
             self.train()
@@ -172,8 +179,9 @@ class Model3D(ModelBase):
             torch.cat((imgs, gt), 1), scale=[4, 2, 1])
         sp = tuple(min(a, b) for a, b in zip(imgs.shape[2:], mask.shape[2:]))
         gt = gt[(slice(None), slice(None)) + tuple(slice(0, s) for s in sp)]
-        loss_l1 = ops.l1_loss(merged[2], gt)          # RIFE.py:132 (fused |a-b| + reduction)
-        loss_tea = ops.l1_loss(merged_teacher, gt)    # RIFE.py:134
+        pair_loss = self.lap if lap_loss else ops.l1_loss
+        loss_l1 = pair_loss(merged[2], gt)          # RIFE.py:132 (fused |a-b| + reduction)
+        loss_tea = pair_loss(merged_teacher, gt)    # RIFE.py:134
         # RIFE.py:141-143 also sums an L1 norm of all parameters that never reaches loss_G
         # (lambda_reg = 0 and the term is commented out of :158); it is not computed here.
         loss_G = loss_l1 * 1 + loss_tea * 1 + loss_distill * 0.1  # RIFE.py:151-158
@@ -201,6 +209,10 @@ class LapLoss(torch.nn.Module):
         self.max_levels, self.channels = max_levels, channels
 
     def forward(self, input, target):
+        if input.dim() == 5:
+            # Flow-3D/model/laplacian.py (dead code in the reference, CPU scipy round trip): the real 3-D
+            # pyramid of csrc/laplacian3d.hip -- parity unpinned, see ops._LapLoss3D
+            return ops.laploss3d(input, target, self.max_levels)
         return ops.laploss2d(input, target, self.max_levels)
 
 

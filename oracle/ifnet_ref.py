@@ -218,3 +218,36 @@ class ModelRef:
             self.optimG.step()
         info.update(flow=flow[2], merged_tea=merged_teacher, flow_tea=flow_teacher)
         return merged[2], info
+
+
+# --------------------------------------------------------------------------------------------
+# f3 (second half): 3-D Laplacian-pyramid loss.  PARITY UNPINNED: Flow-3D/model/laplacian.py:37-91 is dead
+# code in the reference whose conv_gauss (:44-58) ignores its kernel and round-trips through
+# scipy.ndimage.gaussian_filter on the CPU (all five axes, detached).  This is the 3-D analogue of
+# Flow-2D/model/laplacian.py:10-88 with stock ops: G3 = g (x) g (x) g with g = [1,4,6,4,1]/16, reflect
+# padding by 2 (:46), ::2 decimation (:21-22), zero-interleave x 8 (:24-41) and the same filter for `up`.
+# --------------------------------------------------------------------------------------------
+def _gauss3(channels):
+    g = torch.tensor([1., 4., 6., 4., 1.]) / 16.
+    k = g[:, None, None] * g[None, :, None] * g[None, None, :]
+    return k.repeat(channels, 1, 1, 1, 1)
+
+
+def _conv_gauss3(img, kernel):
+    return F.conv3d(F.pad(img, (2, 2, 2, 2, 2, 2), mode='reflect'), kernel, groups=img.shape[1])
+
+
+def lap_loss3d(inp, target, max_levels=5):
+    def pyramid(img):
+        k = _gauss3(img.shape[1]).to(img.dtype)
+        cur, pyr = img, []
+        for _ in range(max_levels):
+            down = _conv_gauss3(cur, k)[:, :, ::2, ::2, ::2]
+            up = cur.new_zeros(down.shape[:2] + tuple(2 * n for n in down.shape[2:]))
+            up[:, :, ::2, ::2, ::2] = down
+            up = _conv_gauss3(up * 8, k)
+            sl = (slice(None), slice(None)) + tuple(slice(0, n) for n in cur.shape[2:])
+            pyr.append(cur - up[sl])
+            cur = down
+        return pyr
+    return sum(F.l1_loss(a, b) for a, b in zip(pyramid(inp), pyramid(target)))

@@ -615,3 +615,42 @@ def test_conv3d_fwd_big_bricks_vs_fp64(ops, size, wmode):
         got = ops.conv3d_fwd(x.to(DEV), wt.to(DEV), None, 3, 1, 1, 1)
     assert got.shape == ref.shape
     assert float((got.cpu().double() - ref).abs().max()) < 3e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape,levels", [((1, 1, 24, 32, 40), 3), ((2, 1, 17, 21, 13), 2), ((1, 2, 12, 12, 12), 2),
+                                          ((1, 1, 64, 64, 64), 5), ((1, 1, 7, 9, 11), 1)])
+def test_laploss3d_vs_oracle(ops, shape, levels):
+    """§8f.3 second half: the 3-D Laplacian-pyramid loss (csrc/laplacian3d.hip).  PARITY UNPINNED: the
+    reference's Flow-3D/model/laplacian.py is dead code with a CPU scipy round trip; the oracle is this build's
+    restatement of the 3-D analogue of Flow-2D's LapLoss (oracle/ifnet_ref.py::lap_loss3d).  Value and both
+    gradients, even and odd extents, multi-channel."""
+    from oracle.ifnet_ref import lap_loss3d
+    g = torch.Generator().manual_seed(sum(shape) + levels)
+    a = torch.rand(shape, generator=g)
+    b = (a + 0.2 * torch.randn(shape, generator=g)).clamp(0, 1)
+    ao, bo = a.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = lap_loss3d(ao, bo, levels)
+    ga, gb = torch.autograd.grad(ref, [ao, bo])
+    ad, bd = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    got = ops.laploss3d(ad, bd, levels)
+    assert abs(float(got) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    ha, hb = torch.autograd.grad(got * 1.7, [ad, bd])
+    # |.| has a kink: voxels whose pyramid value is within fp32 noise of 0 may take the other sign
+    for h, r in ((ha, ga), (hb, gb)):
+        bad = ((h.cpu() / 1.7 - r).abs() > 1e-6 * max(1.0, float(r.abs().max()))).float().mean()
+        assert float(bad) < 1e-4
+    with pytest.raises(ValueError):
+        ops.laploss3d(torch.rand(1, 1, 2, 8, 8, device=DEV), torch.rand(1, 1, 2, 8, 8, device=DEV), 1)
+
+
+def test_model3d_lap_loss_option():
+    """Model3D.update(lap_loss=True) trains on the pyramid loss the reference has commented out (RIFE.py:126)."""
+    from opticalflowscivis_amd.flow3d.model.RIFE import Model
+    from opticalflowscivis_amd.data import synthetic
+    torch.manual_seed(3)
+    m = Model(local_rank=-1, device=DEV)
+    data = synthetic.droplet3d_batch(1, 32, seed=2, device=DEV)
+    _, i0 = m.update(data[:, :2], data[:, 2:3], learning_rate=1e-4, training=True, lap_loss=True)
+    _, i1 = m.update(data[:, :2], data[:, 2:3], learning_rate=1e-4, training=True, lap_loss=True)
+    assert torch.isfinite(i0["loss_G"]) and torch.isfinite(i1["loss_G"])
+    assert float(i0["loss_l1"]) != float(i1["loss_l1"])
