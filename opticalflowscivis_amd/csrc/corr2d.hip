@@ -80,67 +80,32 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr2d_fwd_kernel(C2Set a, 
 #pragma unroll
     for (int j = 0; j < ND; ++j) acc[i][j] = 0.f;
 
-  // Staging.  Every thread moves IT2 elements of the f2 window and IT1 of the f1 tile per chunk; their
-  // in-plane offsets and channel slots do not depend on the chunk, so they are resolved once, and a chunk's
-  // loads are issued back to back, branch-free (clamped address + select), into registers: the NEXT chunk's
-  // loads fly under the current chunk's FMA phase.  (Round 1 looped `load if in range -> LDS store` with a
-  // branch per element: ~13 exposed load latencies per chunk made the kernel latency-bound at every level.)
-  constexpr int N2 = CC * SR * SCOLS, N1 = CC * TY * TX;
-  constexpr int IT2 = (N2 + NT - 1) / NT, IT1 = (N1 + NT - 1) / NT;
-  int off2[IT2], off1[IT1];  // offset inside the chunk's first channel plane; -1: zero (outside the image)
-#pragma unroll
-  for (int it = 0; it < IT2; ++it) {
-    const int i = t + NT * it;
-    const int c = i / (SR * SCOLS), rem = i - c * (SR * SCOLS);
-    const int r = rem / SCOLS, col = rem - r * SCOLS;
-    const int gy = y0 + r - MD, gx = x0 + col - MD;
-    off2[it] = (i < N2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? c * (int)HW + gy * W + gx : -1;
-  }
-#pragma unroll
-  for (int it = 0; it < IT1; ++it) {
-    const int i = t + NT * it;
-    const int c = i / (TY * TX), rem = i - c * (TY * TX);
-    const int r = rem / TX, col = rem - r * TX;
-    const int gy = y0 + r, gx = x0 + col;
-    off1[it] = (i < N1 && gy < H && gx < W) ? c * (int)HW + gy * W + gx : -1;
-  }
-  float r2[IT2], r1[IT1];
-  auto fetch = [&](int c0) {
-    const float* p2 = f2b + (size_t)c0 * HW;
-    const float* p1 = f1b + (size_t)c0 * HW;
-#pragma unroll
-    for (int it = 0; it < IT2; ++it) {
-      const int c = c0 + (t + NT * it) / (SR * SCOLS);
-      const bool ok = off2[it] >= 0 && c < C;
-      float v = p2[ok ? off2[it] : 0];
-      // normalize_features folded into the load (§8f.4): the zero padding applies AFTER it
-      if (st2) { const float2 q = *reinterpret_cast<const float2*>(st2 + 2 * ((size_t)b * C + (ok ? c : 0))); v = (v - q.x) * q.y; }
-      r2[it] = ok ? v : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < IT1; ++it) {
-      const int c = c0 + (t + NT * it) / (TY * TX);
-      const bool ok = off1[it] >= 0 && c < C;
-      float v = p1[ok ? off1[it] : 0];
-      if (st1) { const float2 q = *reinterpret_cast<const float2*>(st1 + 2 * ((size_t)b * C + (ok ? c : 0))); v = (v - q.x) * q.y; }
-      r1[it] = ok ? v : 0.f;
-    }
-  };
-  fetch(0);
   for (int c0 = 0; c0 < C; c0 += CC) {
-#pragma unroll
-    for (int it = 0; it < IT2; ++it) {
-      const int i = t + NT * it;
+    // stage the f2 window and the f1 tile of CC channels (zeros outside image / channel range)
+    for (int i = t; i < CC * SR * SCOLS; i += NT) {
       const int c = i / (SR * SCOLS), rem = i - c * (SR * SCOLS);
-      if (i < N2) s2[c][rem / SCOLS][rem % SCOLS] = r2[it];
+      const int r = rem / SCOLS, col = rem - r * SCOLS;
+      const int gy = y0 + r - MD, gx = x0 + col - MD;
+      float v = 0.f;
+      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        v = f2b[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
+        // normalize_features folded into the load (§8f.4): the zero padding applies AFTER it
+        if (st2) { const float* q = st2 + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
+      }
+      s2[c][r][col] = v;
     }
-#pragma unroll
-    for (int it = 0; it < IT1; ++it) {
-      const int i = t + NT * it;
-      if (i < N1) (&s1[0][0][0])[i] = r1[it];
+    for (int i = t; i < CC * TY * TX; i += NT) {
+      const int c = i / (TY * TX), rem = i - c * (TY * TX);
+      const int r = rem / TX, col = rem - r * TX;
+      const int gy = y0 + r, gx = x0 + col;
+      float v = 0.f;
+      if (c0 + c < C && gy < H && gx < W) {
+        v = f1b[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
+        if (st1) { const float* q = st1 + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
+      }
+      s1[c][r][col] = v;
     }
     __syncthreads();
-    if (c0 + CC < C) fetch(c0 + CC);
 #pragma unroll
     for (int c = 0; c < CC; ++c) {
       const float4 a = *reinterpret_cast<const float4*>(&s1[c][qy][qx]);
@@ -199,59 +164,40 @@ __global__ __launch_bounds__(256) void corr2d_bwd_kernel(C2Set a, int B, int C, 
   const float* gb = gout + (size_t)b * ND * ND * HW;
   const float* ob = other + (size_t)b * C * HW;
 
-  // this pixel's (2md+1)^2 upstream gradients: 81 loads issued back to back (clamped address + select,
-  // no branch per element)
+  // this pixel's (2md+1)^2 upstream gradients
   float g[ND][ND];
 #pragma unroll
   for (int j = 0; j < ND; ++j)
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-      int idx;
-      bool ok = live;
-      if (!second) {
-        idx = (j * ND + i) * (int)HW + y * W + x;
-      } else {
-        // gT[d, q] = g[-d, q + d]
-        const int yy = y + (j - MD), xx = x + (i - MD);
-        ok = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        idx = ((ND - 1 - j) * ND + (ND - 1 - i)) * (int)HW + yy * W + xx;
+      float v = 0.f;
+      if (live) {
+        if (!second) {
+          v = gb[(size_t)(j * ND + i) * HW + (size_t)y * W + x];
+        } else {
+          // gT[d, q] = g[-d, q + d]
+          const int yy = y + (j - MD), xx = x + (i - MD);
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            v = gb[(size_t)((ND - 1 - j) * ND + (ND - 1 - i)) * HW + (size_t)yy * W + xx];
+        }
       }
-      const float v = gb[ok ? idx : 0];
-      g[j][i] = ok ? v : 0.f;
+      g[j][i] = v;
     }
 
   const float fC = (float)C;
-  constexpr int NS = CC * SR * SW, ITS = (NS + 255) / 256;
-  int offs[ITS];
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    const int i = t + 256 * it;
-    const int c = i / (SR * SW), rem = i - c * (SR * SW);
-    const int r = rem / SW, col = rem - r * SW;
-    const int gy = y0 + r - MD, gx = x0 + col - MD;
-    offs[it] = (i < NS && gy >= 0 && gy < H && gx >= 0 && gx < W) ? c * (int)HW + gy * W + gx : -1;
-  }
-  float rs[ITS];
-  auto fetch = [&](int c0) {
-    const float* po = ob + (size_t)c0 * HW;
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const int c = c0 + (t + 256 * it) / (SR * SW);
-      const bool ok = offs[it] >= 0 && c < C;
-      float v = po[ok ? offs[it] : 0];
-      if (ost) { const float2 q = *reinterpret_cast<const float2*>(ost + 2 * ((size_t)b * C + (ok ? c : 0))); v = (v - q.x) * q.y; }
-      rs[it] = ok ? v : 0.f;
-    }
-  };
-  fetch(0);
   for (int c0 = 0; c0 < C; c0 += CC) {
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const int i = t + 256 * it;
-      if (i < NS) (&s[0][0][0])[i] = rs[it];
+    for (int i = t; i < CC * SR * SW; i += 256) {
+      const int c = i / (SR * SW), rem = i - c * (SR * SW);
+      const int r = rem / SW, col = rem - r * SW;
+      const int gy = y0 + r - MD, gx = x0 + col - MD;
+      float v = 0.f;
+      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        v = ob[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
+        if (ost) { const float* q = ost + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
+      }
+      s[c][r][col] = v;
     }
     __syncthreads();
-    if (c0 + CC < C) fetch(c0 + CC);
     for (int c = 0; c < CC && c0 + c < C; ++c) {
       float a = 0.f;
 #pragma unroll

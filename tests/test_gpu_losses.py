@@ -649,7 +649,7 @@ def test_model3d_lap_loss_option():
     from opticalflowscivis_amd.data import synthetic
     torch.manual_seed(3)
     m = Model(local_rank=-1, device=DEV)
-    data = synthetic.droplet3d_batch(1, 32, seed=2, device=DEV)
+    data = synthetic.droplet3d_batch(1, 64, seed=2, device=DEV)  # 5 levels: 64, 32, 16, 8, 4 voxels per side
     _, i0 = m.update(data[:, :2], data[:, 2:3], learning_rate=1e-4, training=True, lap_loss=True)
     _, i1 = m.update(data[:, :2], data[:, 2:3], learning_rate=1e-4, training=True, lap_loss=True)
     assert torch.isfinite(i0["loss_G"]) and torch.isfinite(i1["loss_G"])
