@@ -307,6 +307,20 @@ int fs_distill_fwd(const float* merged_i, const float* merged_tea, const float* 
 int fs_distill_bwd(const float* merged_i, const float* merged_tea, const float* gt,
                    const float* flow_i, const float* flow_tea, const float* coef,
                    float* grad_flow_i, int B, int C, int F, int S, fs_stream_t stream);
+/* The three student terms of loss_distill (one per block, all against the same teacher: Flow-3D/model/
+ * IFNet.py:259-262, Flow-2D/model/IFNet.py:244-248) in one launch each way: the teacher's flow / merged frame
+ * and the ground truth are read once instead of three times.  sums[0..2] = the per-term sums of
+ * sqrt(mean_c dflow^2) * mask (divide by B*S for the means; sums[3] is scratch: pass 4 floats);
+ * ws: 4 * FS_REDUCE_BLOCKS floats.  bwd: coef = device scalar d(objective)/d(sum), shared by the terms. */
+int fs_distill3_fwd(const float* merged0, const float* merged1, const float* merged2,
+                    const float* merged_tea, const float* gt, const float* flow0, const float* flow1,
+                    const float* flow2, const float* flow_tea, float* sums, float* ws,
+                    int B, int C, int F, int S, fs_stream_t stream);
+int fs_distill3_bwd(const float* merged0, const float* merged1, const float* merged2,
+                    const float* merged_tea, const float* gt, const float* flow0, const float* flow1,
+                    const float* flow2, const float* flow_tea, const float* coef,
+                    float* grad_flow0, float* grad_flow1, float* grad_flow2,
+                    int B, int C, int F, int S, fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * §8f.1  Backward of the trilinear resizes inside IFBlock (Flow-3D/model/IFNet.py:85,88,118-119):

@@ -71,6 +71,8 @@ SIGNATURES = {
     "fs_census_dist_bwd": [_f32p] * 5 + [_int] * 4 + [_stream],
     "fs_merge_fwd": [_f32p] * 5 + [_int] * 3 + [_stream],
     "fs_merge_bwd": [_f32p] * 8 + [_int] * 3 + [_stream],
+    "fs_distill3_fwd": [_f32p] * 11 + [_int] * 4 + [_stream],
+    "fs_distill3_bwd": [_f32p] * 13 + [_int] * 4 + [_stream],
     "fs_distill_fwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_distill_bwd": [_f32p] * 7 + [_int] * 4 + [_stream],
     "fs_interp3d_bwd": [_f32p] * 3 + [_int] * 10 + [_stream],

@@ -230,8 +230,15 @@ class IFNet(nn.Module):
             merged[i] = _crop(m, _min_spatial(m, gt))
             if gt.shape[1] == 1:
                 flow_list[i] = _crop(flow_list[i], flow_teacher.shape[2:])
-                loss_distill = loss_distill + ops.distill_term(merged[i], merged_teacher, gt,
-                                                               flow_list[i], flow_teacher.detach())
+        if gt.shape[1] == 1:
+            ft = flow_teacher.detach()
+            if (x.is_cuda and all(m.shape == merged[0].shape == merged_teacher.shape for m in merged) and
+                    all(f.shape == ft.shape for f in flow_list)):
+                # the three terms against the one teacher in one launch each way
+                loss_distill = ops.distill_terms3(merged, merged_teacher, gt, flow_list, ft)
+            else:
+                for i in range(3):
+                    loss_distill = loss_distill + ops.distill_term(merged[i], merged_teacher, gt, flow_list[i], ft)
         # Flow-2D returns every block's mask (IFNet.py:276), Flow-3D the last one (IFNet.py:280)
         masks = mask_list if self.nd == 2 else mask_list[2]
         return flow_list, masks, merged, flow_teacher, merged_teacher, loss_distill

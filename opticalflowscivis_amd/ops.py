@@ -910,6 +910,57 @@ class _Distill(torch.autograd.Function):
         return None, None, None, gf, None
 
 
+class _Distill3(torch.autograd.Function):
+    """Sum of the three student blocks' distillation terms in one launch each way (fs_distill3_*)."""
+
+    @staticmethod
+    def forward(ctx, m0, m1, m2, merged_tea, gt, f0, f1, f2, flow_tea):
+        d = m0.dim()
+        ms = [_need_cuda_f32("merged", t, d) for t in (m0, m1, m2)]
+        fl = [_need_cuda_f32("flow", t, d) for t in (f0, f1, f2)]
+        merged_tea, gt = _need_cuda_f32("merged_teacher", merged_tea, d), _need_cuda_f32("gt", gt, d)
+        flow_tea = _need_cuda_f32("flow_teacher", flow_tea, d)
+        B, C, S = _flat3(ms[0])
+        F_ = fl[0].shape[1]
+        if not (all(t.shape == ms[0].shape for t in ms + [merged_tea, gt]) and
+                all(t.shape == fl[0].shape for t in fl + [flow_tea]) and fl[0].shape[2:] == ms[0].shape[2:]):
+            raise ValueError("distill operands mismatch")
+        sums = ms[0].new_empty(4)
+        ws = ms[0].new_empty(4 * _REDUCE_BLOCKS)
+        with torch.cuda.device(ms[0].device):
+            _call("fs_distill3_fwd", ms[0].data_ptr(), ms[1].data_ptr(), ms[2].data_ptr(), merged_tea.data_ptr(),
+                  gt.data_ptr(), fl[0].data_ptr(), fl[1].data_ptr(), fl[2].data_ptr(), flow_tea.data_ptr(),
+                  sums.data_ptr(), ws.data_ptr(), B, C, F_, S, _stream(ms[0]),
+                  algo_bytes=4 * (5 * ms[0].numel() + 4 * fl[0].numel()), record_as="fs_distill_fwd")
+        ctx.save_for_backward(*ms, merged_tea, gt, *fl, flow_tea)
+        n = float(B * S)
+        return (0 + sums[0] / n) + sums[1] / n + sums[2] / n  # the order of IFNet.forward's running sum
+
+    @staticmethod
+    def backward(ctx, gout):
+        m0, m1, m2, merged_tea, gt, f0, f1, f2, flow_tea = ctx.saved_tensors
+        if not any(ctx.needs_input_grad[5:8]):
+            return (None,) * 9
+        B, C, S = _flat3(m0)
+        F_ = f0.shape[1]
+        coef = (gout / float(B * S)).reshape(1).contiguous()
+        g = [torch.empty_like(f0) for _ in range(3)]
+        with torch.cuda.device(m0.device):
+            _call("fs_distill3_bwd", m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), merged_tea.data_ptr(),
+                  gt.data_ptr(), f0.data_ptr(), f1.data_ptr(), f2.data_ptr(), flow_tea.data_ptr(), coef.data_ptr(),
+                  g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), B, C, F_, S, _stream(m0),
+                  algo_bytes=4 * (5 * m0.numel() + 7 * f0.numel()), record_as="fs_distill_bwd")
+        return (None, None, None, None, None) + tuple(g[i] if ctx.needs_input_grad[5 + i] else None
+                                                      for i in range(3)) + (None,)
+
+
+def distill_terms3(merged, merged_teacher, gt, flows, flow_teacher):
+    """sum_i distill_term(merged[i], merged_teacher, gt, flows[i], flow_teacher) for the three student blocks
+    in one launch each way; the operands of the three terms must share their shapes."""
+    return _Distill3.apply(merged[0], merged[1], merged[2], merged_teacher, gt, flows[0], flows[1], flows[2],
+                           flow_teacher)
+
+
 def distill_term(merged_i, merged_teacher, gt, flow_i, flow_teacher):
     """One block's term of loss_distill; gradient reaches flow_i only (the reference detaches the
     teacher flow and the loss mask)."""

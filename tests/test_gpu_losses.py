@@ -654,3 +654,28 @@ def test_model3d_lap_loss_option():
     _, i1 = m.update(data[:, :2], data[:, 2:3], learning_rate=1e-4, training=True, lap_loss=True)
     assert torch.isfinite(i0["loss_G"]) and torch.isfinite(i1["loss_G"])
     assert float(i0["loss_l1"]) != float(i1["loss_l1"])
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 12, 20, 16), (3, 1, 40, 56)])
+def test_distill_terms3_is_three_single_terms(ops, shape):
+    """The three student terms of loss_distill against one teacher in one launch each way == the three
+    single-term launches, values and flow gradients bit for bit."""
+    g = torch.Generator().manual_seed(len(shape))
+    nd = len(shape) - 2
+    B = shape[0]
+    fshape = (B, 2 * nd) + tuple(shape[2:])
+    gt = torch.rand(shape, generator=g).to(DEV)
+    mt = (gt + 0.05 * torch.randn(shape, generator=g).to(DEV))
+    ft = torch.randn(fshape, generator=g).to(DEV)
+    ms = [(gt + s_ * torch.randn(shape, generator=g).to(DEV)) for s_ in (0.2, 0.1, 0.02)]
+    fa = [torch.randn(fshape, generator=g).to(DEV).requires_grad_() for _ in range(3)]
+    fb = [t.detach().clone().requires_grad_() for t in fa]
+    one = ops.distill_terms3(ms, mt, gt, fa, ft)
+    ref = 0
+    for i in range(3):
+        ref = ref + ops.distill_term(ms[i], mt, gt, fb[i], ft)
+    assert torch.equal(one, ref)
+    ga = torch.autograd.grad(one * 0.37, fa)
+    gb = torch.autograd.grad(ref * 0.37, fb)
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
