@@ -138,19 +138,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   auto load_x = [&](int c0, int it) -> float {
     const char* xb = reinterpret_cast<const char*>(X + ((size_t)b * p.Cin + c0) * xvol);
     const bool chan_ok = (c0 + CI <= p.Cin) || (c0 + (t + 256 * it) / CHS < p.Cin);
-    // branch-free: an always-legal address + a select (a branch per load kept the ~30 loads of a chunk from
-    // being issued back to back and cost ~25 instructions each)
-    const bool ok = xoff[it] != ~0u && chan_ok;
-    const float v = *reinterpret_cast<const float*>(xb + (ok ? xoff[it] : 0u));
-    return ok ? v : 0.f;
+    return (xoff[it] != ~0u && chan_ok) ? *reinterpret_cast<const float*>(xb + xoff[it]) : 0.f;
   };
   auto load_w = [&](int c0, int it) -> float4 {
     const int i4 = t + 256 * it;
     const int row = i4 / (CP / 4), j4 = i4 - row * (CP / 4);
     const float* wb = Wt + (size_t)c0 * K3 * p.CoutP + co0;
-    // slots past the slab are never parked (park() tests i4 < NW / 4): read a legal address instead of branching
-    const bool ok = i4 < NW / 4;
-    return *reinterpret_cast<const float4*>(wb + (ok ? (size_t)row * p.CoutP + 4 * j4 : (size_t)0));
+    return (i4 < NW / 4) ? *reinterpret_cast<const float4*>(wb + (size_t)row * p.CoutP + 4 * j4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto fetch = [&](int c0) {
 #pragma unroll

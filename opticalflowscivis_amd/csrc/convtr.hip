@@ -152,9 +152,7 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __rest
 #pragma unroll
     for (int it = 0; it < ITX; ++it) {
       const bool chan_ok = (c0 + CI <= p.Cin) || (c0 + (t + 256 * it) / CHS < p.Cin);
-      const bool ok = xoff[it] != ~0u && chan_ok;  // branch-free: legal address + select
-      const float v = *reinterpret_cast<const float*>(xb + (ok ? xoff[it] : 0u));
-      rX[it] = ok ? v : 0.f;
+      rX[it] = (xoff[it] != ~0u && chan_ok) ? *reinterpret_cast<const float*>(xb + xoff[it]) : 0.f;
     }
     const float4* wb = reinterpret_cast<const float4*>(Wt + (size_t)c0 * 64 * 32);
 #pragma unroll
@@ -288,9 +286,7 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma16_kernel(const float* __re
 #pragma unroll
     for (int it = 0; it < ITX; ++it) {
       const bool chan_ok = (c0 + CI <= p.Cin) || (c0 + (t + 256 * it) / CHS < p.Cin);
-      const bool ok = xoff[it] != ~0u && chan_ok;  // branch-free: legal address + select
-      const float v = *reinterpret_cast<const float*>(xb + (ok ? xoff[it] : 0u));
-      rX[it] = ok ? v : 0.f;
+      rX[it] = (xoff[it] != ~0u && chan_ok) ? *reinterpret_cast<const float*>(xb + xoff[it]) : 0.f;
     }
     const float4* wb = reinterpret_cast<const float4*>(Wt + (size_t)c0 * 64 * 16);
 #pragma unroll

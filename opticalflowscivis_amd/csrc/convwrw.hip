@@ -25,8 +25,6 @@
 // are read from LDS one reduction pair ahead of the MFMAs that use them.  Accumulators stay in
 // registers over the whole run; the epilogue adds the partial tile to dW with float atomics (128
 // contiguous bytes per half-wave = the full-rate shape).
-#include <type_traits>
-
 #include "common.hpp"
 
 namespace {
@@ -59,13 +57,7 @@ struct WB {
 
 constexpr int pad_to(int n, int want) { return n + (((want - n) % 32) + 32) % 32; }
 
-// EXACT: the bricks tile the output grid exactly, Cg is a multiple of 32*MT, Cs of NC and pad <= TZ*S, TY*S:
-// then no G element is ever out of range and a source element can only fall outside the volume in the halo of
-// a brick that touches a border -- a 7-bit class per staged element tested against a per-brick mask -- and the
-// staging (52 loads per 256-MFMA brick) is ~4 vector instructions per load, branch-free.  (Round 1's general
-// form -- a branch and ~25 instructions of index / bounds arithmetic per load, 1350 instructions between the
-// barrier and the first MFMA of every brick -- is kept for layers that do not tile.)
-template <int K, int S, int NC, int MT, int TZ, int TY, bool EXACT>
+template <int K, int S, int NC, int MT, int TZ, int TY>
 __global__ __launch_bounds__(256, 2) void conv3d_wrw_brick_kernel(const float* __restrict__ G,
                                                                const float* __restrict__ Src,
                                                                float* __restrict__ dW, WB p) {
@@ -124,27 +116,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_brick_kernel(const float* _
     const bool ok = i < NS && c0 + c < p.Cs;
     szyx[it] = ok ? ((unsigned)z | ((unsigned)y << 8) | ((unsigned)x << 16) | ((unsigned)c << 24)) : ~0u;
   }
-  // EXACT: per staged source element its offset from the brick origin and its border class
-  // (bit 0/1: in the low / high z halo, 2/3: y, 4/5: x, 6: channel or element slot unused)
-  unsigned eoff[EXACT ? ITS : 1];
-  unsigned ecls[EXACT ? (ITS + 3) / 4 : 1];  // four 8-bit classes per register
-  const int zhi = p.Di - (p.Do - TZ) * S + p.pad, yhi = p.Hi - (p.Ho - TY) * S + p.pad,
-            xhi = p.Wi - (p.Wo - KW) * S + p.pad;  // first invalid brick coordinate of the LAST brick per axis
-  if (EXACT) {
-#pragma unroll
-    for (int k = 0; k < (ITS + 3) / 4; ++k) ecls[k] = 0u;
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const unsigned zyx = szyx[it];
-      const int z = (int)(zyx & 255u), y = (int)((zyx >> 8) & 255u), x = (int)((zyx >> 16) & 255u);
-      unsigned cls = (z < p.pad ? 1u : 0u) | (z >= zhi ? 2u : 0u) | (y < p.pad ? 4u : 0u) | (y >= yhi ? 8u : 0u) |
-                     (x < p.pad ? 16u : 0u) | (x >= xhi ? 32u : 0u);
-      if (zyx == ~0u) cls = 64u;
-      eoff[it] = (zyx == ~0u) ? 0u
-                              : ((zyx >> 24) * (unsigned)svol + ((unsigned)z * p.Hi + (unsigned)y) * p.Wi + (unsigned)x) * 4u;
-      ecls[it / 4] |= cls << (8 * (it % 4));
-    }
-  }
   float rG[ITG], rS[ITS];
   static_assert(256 % (ROWS * KW) == 0, "G brick rows per thread");
   constexpr int RPI = 256 / (ROWS * KW);  // G channels covered by one pass of the 256 threads
@@ -152,43 +123,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_brick_kernel(const float* _
 
   const long long s0 = (long long)blockIdx.x * p.spw;
   const long long s1 = min(s0 + p.spw, p.bricks);
-  // coordinates of the next brick to fetch: decoded once (64-bit divisions), then advanced like an odometer
-  // (the per-brick decode was ~500 scalar instructions of emulated division in front of every MFMA phase)
-  int nbx, nby, nbz, nbb;
-  {
-    long long q = s0;
-    nbx = (int)(q % p.bx); q /= p.bx;
-    nby = (int)(q % p.by); q /= p.by;
-    nbz = (int)(q % p.bz);
-    nbb = (int)(q / p.bz);
-  }
-  auto fetch = [&]() {
-    const int bxi = nbx, byi = nby, bzi = nbz, b = nbb;
-    if (++nbx == p.bx) { nbx = 0; if (++nby == p.by) { nby = 0; if (++nbz == p.bz) { nbz = 0; ++nbb; } } }
+  auto fetch = [&](long long q) {
+    const int bxi = (int)(q % p.bx); q /= p.bx;
+    const int byi = (int)(q % p.by); q /= p.by;
+    const int bzi = (int)(q % p.bz);
+    const int b = (int)(q / p.bz);
     const int oz0 = bzi * TZ, oy0 = byi * TY, ox0 = bxi * KW;
-    if (EXACT) {
-      // G: every element in range; a thread's elements differ only by a uniform channel stride
-      const char* gbx = reinterpret_cast<const char*>(G + ((size_t)b * p.Cg + g0) * gvol) +
-                        (size_t)(((unsigned)(oz0 + g_row / TY) * p.Ho + (oy0 + g_row % TY)) * p.Wo + ox0 + g_col) * 4u;
-      const unsigned glane = (unsigned)gr_t * (unsigned)gvol * 4u;
-#pragma unroll
-      for (int it = 0; it < ITG; ++it)
-        rG[it] = *reinterpret_cast<const float*>(gbx + (size_t)it * RPI * gvol * 4u + glane);
-      // source: byte offset of the brick origin (may lie before the volume: unsigned wrap-around) + the
-      // element's; the element is outside the volume iff its border class meets the brick's border mask
-      const int gz0x = oz0 * S - p.pad, gy0x = oy0 * S - p.pad, gx0x = ox0 * S - p.pad;
-      const unsigned base = (unsigned)((gz0x * p.Hi + gy0x) * p.Wi + gx0x) * 4u;
-      const unsigned bmask = (bzi == 0 ? 1u : 0u) | (bzi == p.bz - 1 ? 2u : 0u) | (byi == 0 ? 4u : 0u) |
-                             (byi == p.by - 1 ? 8u : 0u) | (bxi == 0 ? 16u : 0u) | (bxi == p.bx - 1 ? 32u : 0u) | 64u;
-      const char* sbx = reinterpret_cast<const char*>(Src + ((size_t)b * p.Cs + c0) * svol);
-#pragma unroll
-      for (int it = 0; it < ITS; ++it) {
-        const bool ok = (ecls[it / 4] & (bmask << (8 * (it % 4)))) == 0u;
-        const float v = *reinterpret_cast<const float*>(sbx + (ok ? base + eoff[it] : 0u));
-        rS[it] = ok ? v : 0.f;
-      }
-      return;
-    }
     // G brick: element t + 256*it is (channel gr_t + RPI*it, row g_row, column g_col): the position part
     // is the same for all of a thread's elements.  (k = 3 keeps the per-element form: measured 12 %
     // faster there -- the compiler overlaps its longer address chains with the previous MFMA phase --
@@ -255,11 +195,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_brick_kernel(const float* _
     }
   };
 
-  if (s0 < s1) fetch();
+  if (s0 < s1) fetch(s0);
   for (long long st = s0; st < s1; ++st) {
     park();
     __syncthreads();
-    if (st + 1 < s1) fetch();
+    if (st + 1 < s1) fetch(st + 1);
     // reduction pair kk of row `row`: positions ox = 2 kk + kh
     auto lds_ops = [&](int q, float (&a)[MT], float (&bq)[NPW]) {
       const int row = q / (KW / 2), kk = q % (KW / 2);
@@ -270,32 +210,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_brick_kernel(const float* _
       for (int n = 0; n < NPW; ++n)
         bq[n] = sS[boff[n] + (row / TY) * S * PSP + (row % TY) * S * XP + ox * S];
     };
-    // NL = column tiles this wave really owns (wave-uniform: the last tile row of a 216-column N is short);
-    // the loop is instantiated per NL so that no branch sits between the MFMAs
-    auto run = [&](auto nl_tag) {
-      constexpr int NL = decltype(nl_tag)::value;
-      auto mma = [&](const float (&a)[MT], const float (&bq)[NPW]) {
+    auto mma = [&](const float (&a)[MT], const float (&bq)[NPW]) {
 #pragma unroll
-        for (int n = 0; n < NL; ++n)
+      for (int n = 0; n < NPW; ++n) {
+        if ((wv + 4 * n) < NT32) {  // wave-uniform
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[n], acc[m][n], 0, 0, 0);
-      };
-      constexpr int NQ = ROWS * (KW / 2);
-      float a0[MT], b0[NPW], a1[MT], b1[NPW];
-      lds_ops(0, a0, b0);
-#pragma unroll
-      for (int q = 0; q < NQ; q += 2) {
-        lds_ops(q + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        if (q + 2 < NQ) lds_ops(q + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
+        }
       }
     };
-    if (wv + 4 * (NPW - 1) < NT32) run(std::integral_constant<int, NPW>());
-    else run(std::integral_constant<int, (NPW > 1 ? NPW - 1 : 1)>());
+    constexpr int NQ = ROWS * (KW / 2);
+    float a0[MT], b0[NPW], a1[MT], b1[NPW];
+    lds_ops(0, a0, b0);
+#pragma unroll
+    for (int q = 0; q < NQ; q += 2) {
+      lds_ops(q + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      if (q + 2 < NQ) lds_ops(q + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+    }
     __syncthreads();
   }
 
@@ -335,16 +271,10 @@ int launch_brick(const float* G, const float* Src, float* dW, const WP& w, hipSt
   const long long gx = (p.bricks + p.spw - 1) / p.spw;
   if (gx >= (1ll << 31) || nchunks > 65535 || mtiles > 65535) return FS_ERR_SHAPE;
   dim3 grid((unsigned)gx, nchunks, mtiles);
-  const bool exact = p.Do % TZ == 0 && p.Ho % TY == 0 && p.Wo % KW == 0 && p.Cg % (32 * mt) == 0 && p.Cs % NC == 0 &&
-                     p.pad <= TZ * S && p.pad <= TY * S && p.pad <= KW * S;
-  if (mt == 2 && exact)
-    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 2, TZ, TY, true>), grid, dim3(256), 0, st, G, Src, dW, p);
-  else if (mt == 2)
-    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 2, TZ, TY, false>), grid, dim3(256), 0, st, G, Src, dW, p);
-  else if (exact)
-    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 1, TZ, TY, true>), grid, dim3(256), 0, st, G, Src, dW, p);
+  if (mt == 2)
+    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 2, TZ, TY>), grid, dim3(256), 0, st, G, Src, dW, p);
   else
-    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 1, TZ, TY, false>), grid, dim3(256), 0, st, G, Src, dW, p);
+    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 1, TZ, TY>), grid, dim3(256), 0, st, G, Src, dW, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
