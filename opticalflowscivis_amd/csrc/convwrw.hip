@@ -25,6 +25,9 @@
 // are read from LDS one reduction pair ahead of the MFMAs that use them.  Accumulators stay in
 // registers over the whole run; the epilogue adds the partial tile to dW with float atomics (128
 // contiguous bytes per half-wave = the full-rate shape).
+#include <cstdint>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -279,7 +282,296 @@ int launch_brick(const float* G, const float* Src, float* dW, const WP& w, hipSt
   return FS_OK;
 }
 
+
+// ---- DMA-staged brick kernel: one 8-wave workgroup per CU, loader waves + matrix waves, two LDS buffers -------
+// Same implicit GEMM, restructured around `buffer_load_dwordx4 ... lds` (global -> LDS with no VGPR stop and no
+// ds_write pass).  Waves 4-7 (one per SIMD) only stage: they decode the next brick, build two buffer descriptors
+// and issue ~20 LDS-DMA pieces each into the second LDS buffer; waves 0-3 (their SIMD partners) only read operands
+// and issue MFMAs on the first; one barrier per K-step.  What that buys over the register-staged kernel above:
+//   * the matrix waves' instruction stream is operand reads + MFMAs only (28 350 cycles per 448-MFMA brick is
+//     back-to-back issue; measured 29 600 with the loaders running beside them);
+//   * no staging registers (52-70 per thread above), so a matrix wave holds 7-8 accumulator tiles: the
+//     32*MT x NC*k^3 tile of a workgroup is dealt to its four matrix waves in equal shares -- FULL whole
+//     column tiles (all MT row tiles) plus, with HALF, one row tile of a column tile shared by a wave pair; for
+//     k = 3 / NC = 16 that is 13.5 column tiles -> 14 x 2 = 28 MFMA tiles, 7 per wave (27/28 useful; the
+//     kernel above runs 4,4,4,2 tiles on 216 of 256 columns: 84 %);
+//   * NC = 16 source channels per chunk for k = 3 (8 above): every G brick is read by half as many workgroups;
+//   * ~256 workgroups instead of ~1024: a quarter of the atomic epilogue traffic.
+// Measured on the way (s_memtime stamps, -DFS_WRW_STAMPS, scripts/wrw_stamps.py; 64-channel k3 layer at 64^3):
+// an LDS-DMA wave-instruction costs the issuing wave ~90-130 cycles whatever its width -- 76 dword pieces per
+// wave and brick took 6 800 cycles in front of the MFMA phase (1.02 ms per launch) and 10 000 spread between the
+// MFMAs (1.10 ms); 21 sixteen-byte pieces 2 000 cycles (0.90 ms); moved to partner waves 0.85 ms = 137 TFLOP/s
+// (the register-staged kernel: 1.17 ms).  Hence 16-byte pieces: every row of the source brick starts 4 floats
+// left of the first output column (16-byte aligned in memory when W % 4 == 0) and all pitches are multiples of
+// 4 floats.  An LDS-DMA writes 64 consecutive 16-byte slots; slots that are padding, halo outside the volume
+// or channels past Cs carry an out-of-range offset and receive 0 (measured on gfx950).  A piece can only be
+// outside the volume in the halo of a brick that touches a border (pad <= stride, W % 4 == 0): a 6-bit border
+// class per piece, tested against the brick's border mask, is the whole per-brick address arithmetic.  The
+// pitches are no longer conflict-free (multiples of 4): the 7 operand reads per 7 MFMAs of a wave leave the
+// LDS far from saturated.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned DMA_OOB = 0x80000000u;
+#ifdef FS_WRW_STAMPS
+__device__ unsigned long long fs_wrw_dbg[4 * 8];
+#define STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dt[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+constexpr int up4(int n) { return (n + 3) / 4 * 4; }
+
+template <int K, int S, int NC, int MT, int TZ, int TY, int FULL, int HALF>
+__global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __restrict__ G,
+                                                             const float* __restrict__ Src,
+                                                             float* __restrict__ dW, WB p) {
+  constexpr int K3 = K * K * K;
+  constexpr int NTOT = NC * K3;
+  constexpr int NT32 = 4 * FULL + 2 * HALF;
+  static_assert(NT32 * 32 >= NTOT && (NT32 - 1) * 32 < NTOT + 32, "column tiles cover the chunk");
+  static_assert(HALF == 0 || MT == 2, "a shared column tile is split by row tile");
+  constexpr int NB = FULL + HALF;  // B operands per reduction pair
+  constexpr int ROWS = TZ * TY;
+  constexpr int ZT = (TZ - 1) * S + K, YT = (TY - 1) * S + K;
+  constexpr int XL = 4;                                  // floats between the row start and output column 0's tap 0 + pad
+  constexpr int XP = up4(XL + (KW - 1) * S + K);         // row pitch = staged row length (the pad shifts taps, not rows)
+  constexpr int PSP = YT * XP, CHSP = ZT * PSP;
+  constexpr int GP = ROWS * KW + 4;
+  constexpr int NGF = 32 * MT * GP;                      // floats of the G image
+  constexpr int NGL = (NGF + 255) / 256 * 256;
+  constexpr int NSF = NC * CHSP;                         // floats of the source image
+  constexpr int NSL = (NSF + 255) / 256 * 256;
+  constexpr int NGW = (NGL / 256 + 3) / 4;               // G pieces (1-KiB wave-instructions) per loader wave
+  constexpr int NSW = (NSL / 256 + 3) / 4;               // source pieces per loader wave
+  constexpr int BUF = NGL + NSL;
+  static_assert(2 * BUF * 4 <= 160 * 1024, "two buffers fit the CU's LDS");
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wv = wave & 3;           // waves 0-3: matrix waves, one per SIMD; waves 4-7: their loader partners
+  const bool loader = wave >= 4;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int c0 = blockIdx.y * NC;
+  const int g0 = blockIdx.z * 32 * MT;
+  const size_t gvol = (size_t)p.Do * p.Ho * p.Wo, svol = (size_t)p.Di * p.Hi * p.Wi;
+  const long long s0 = (long long)blockIdx.x * p.spw;
+  const long long s1 = min(s0 + p.spw, p.bricks);
+
+  if (loader) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
+    // ---- brick-invariant part of the staging.  Piece k of loader wave wv fills the 16-byte slots
+    // 256 (wv + 4 k) + 4 lane .. + 3 of an image.
+    // source image: byte offset from the brick origin and border class (bit 0/1: low / high z halo, 2/3: y,
+    // 4/5: x); pad slots and channels past Cs are permanently out of range
+    unsigned soff[NSW], scls[NSW];
+    const int zhi = p.Di + p.pad - (p.bz - 1) * TZ * S, yhi = p.Hi + p.pad - (p.by - 1) * TY * S,
+              xhi = p.Wi + XL - (p.bx - 1) * KW * S;  // first invalid brick coordinate in the LAST brick of an axis
+#pragma unroll
+    for (int k = 0; k < NSW; ++k) {
+      const int q = 256 * (wv + 4 * k) + 4 * lane;
+      const int c = q / CHSP, r1 = q - c * CHSP;
+      const int z = r1 / PSP, r2 = r1 - z * PSP;
+      const int y = r2 / XP, x = r2 - y * XP;
+      const bool ok = q < NSF && c0 + c < p.Cs;
+      soff[k] = ok ? ((unsigned)c * (unsigned)svol + ((unsigned)z * p.Hi + (unsigned)y) * p.Wi + (unsigned)x) * 4u : DMA_OOB;
+      scls[k] = (z < p.pad ? 1u : 0u) | (z >= zhi ? 2u : 0u) | (y < p.pad ? 4u : 0u) | (y >= yhi ? 8u : 0u) |
+                (x < XL ? 16u : 0u) | (x >= xhi ? 32u : 0u);
+    }
+    // G image [channel][GP]: byte offset of the piece from the brick's first position, packed (rz, ry, col) for
+    // the bounds test of bricks that stick out of the output grid
+    unsigned goff[NGW], gpk[NGW];
+#pragma unroll
+    for (int k = 0; k < NGW; ++k) {
+      const int f = 256 * (wv + 4 * k) + 4 * lane;
+      const int r = f / GP, w = f - r * GP;
+      const int row = w / KW, col = w % KW;
+      const bool ok = f < NGF && w < ROWS * KW && g0 + r < p.Cg;
+      goff[k] = ok ? ((unsigned)r * (unsigned)gvol + (unsigned)(((row / TY) * p.Ho + (row % TY)) * p.Wo + col)) * 4u : DMA_OOB;
+      gpk[k] = (unsigned)(row / TY) | ((unsigned)(row % TY) << 8) | ((unsigned)col << 16);
+    }
+    const bool g_exact = p.Do % TZ == 0 && p.Ho % TY == 0 && p.Wo % KW == 0;
+    int bxi, byi, bzi, b;  // the brick to stage next (decoded once, then advanced like an odometer)
+    {
+      long long q = s0;
+      bxi = (int)(q % p.bx); q /= p.bx;
+      byi = (int)(q % p.by); q /= p.by;
+      bzi = (int)(q % p.bz);
+      b = (int)(q / p.bz);
+    }
+    auto stage = [&](int buf) {
+      const int oz0 = bzi * TZ, oy0 = byi * TY, ox0 = bxi * KW;
+      float* dbase = lds + buf * BUF;
+      __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(G + ((size_t)b * p.Cg + g0) * gvol), (short)0,
+                                                                     0x7fffffff, 0x00020000);
+      const unsigned pos0 = (unsigned)(((oz0 * p.Ho + oy0) * p.Wo + ox0) * 4);
+      const long long org = ((long long)(oz0 * S - p.pad) * p.Hi + (oy0 * S - p.pad)) * p.Wi + (ox0 * S - XL);
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Src + ((size_t)b * p.Cs + c0) * svol + org),
+                                                                     (short)0, 0x7fffffff, 0x00020000);
+      const unsigned bmask = (bzi == 0 ? 1u : 0u) | (bzi == p.bz - 1 ? 2u : 0u) | (byi == 0 ? 4u : 0u) |
+                             (byi == p.by - 1 ? 8u : 0u) | (bxi == 0 ? 16u : 0u) | (bxi == p.bx - 1 ? 32u : 0u);
+#pragma unroll
+      for (int i = 0; i < NGW; ++i) {
+        if (256 * (wv + 4 * i) < NGL) {  // wave-uniform
+          unsigned v = goff[i];
+          if (!g_exact) {
+            const bool ok = oz0 + (int)(gpk[i] & 255u) < p.Do && oy0 + (int)((gpk[i] >> 8) & 255u) < p.Ho &&
+                            ox0 + (int)(gpk[i] >> 16) < p.Wo;
+            v = ok ? v : DMA_OOB;
+          }
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(dbase + 256 * (wv + 4 * i)), 16, v, pos0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NSW; ++k) {
+        if (256 * (wv + 4 * k) < NSL) {  // wave-uniform
+          const unsigned vo = (scls[k] & bmask) == 0u ? soff[k] : DMA_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dbase + NGL + 256 * (wv + 4 * k)), 16, vo, 0, 0, 0);
+        }
+      }
+      if (++bxi == p.bx) { bxi = 0; if (++byi == p.by) { byi = 0; if (++bzi == p.bz) { bzi = 0; ++b; } } }
+    };
+    if (s0 < s1) stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (long long st = s0; st < s1; ++st) {
+      if (st + 1 < s1) stage(buf ^ 1);
+      // the pieces of the next brick have landed; past the barrier the matrix waves are done reading `buf`
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      buf ^= 1;
+    }
+#else
+    (void)gvol; (void)svol; (void)NGW; (void)NSW; (void)DMA_OOB;
+#endif
+    return;
+  }
+
+  // ---- matrix waves
+  // B operand column offsets of this wave's column tiles
+  int boff[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int tile = (n < FULL) ? wv * FULL + n : 4 * FULL + (wv >> 1);
+    const int j = tile * 32 + l31;
+    int off = 0;
+    if (j < NTOT) {
+      const int c = j / K3, r = j - c * K3;
+      const int kz = r / (K * K), ky = (r / K) % K, kx = r % K;
+      off = c * CHSP + kz * PSP + ky * XP + kx;
+    }
+    boff[n] = off + XL - p.pad;
+  }
+
+  f32x16 acc[FULL > 0 ? FULL : 1][MT];
+  f32x16 acch;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acch[r] = 0.f;
+#pragma unroll
+    for (int n = 0; n < FULL; ++n)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[n][m][r] = 0.f;
+  }
+
+  __builtin_amdgcn_s_barrier();  // brick s0 has landed
+  int buf = 0;
+#ifdef FS_WRW_STAMPS
+  unsigned long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+  for (long long st = s0; st < s1; ++st) {
+    const float* sG = lds + buf * BUF;
+    const float* sS = sG + NGL;
+    // reduction pair kk of row `row`: positions ox = 2 kk + kh
+    auto lds_ops = [&](int q, float (&a)[MT], float& ah, float (&bq)[NB]) {
+      const int row = q / (KW / 2), kk = q % (KW / 2);
+      const int ox = 2 * kk + kh;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = sG[(m * 32 + l31) * GP + row * KW + ox];
+      if (HALF) ah = sG[((wv & 1) * 32 + l31) * GP + row * KW + ox];
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+        bq[n] = sS[boff[n] + (row / TY) * S * PSP + (row % TY) * S * XP + ox * S];
+    };
+    auto mma = [&](const float (&a)[MT], const float& ah, const float (&bq)[NB]) {
+#pragma unroll
+      for (int n = 0; n < FULL; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[n], acc[n][m], 0, 0, 0);
+      if (HALF) acch = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, bq[NB - 1], acch, 0, 0, 0);
+    };
+    constexpr int NQ = ROWS * (KW / 2);
+    float a0[MT], b0[NB], a1[MT], b1[NB], h0 = 0.f, h1 = 0.f;
+    lds_ops(0, a0, h0, b0);
+#pragma unroll
+    for (int q = 0; q < NQ; q += 2) {
+      lds_ops(q + 1, a1, h1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, h0, b0);
+      if (q + 2 < NQ) lds_ops(q + 2, a0, h0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, h1, b1);
+    }
+    STAMP(2);
+    __builtin_amdgcn_s_barrier();  // the next brick has landed, everyone is done reading `buf`
+    STAMP(4);
+    buf ^= 1;
+  }
+#ifdef FS_WRW_STAMPS
+  if (blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0) {
+    for (int i = 0; i < 8; ++i) fs_wrw_dbg[wv * 8 + i] = dt[i];
+    fs_wrw_dbg[wv * 8 + 7] = (unsigned long long)(s1 - s0);
+  }
+#endif
+
+  auto flush = [&](const f32x16& a, int tile, int m) {
+    const int j = tile * 32 + l31;
+    if (j >= NTOT || c0 * K3 + j >= p.Cs * K3) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int g = g0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (g < p.Cg) atomicAdd(dW + (size_t)g * p.Cs * K3 + (size_t)c0 * K3 + j, a[r]);
+    }
+  };
+#pragma unroll
+  for (int n = 0; n < FULL; ++n)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) flush(acc[n][m], wv * FULL + n, m);
+  if (HALF) flush(acch, 4 * FULL + (wv >> 1), wv & 1);
+}
+
+template <int K, int S, int NC, int MT, int TZ, int TY, int FULL, int HALF>
+int launch_dma(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st) {
+  WB p;
+  p.B = w.B; p.Cg = w.Cg; p.Cs = w.Cs; p.Do = w.Do; p.Ho = w.Ho; p.Wo = w.Wo;
+  p.Di = w.Di; p.Hi = w.Hi; p.Wi = w.Wi; p.pad = w.pad;
+  p.bz = fs::cdiv(p.Do, TZ); p.by = fs::cdiv(p.Ho, TY); p.bx = fs::cdiv(p.Wo, KW);
+  p.bricks = (long long)p.B * p.bz * p.by * p.bx;
+  const int mtiles = fs::cdiv(p.Cg, 32 * MT);
+  const int nchunks = fs::cdiv(p.Cs, NC);
+  // one workgroup per CU: 256 equal runs of bricks
+  long long want = 256 / ((long long)mtiles * nchunks);
+  if (want < 1) want = 1;
+  long long spw = (p.bricks + want - 1) / want;
+  if (spw < 1) spw = 1;
+  p.spw = (int)(spw > (1 << 20) ? (1 << 20) : spw);
+  const long long gx = (p.bricks + p.spw - 1) / p.spw;
+  if (gx >= (1ll << 31) || nchunks > 65535 || mtiles > 65535) return FS_ERR_SHAPE;
+  hipLaunchKernelGGL((conv3d_wrw_dma_kernel<K, S, NC, MT, TZ, TY, FULL, HALF>), dim3((unsigned)gx, nchunks, mtiles),
+                     dim3(512), 0, st, G, Src, dW, p);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
 }  // namespace
+
+#ifdef FS_WRW_STAMPS
+extern "C" int fs_debug_wrw_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs_wrw_dbg), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B, int Cg, int Cs, int Do,
                              int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride, int pad,
@@ -303,6 +595,18 @@ extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B,
   p.segs = fs::cdiv(Wo, KW);
   p.steps = (long long)B * Do * Ho * p.segs;
   hipStream_t st = (hipStream_t)stream;
+  // DMA-staged kernel: 16-byte pieces (W % 4 == 0 on both grids, 16-byte aligned tensors), a full brick column,
+  // pad <= stride, 31-bit byte offsets inside one (b, chunk) slab.  `FLOWSCI_WRW_REG=1`: the register-staged
+  // kernel everywhere (scripts/wrwbench.py compares the two).
+  static const bool reg_only = getenv("FLOWSCI_WRW_REG") != nullptr;
+  const bool dma_ok = !reg_only && pad <= stride && Wo >= KW && Wo % 4 == 0 && Wi % 4 == 0 &&
+                      (((uintptr_t)g | (uintptr_t)src) & 15) == 0 && (long long)64 * Do * Ho * Wo * 4 < (1ll << 31) &&
+                      (long long)16 * Di * Hi * Wi * 4 < (1ll << 31);
+  if (dma_ok) {
+    if (kernel == 3 && Cg > 32 && Cs >= 8) return launch_dma<3, 1, 16, 2, 1, 4, 3, 1>(g, src, dw, p, st);
+    if (kernel == 4 && Cg > 32 && Cs >= 4) return launch_dma<4, 2, 8, 2, 1, 2, 4, 0>(g, src, dw, p, st);
+    if (kernel == 4 && Cg <= 32 && Cs >= 3) return launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st);
+  }
   if (kernel == 3) return launch_brick<3, 1, 8, 1, 4>(g, src, dw, p, st);
   // k = 4: 64 columns per source channel.  NC = 4 gives every wave two 32-column tiles, NC = 2 one;
   // pick the chunking with less padded matrix work (Cs = 1, 2, 5, 6: the IFNet heads / block0 input)

@@ -260,6 +260,12 @@ def test_corr3d_vs_oracle(ops, shape, md):
     dict(cin=32, cout=6, k=4, s=2, size=(6, 7, 34), tr=True),       # deconv head, flow output
     dict(cin=32, cout=1, k=4, s=2, size=(4, 9, 16), tr=True),       # mask output
     dict(cin=3, cout=5, k=4, s=2, size=(7, 9, 13), tr=False),       # odd input extent: trailing rows unused
+    # W % 4 == 0 and >= 32 output columns: the DMA-staged kernels (bricks sticking out of the grid on every axis)
+    dict(cin=32, cout=64, k=4, s=2, size=(10, 14, 72), tr=False),   # k4, 64 G channels, 8-channel chunks
+    dict(cin=12, cout=32, k=4, s=2, size=(6, 10, 136), tr=False),   # k4, 32 G channels, 6-channel chunks (teacher conv0)
+    dict(cin=64, cout=32, k=4, s=2, size=(3, 5, 36), tr=True),      # deconv: G = the layer input
+    dict(cin=32, cout=6, k=4, s=2, size=(5, 6, 40), tr=True),       # flow head through the 6-channel chunk kernel
+    dict(cin=24, cout=72, k=3, s=1, size=(5, 7, 68), tr=False),     # k3: Cg = 72 (two M groups, ragged), Cs = 24 (ragged chunk)
 ])
 def test_conv3d_wrw_mfma_vs_autograd(ops, cfg):
     import torch.nn.functional as F
