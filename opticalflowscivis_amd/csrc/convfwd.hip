@@ -23,6 +23,9 @@
 // Weights arrive re-laid-out as Wt[ci][tap][co] (co contiguous, zero padded to the tile sizes) by
 // wprep_kernel, which also applies the flip + transpose that turns the stride-1 input gradient
 // into a forward convolution.
+#include <cstdint>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -257,6 +260,229 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   }
 }
 
+
+// ---- loader-wave form (one 8-wave workgroup per CU, two LDS buffers) ---------------------------------
+// Same decomposition; the staging moves to partner waves and to `buffer_load_dwordx4 ... lds` (global -> LDS,
+// no VGPR stop, no ds_write pass; csrc/convwrw.hip has the measurements that led here).  Waves 4-7 issue the
+// 16-byte pieces of chunk c+1 -- the haloed input brick and the weight slab -- into the second LDS buffer while
+// waves 0-3 run the MFMA phase of chunk c on the first; one barrier per chunk.  The matrix waves' stream is
+// operand reads + MFMAs only, and with no staging registers they can hold twice the column tiles (k = 4).
+// Rows of the staged brick start 4 floats left of output column 0's first tap + pad (16-byte aligned in
+// memory when Wi % 4 == 0), the row pitch is a multiple of 4 floats; a piece is inside or outside the volume
+// as a whole, and outside pieces / channels past Cin carry an out-of-range offset: the DMA writes 0 there.
+// A workgroup keeps its brick for all chunks, so the piece offsets are computed once.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned DMA_OOB = 0x80000000u;
+constexpr int up4(int n) { return (n + 3) / 4 * 4; }
+
+template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __restrict__ X,
+                                                            const float* __restrict__ Wt,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ Y, FP p) {
+  constexpr int K3 = K * K * K;
+  constexpr int R = 32 / TW;
+  constexpr int TYR = TY * R;
+  static_assert(TZ * TY == 4 * NT && TY % NT == 0 && (CI % 2) == 0 && (TW == 32 || TW == 16), "tile shape");
+  constexpr int XL = 4;
+  constexpr int ZT = (TZ - 1) * S + K, YT = (TYR - 1) * S + K;
+  constexpr int XP = up4(XL + (TW - 1) * S + K);  // row pitch = staged row length
+  constexpr int PS = YT * XP, CHS = ZT * PS;
+  constexpr int CP = 32 * MT;
+  constexpr int NP = (CI / 2) * K3;
+  constexpr int NX = CI * CHS, NW = CI * K3 * CP;
+  constexpr int NXL = (NX + 255) / 256 * 256, NWL = (NW + 255) / 256 * 256;
+  constexpr int NXW = (NXL / 256 + 3) / 4, NWW = (NWL / 256 + 3) / 4;  // pieces per loader wave
+  constexpr int BUF = NXL + NWL;
+  static_assert(2 * BUF * 4 <= 160 * 1024, "two buffers fit the CU's LDS");
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wv = wave & 3;
+  const int col = lane & 31, kh = lane >> 5;
+
+  long long tile = blockIdx.x;
+  {
+    const long long per = p.tiles / 8;
+    if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int txi = (int)(tile % p.tx); tile /= p.tx;
+  const int tyi = (int)(tile % p.ty); tile /= p.ty;
+  const int tzi = (int)(tile % p.tz);
+  const int b = (int)(tile / p.tz);
+  const int oz0 = tzi * TZ, oy0 = tyi * TYR, ox0 = txi * TW;
+  const int co0 = blockIdx.y * CP;
+  const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
+
+  if (wave >= 4) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
+    // piece k of loader wave wv fills the 16-byte slots 256 (wv + 4 k) + 4 lane .. + 3 of an image
+    const int gz0 = oz0 * S - p.pad, gy0 = oy0 * S - p.pad, gx0 = ox0 * S - XL;
+    unsigned xoff[NXW], woff[NWW];
+#pragma unroll
+    for (int k = 0; k < NXW; ++k) {
+      const int i = 256 * (wv + 4 * k) + 4 * lane;
+      const int c = i / CHS, r1 = i - c * CHS;
+      const int z = r1 / PS, r2 = r1 - z * PS;
+      const int y = r2 / XP, x = r2 - y * XP;
+      const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
+      const bool ok = i < NX && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+      xoff[k] = ok ? ((unsigned)c * (unsigned)xvol + ((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u : DMA_OOB;
+    }
+#pragma unroll
+    for (int k = 0; k < NWW; ++k) {
+      const int i = 256 * (wv + 4 * k) + 4 * lane;
+      const int row = i / CP, j = i - row * CP;
+      woff[k] = i < NW ? ((unsigned)row * (unsigned)p.CoutP + (unsigned)j) * 4u : DMA_OOB;
+    }
+    auto stage = [&](int c0, int buf) {
+      // channels past Cin read as zero: the descriptor ends after the chunk's real channels
+      const int nch = (p.Cin - c0 < CI) ? (p.Cin - c0) : CI;
+      __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(X + ((size_t)b * p.Cin + c0) * xvol), (short)0, (int)((unsigned)nch * (unsigned)xvol * 4u), 0x00020000);
+      __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(Wt + (size_t)c0 * K3 * p.CoutP + co0), (short)0, 0x7fffffff, 0x00020000);
+      float* base = lds + buf * BUF;
+#pragma unroll
+      for (int k = 0; k < NXW; ++k)
+        if (256 * (wv + 4 * k) < NXL)  // wave-uniform
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + 256 * (wv + 4 * k)), 16, xoff[k], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < NWW; ++k)
+        if (256 * (wv + 4 * k) < NWL)  // wave-uniform
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + NXL + 256 * (wv + 4 * k)), 16, woff[k], 0, 0, 0);
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+      if (c0 + CI < p.Cin) stage(c0 + CI, buf ^ 1);
+      // the pieces of the next chunk have landed; past the barrier the matrix waves are done reading `buf`
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      buf ^= 1;
+    }
+#else
+    (void)xvol; (void)NXW; (void)NWW; (void)DMA_OOB;
+#endif
+    return;
+  }
+
+  // ---- matrix waves
+  const int ly = col / TW, lx = col % TW;
+  const int rr0 = wv * NT;
+  const int wz = rr0 / TY, wy = rr0 % TY;
+  const int bBo = kh * (CI / 2) * CHS + (wz * S) * PS + ((wy * R + ly) * S) * XP + lx * S + XL - p.pad;
+  const int aBo = NXL + kh * (CI / 2) * K3 * CP + col;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  __builtin_amdgcn_s_barrier();  // chunk 0 has landed
+  int buf = 0;
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+    const float* bB = lds + buf * BUF + bBo;
+    const float* aB = lds + buf * BUF + aBo;
+    auto lds_ops = [&](int j, float (&a)[MT], float (&bq)[NT]) {
+      const int cl = j / K3, tap = j - cl * K3;
+      const int kz = tap / (K * K), ky = (tap / K) % K, kx = tap % K;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = aB[(cl * K3 + tap) * CP + m * 32];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bq[n] = bB[cl * CHS + kz * PS + (ky + n * R * S) * XP + kx];
+    };
+    auto mma = [&](const float (&a)[MT], const float (&bq)[NT]) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[n], acc[m][n], 0, 0, 0);
+    };
+    float a0[MT], b0[NT], a1[MT], b1[NT];
+    lds_ops(0, a0, b0);
+#pragma unroll
+    for (int j = 0; j < NP; j += 2) {
+      if (j + 1 < NP) lds_ops(j + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      if (j + 2 < NP) lds_ops(j + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < NP) mma(a1, b1);
+    }
+    __builtin_amdgcn_s_barrier();  // the next chunk has landed, everyone is done reading `buf`
+    buf ^= 1;
+  }
+
+  // ---- epilogue (as above)
+  const float* __restrict__ ad = p.addend;
+  const float* __restrict__ slope = p.slope;
+  float* __restrict__ Zp = p.Z;
+  float* __restrict__ Yp = Y;
+  const int oz = oz0 + wz;
+  const int ox = ox0 + lx;
+  if (oz < p.Do && ox < p.Wo) {
+    const size_t yvol = (size_t)p.Do * p.Ho * p.Wo;
+    float bv[MT][16], sv[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        bv[m][r] = (bias != nullptr && co < p.Cout) ? bias[co] : 0.f;
+        sv[m][r] = (Zp != nullptr && co < p.Cout) ? slope[p.nslope == 1 ? 0 : co] : 0.f;
+      }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int oy = oy0 + (wy + n) * R + ly;
+      if (oy >= p.Ho) continue;
+      const size_t o0 = (size_t)b * p.Cout * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float av[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          av[r] = (ad != nullptr && co < p.Cout) ? ad[o0 + (size_t)co * yvol] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (co < p.Cout) {
+            const float v = acc[m][n][r] + bv[m][r];
+            const size_t o = o0 + (size_t)co * yvol;
+            if (Zp != nullptr) {
+              Yp[o] = v;
+              Zp[o] = (v > 0.f ? v : sv[m][r] * v) + av[r];
+            } else {
+              Yp[o] = v + av[r];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
+int launch_ws(const float* X, const float* Wt, const float* bias, float* Y, FP& p, hipStream_t st) {
+  constexpr int TYR = TY * (32 / TW);
+  p.tz = fs::cdiv(p.Do, TZ); p.ty = fs::cdiv(p.Ho, TYR); p.tx = fs::cdiv(p.Wo, TW);
+  p.tiles = (long long)p.B * p.tz * p.ty * p.tx;
+  const int mgroups = p.CoutP / (32 * MT);
+  if (p.tiles >= (1ll << 31) || mgroups > 65535) return FS_ERR_SHAPE;
+  hipLaunchKernelGGL((conv3d_fwd_ws_kernel<K, S, CI, MT, NT, TZ, TY, TW>), dim3((unsigned)p.tiles, mgroups),
+                     dim3(512), 0, st, X, Wt, bias, Y, p);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
 template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
 int launch(const float* X, const float* Wt, const float* bias, float* Y, FP& p, hipStream_t st) {
   constexpr int TYR = TY * (32 / TW);
@@ -314,6 +540,13 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   const int total = cinp * K3 * p.CoutP;
   hipLaunchKernelGGL(wprep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, ws, Cout, Cin, K3, cinp,
                      p.CoutP, wmode);
+  // loader-wave kernels (k = 4 only: 100 / 129 TFLOP/s vs 92 / 120 for conv0a / conv0b at 256^3; the 64-channel
+  // k = 3 layers run at 132 TFLOP/s in either form, so they stay on the two-workgroups-per-CU kernel): 16-byte
+  // pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets inside one staged channel
+  // chunk, enough bricks to fill the chip with one workgroup per CU
+  static const bool reg_only = getenv("FLOWSCI_FWD_REG") != nullptr;
+  const bool ws_ok = !reg_only && Wi % 4 == 0 && Wo > 16 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 &&
+                     (long long)(kernel == 3 ? 4 : 2) * Di * Hi * Wi * 4 < (1ll << 31);
   if (kernel == 3) {
     // big bricks (2 x 8 x 32 / 2 x 16 x 16 voxels) when they fill the chip, else quarter-size bricks
     // (1 x 4 x 32 / 1 x 8 x 16): the 16^3 / 32^3 trunk layers of the coarse blocks have only 8K-64K
@@ -328,10 +561,13 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     if (wide) return launch<3, 1, 4, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
     return launch<3, 1, 4, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
   }
+  const long long k4tiles = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, 8) * fs::cdiv(Wo, 32);
   if (p.CoutP == 32) {
+    if (ws_ok && k4tiles >= 512) return launch_ws<4, 2, 2, 1, 4, 2, 8, 32>(x, ws, bias, y, p, st);
     if (Wo > 16) return launch<4, 2, 2, 1, 2, 1, 8, 32>(x, ws, bias, y, p, st);
     return launch<4, 2, 2, 1, 2, 1, 8, 16>(x, ws, bias, y, p, st);
   }
+  if (ws_ok && 2 * k4tiles * (p.CoutP / 64) >= 512) return launch_ws<4, 2, 2, 2, 2, 1, 8, 32>(x, ws, bias, y, p, st);
   if (Wo > 16) return launch<4, 2, 2, 2, 2, 1, 8, 32>(x, ws, bias, y, p, st);
   return launch<4, 2, 2, 2, 2, 1, 8, 16>(x, ws, bias, y, p, st);
 }
