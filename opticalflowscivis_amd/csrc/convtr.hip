@@ -21,6 +21,9 @@
 //       tile wastes most of the matrix core, and the fp32 vector ALUs have the same peak as the fp32
 //       matrix cores on this part.  One thread per two q (consecutive qy), 16*CO accumulators, weights
 //       are wave-uniform -> scalar loads feeding v_fmac's SGPR operand (each feeds two FMAs).
+#include <cstdint>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -354,6 +357,265 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma16_kernel(const float* __re
   }
 }
 
+// ---- loader-wave forms (one 8-wave workgroup per CU, two LDS buffers) --------------------------------
+// The two MFMA kernels above with the staging moved to partner waves and to `buffer_load_dwordx4 ... lds`
+// (csrc/convwrw.hip has the measurements that led here): waves 4-7 issue the 16-byte pieces of chunk c+1 --
+// the haloed input brick (rows start 4 floats left of the first position: 16-byte aligned when Wi % 4 == 0,
+// pitch 40) and the weight slab -- into the second LDS buffer while waves 0-3 run the MFMA phase of chunk c.
+// The MFMA phase of a chunk is short here (128 matrix instructions per wave) and the weight slab is 3/4 of
+// the staged bytes: in the kernels above every thread spent ~33 load / ds_write instructions per chunk on it.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+[[maybe_unused]] constexpr unsigned DMA_OOB = 0x80000000u;
+
+// the loader waves' whole life: CPW = channels per weight-slab row (32 / 16)
+template <int TZ, int TY, int CPW>
+__device__ __forceinline__ void tr_loader(const float* __restrict__ X, const float* __restrict__ Wt, const TP& p,
+                                          float* lds, int wv, int lane, int b, int qz0, int qy0, int qx0) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
+  constexpr int CI = 4;
+  constexpr int ZT = TZ + 2, YT = TY + 2, XP = 40;
+  constexpr int PS = YT * XP, CHS = ZT * PS;
+  constexpr int NX = CI * CHS, NW = CI * 64 * CPW;
+  constexpr int NXL = (NX + 255) / 256 * 256, NWL = (NW + 255) / 256 * 256;
+  constexpr int NXW = (NXL / 256 + 3) / 4, NWW = (NWL / 256 + 3) / 4;
+  constexpr int BUF = NXL + NWL;
+  const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
+  unsigned xoff[NXW], woff[NWW];
+#pragma unroll
+  for (int k = 0; k < NXW; ++k) {
+    const int i = 256 * (wv + 4 * k) + 4 * lane;
+    const int c = i / CHS, r1 = i - c * CHS;
+    const int z = r1 / PS, r2 = r1 - z * PS;
+    const int y = r2 / XP, x = r2 - y * XP;
+    const int gz = qz0 - 1 + z, gy = qy0 - 1 + y, gx = qx0 - 4 + x;
+    const bool ok = i < NX && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+    xoff[k] = ok ? ((unsigned)c * (unsigned)xvol + ((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u : DMA_OOB;
+  }
+#pragma unroll
+  for (int k = 0; k < NWW; ++k) {
+    const int i = 256 * (wv + 4 * k) + 4 * lane;
+    woff[k] = i < NW ? (unsigned)i * 4u : DMA_OOB;
+  }
+  auto stage = [&](int c0, int buf) {
+    const int nch = (p.Cin - c0 < CI) ? (p.Cin - c0) : CI;  // channels past Cin read as zero
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(X + ((size_t)b * p.Cin + c0) * xvol), (short)0, (int)((unsigned)nch * (unsigned)xvol * 4u), 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(Wt + (size_t)c0 * 64 * CPW), (short)0,
+                                                                   0x7fffffff, 0x00020000);
+    float* base = lds + buf * BUF;
+#pragma unroll
+    for (int k = 0; k < NXW; ++k)
+      if (256 * (wv + 4 * k) < NXL)  // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + 256 * (wv + 4 * k)), 16, xoff[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NWW; ++k)
+      if (256 * (wv + 4 * k) < NWL)  // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + NXL + 256 * (wv + 4 * k)), 16, woff[k], 0, 0, 0);
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+    if (c0 + CI < p.Cin) stage(c0 + CI, buf ^ 1);
+    // the pieces of the next chunk have landed; past the barrier the matrix waves are done reading `buf`
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf ^= 1;
+  }
+#endif
+}
+
+template <int TZ, int TY>
+__global__ __launch_bounds__(512, 2) void convtr_mfma_ws_kernel(const float* __restrict__ X,
+                                                             const float* __restrict__ Wt,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ Y, TP p) {
+  static_assert(TZ * TY == 4, "one 32-position row per matrix wave");
+  constexpr int CI = 4;
+  constexpr int ZT = TZ + 2, YT = TY + 2, XP = 40;
+  constexpr int PS = YT * XP, CHS = ZT * PS;
+  constexpr int NX = CI * CHS, NW = CI * 64 * 32;
+  constexpr int NXL = (NX + 255) / 256 * 256, NWL = (NW + 255) / 256 * 256;
+  constexpr int BUF = NXL + NWL;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wv = wave & 3;
+  const int col = lane & 31, kh = lane >> 5;
+  long long tile = blockIdx.x;
+  {
+    const long long per = p.tiles / 8;
+    if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int txi = (int)(tile % p.tx); tile /= p.tx;
+  const int tyi = (int)(tile % p.ty); tile /= p.ty;
+  const int tzi = (int)(tile % p.tz);
+  const int b = (int)(tile / p.tz);
+  const int qz0 = tzi * TZ, qy0 = tyi * TY, qx0 = txi * 32;
+  if (wave >= 4) {
+    tr_loader<TZ, TY, 32>(X, Wt, p, lds, wv, lane, b, qz0, qy0, qx0);
+    return;
+  }
+  const int wz = wv / TY, wy = wv % TY;
+  const int bBo = kh * 2 * CHS + (wz + 1) * PS + (wy + 1) * XP + (col + 4);
+  const int aBo = NXL + kh * 2 * 64 * 32 + col;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  __builtin_amdgcn_s_barrier();  // chunk 0 has landed
+  int buf = 0;
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+    const float* bB = lds + buf * BUF + bBo;
+    const float* aB = lds + buf * BUF + aBo;
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      float xn[27];
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            xn[(dz * 3 + dy) * 3 + dx] = bB[cl * CHS + (dz - 1) * PS + (dy - 1) * XP + (dx - 1)];
+#pragma unroll
+      for (int cls = 0; cls < 8; ++cls) {
+        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+#pragma unroll
+        for (int tp = 0; tp < 8; ++tp) {
+          const int a = tp >> 2, bb = (tp >> 1) & 1, c = tp & 1;
+          const int kidx = (tap_k(pz, a) * 4 + tap_k(py, bb)) * 4 + tap_k(px, c);
+          const int didx = ((tap_d(pz, a) + 1) * 3 + (tap_d(py, bb) + 1)) * 3 + (tap_d(px, c) + 1);
+          const float av = aB[(cl * 64 + kidx) * 32];
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xn[didx], acc[cls], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();  // the next chunk has landed, everyone is done reading `buf`
+    buf ^= 1;
+  }
+
+  const int qz = qz0 + wz, qy = qy0 + wy, qx = qx0 + col;
+  if (qz < p.Dq && qy < p.Hq && qx < p.Wq) {
+    const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (co >= p.Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = acc[c][r] + bv;
+      store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p,
+             p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
+    }
+  }
+}
+
+template <int TZ, int TY>
+__global__ __launch_bounds__(512, 2) void convtr_mfma16_ws_kernel(const float* __restrict__ X,
+                                                               const float* __restrict__ Wt,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ Y, TP p) {
+  static_assert(TZ * TY == 4, "one 32-position row per matrix wave");
+  constexpr int CI = 4;
+  constexpr int ZT = TZ + 2, YT = TY + 2, XP = 40;
+  constexpr int PS = YT * XP, CHS = ZT * PS;
+  constexpr int NX = CI * CHS, NW = CI * 64 * 16;
+  constexpr int NXL = (NX + 255) / 256 * 256, NWL = (NW + 255) / 256 * 256;
+  constexpr int BUF = NXL + NWL;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wv = wave & 3;
+  const int col = lane & 15, kq = lane >> 4;
+  long long tile = blockIdx.x;
+  {
+    const long long per = p.tiles / 8;
+    if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int txi = (int)(tile % p.tx); tile /= p.tx;
+  const int tyi = (int)(tile % p.ty); tile /= p.ty;
+  const int tzi = (int)(tile % p.tz);
+  const int b = (int)(tile / p.tz);
+  const int qz0 = tzi * TZ, qy0 = tyi * TY, qx0 = txi * 32;
+  if (wave >= 4) {
+    tr_loader<TZ, TY, 16>(X, Wt, p, lds, wv, lane, b, qz0, qy0, qx0);
+    return;
+  }
+  const int wz = wv / TY, wy = wv % TY;
+  const int bBo = kq * CHS + (wz + 1) * PS + (wy + 1) * XP + (col + 4);
+  const int aBo = NXL + kq * 64 * 16 + col;
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[n][c][r] = 0.f;
+
+  __builtin_amdgcn_s_barrier();  // chunk 0 has landed
+  int buf = 0;
+  for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+    const float* bB = lds + buf * BUF + bBo;
+    const float* aB = lds + buf * BUF + aBo;
+    float xn[2][27];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            xn[n][(dz * 3 + dy) * 3 + dx] = bB[16 * n + (dz - 1) * PS + (dy - 1) * XP + (dx - 1)];
+#pragma unroll
+    for (int cls = 0; cls < 8; ++cls) {
+      const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp) {
+        const int a = tp >> 2, bb = (tp >> 1) & 1, c = tp & 1;
+        const int kidx = (tap_k(pz, a) * 4 + tap_k(py, bb)) * 4 + tap_k(px, c);
+        const int didx = ((tap_d(pz, a) + 1) * 3 + (tap_d(py, bb) + 1)) * 3 + (tap_d(px, c) + 1);
+        const float av = aB[kidx * 16];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[n][cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xn[n][didx], acc[n][cls], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();  // the next chunk has landed, everyone is done reading `buf`
+    buf ^= 1;
+  }
+
+  const int qz = qz0 + wz, qy = qy0 + wy;
+  if (qz < p.Dq && qy < p.Hq) {
+    const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int qx = qx0 + 16 * n + col;
+      if (qx >= p.Wq) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * kq + r;
+        if (co >= p.Cout) continue;
+        const float bv = bias ? bias[co] : 0.f;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = acc[n][c][r] + bv;
+        store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p,
+               p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
+      }
+    }
+  }
+}
+
 // NP input-grid positions (consecutive qy) per thread: every scalar-loaded weight feeds NP FMAs.  The
 // kernel is bound by the scalar weight stream (64*CO dwords per input channel and wave through ~100
 // SGPRs), not by the vector ALUs or the address path -- packed FMAs / an LDS-staged input brick did not
@@ -484,15 +746,25 @@ static int conv3d_tr_impl(const float* x, const float* w, const float* bias, con
   p.tz = fs::cdiv(p.Dq, 2); p.ty = fs::cdiv(p.Hq, 2); p.tx = fs::cdiv(p.Wq, 32);
   p.tiles = (long long)B * p.tz * p.ty * p.tx;
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
+  // loader-wave kernels: 16-byte pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets
+  // inside a staged 4-channel chunk, at least two bricks per CU.  `FLOWSCI_TR_REG=1`: the register-staged kernels.
+  static const bool reg_only = getenv("FLOWSCI_TR_REG") != nullptr;
+  const bool ws_ok = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && p.tiles >= 512 &&
+                     (long long)4 * Di * Hi * Wi * 4 < (1ll << 31);
   if (Cout <= 16) {
     hipLaunchKernelGGL(wprep_tr16_kernel, dim3((cinp * 64 * 16 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
                        cinp);
-    hipLaunchKernelGGL((convtr_mfma16_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y,
-                       p);
+    if (ws_ok)
+      hipLaunchKernelGGL((convtr_mfma16_ws_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(512), 0, st, x, ws, bias, y, p);
+    else
+      hipLaunchKernelGGL((convtr_mfma16_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
   } else {
     hipLaunchKernelGGL(wprep_tr_kernel, dim3((cinp * 64 * 32 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
                        cinp);
-    hipLaunchKernelGGL((convtr_mfma_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
+    if (ws_ok)
+      hipLaunchKernelGGL((convtr_mfma_ws_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(512), 0, st, x, ws, bias, y, p);
+    else
+      hipLaunchKernelGGL((convtr_mfma_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
   }
   FS_LAUNCH_CHECK();
   return FS_OK;
