@@ -21,6 +21,7 @@ _float = ctypes.c_float
 _stream = ctypes.c_void_p
 _intp = ctypes.POINTER(ctypes.c_int)  # host array of ints (or None)
 _i64p = ctypes.POINTER(ctypes.c_longlong)  # host out-parameter
+_i64 = ctypes.c_longlong
 
 # name -> argtypes; restype is int unless listed in _RESTYPES
 SIGNATURES = {
@@ -31,6 +32,10 @@ SIGNATURES = {
     "fs_warp3d_pair_fwd": [_f32p] * 5 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_warp3d_pair_bwd": [_f32p] * 8 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_warp3d_pair_bwd_acc": [_f32p] * 9 + [_int, _int, _intp, _int, _int, _int, _stream],
+    "fs_warp3d_pair_bwd_acc3": [_f32p] * 7 + [_f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _int, _int, _intp, _int, _int,
+                                _int, _stream],
+    "fs_upsample_warp3d_pair_bwd3": [_f32p] * 5 + [_f32p, _i64, _f32p, _i64, _f32p, _i64] + [_f32p] * 3 +
+                                    [_int, _int, _intp, _int, _int, _int, _int, _float, _stream],
     "fs_upsample_warp3d_pair_fwd": [_f32p] * 7 + [_int, _int, _intp, _int, _int, _int, _int, _float, _stream],
     "fs_upsample_warp3d_pair_bwd": [_f32p] * 9 + [_int, _int, _intp, _int, _int, _int, _int, _float, _stream],
     "fs_warp2d_pair_fwd": [_f32p] * 5 + [_int, _int, _intp, _int, _int, _int, _stream],

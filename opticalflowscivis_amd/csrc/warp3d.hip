@@ -316,7 +316,8 @@ struct Mover {
   // transposed LDS tile (+ the same positions of `add`, when given) -> global plane (guarded).  `add`
   // may be the plane itself: every element is read and then written by the same thread.
   __device__ static __forceinline__ void store(float* plane, const W3P& p, int h0, int w0,
-                                               const float (*tile)[LDH], const float* add = nullptr) {
+                                               const float (*tile)[LDH], const float* add = nullptr,
+                                               const float* add1 = nullptr, const float* add2 = nullptr) {
     const int t = threadIdx.x, col = t % LPR, row0 = t / LPR;
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
@@ -332,12 +333,24 @@ struct Mover {
             const float4 a = *reinterpret_cast<const float4*>(add + (size_t)h * p.W + w);
             v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
           }
+          if (add1 != nullptr) {
+            const float4 a = *reinterpret_cast<const float4*>(add1 + (size_t)h * p.W + w);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+          if (add2 != nullptr) {
+            const float4 a = *reinterpret_cast<const float4*>(add2 + (size_t)h * p.W + w);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
           *reinterpret_cast<float4*>(plane + (size_t)h * p.W + w) = v;
         }
       } else {
         const int w = w0 + col;
-        if (h < p.H && w < p.W)
-          plane[(size_t)h * p.W + w] = tile[col][hh] + (add != nullptr ? add[(size_t)h * p.W + w] : 0.f);
+        if (h < p.H && w < p.W) {
+          float v = tile[col][hh] + (add != nullptr ? add[(size_t)h * p.W + w] : 0.f);
+          if (add1 != nullptr) v += add1[(size_t)h * p.W + w];
+          if (add2 != nullptr) v += add2[(size_t)h * p.W + w];
+          plane[(size_t)h * p.W + w] = v;
+        }
       }
     }
   }
@@ -431,9 +444,16 @@ __global__ __launch_bounds__(NT, UPS ? 4 : 1) void warp3d_fwd_kernel(W3Fwd io, c
   }
 }
 
+// up to three gradients reaching the flow from its other consumers: [B, >= flowC, D,H,W] tensors or channel
+// slices of wider ones (`bs` = batch stride in floats; the channel stride is always D*H*W)
+struct W3Add {
+  const float* a[3];
+  long long bs[3];
+};
+
 template <int NT, bool VEC, bool WITH_GIN>
 __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* __restrict__ flow,
-                                                        float* gflow, const float* gadd, W3P p) {
+                                                        float* gflow, W3Add gadd, W3P p) {
   using M = Mover<NT, VEC>;
   constexpr int NW = TW / (NT / 64);
   const float* __restrict__ in = io.in[blockIdx.y];
@@ -449,8 +469,11 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
   const size_t ivol = (size_t)p.Di * p.Hi * p.Wi;
   const float* fb = flow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol;
   float* gfb = gflow ? gflow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol : nullptr;
-  // gradient reaching the flow from its other consumers, summed into the stored tile (may alias gflow)
-  const float* gab = (gflow && gadd) ? gadd + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol : nullptr;
+  // gradients reaching the flow from its other consumers, summed into the stored tile (the first may alias gflow)
+  const float* gab[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    gab[i] = (gflow && gadd.a[i]) ? gadd.a[i] + (size_t)b * gadd.bs[i] + (size_t)(3 * blockIdx.y) * vol : nullptr;
   const int dEnd = min(d0 + p.dc, p.D);
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -541,9 +564,12 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
     }
     if (gfb != nullptr) {
       float* g = gfb + (size_t)d * HW;
-      const float* a = gab ? gab + (size_t)d * HW : nullptr;
-      M::store(g, p, h0, w0, sF[0], a); M::store(g + vol, p, h0, w0, sF[1], a ? a + vol : nullptr);
-      M::store(g + 2 * vol, p, h0, w0, sF[2], a ? a + 2 * vol : nullptr);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const size_t o = (size_t)c * vol + (size_t)d * HW;
+        M::store(g + (size_t)c * vol, p, h0, w0, sF[c], gab[0] ? gab[0] + o : nullptr, gab[1] ? gab[1] + o : nullptr,
+                 gab[2] ? gab[2] + o : nullptr);
+      }
     }
     __syncthreads();  // stores have read sF before the next slice's flow overwrites it
   }
@@ -604,19 +630,20 @@ int launch_fwd(const W3Fwd& io, int npair, const float* flow, const UpP* up, W3P
 
 template <int NT, bool VEC>
 void launch_bwd_t(const W3Bwd& io, const dim3& g, bool with_gin, const float* flow, float* gflow,
-                  const float* gadd, const W3P& p, hipStream_t st) {
+                  const W3Add& gadd, const W3P& p, hipStream_t st) {
   if (with_gin)
     hipLaunchKernelGGL((warp3d_bwd_kernel<NT, VEC, true>), g, dim3(NT), 0, st, io, flow, gflow, gadd, p);
   else
     hipLaunchKernelGGL((warp3d_bwd_kernel<NT, VEC, false>), g, dim3(NT), 0, st, io, flow, gflow, gadd, p);
 }
 
-int launch_bwd(const W3Bwd& io, int npair, bool with_gin, const float* flow, float* gflow, const float* gadd,
+int launch_bwd(const W3Bwd& io, int npair, bool with_gin, const float* flow, float* gflow, const W3Add& gadd,
                W3P& p, fs_stream_t stream) {
   const unsigned grid = (unsigned)((long long)p.B * p.nDC * p.tilesH * p.tilesW);
   p.flowC = 3 * npair;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = vec_ok(p, flow, gflow, io.gout[0], io.gout[1]) && vec_ok(p, gadd, nullptr, nullptr, nullptr);
+  const bool vec = vec_ok(p, flow, gflow, io.gout[0], io.gout[1]) && vec_ok(p, gadd.a[0], gadd.a[1], gadd.a[2], nullptr) &&
+                   gadd.bs[0] % 4 == 0 && gadd.bs[1] % 4 == 0 && gadd.bs[2] % 4 == 0;
   const dim3 g(grid, npair);
   if (vec) launch_bwd_t<256, true>(io, g, with_gin, flow, gflow, gadd, p, st);
   else launch_bwd_t<256, false>(io, g, with_gin, flow, gflow, gadd, p, st);
@@ -647,7 +674,7 @@ extern "C" int fs_warp3d_bwd(const float* in, const float* flow, const float* gr
   const int rc = make_params(p, B, C, in_dhw, D, H, W);
   if (rc != FS_OK) return rc;
   W3Bwd io = {{in, nullptr}, {grad_out, nullptr}, {grad_in, nullptr}};
-  return launch_bwd(io, 1, grad_in != nullptr, flow, grad_flow, nullptr, p, stream);
+  return launch_bwd(io, 1, grad_in != nullptr, flow, grad_flow, W3Add{}, p, stream);
 }
 
 extern "C" int fs_warp3d_pair_fwd(const float* img0, const float* img1, const float* flow6,
@@ -676,7 +703,7 @@ extern "C" int fs_warp3d_pair_bwd(const float* img0, const float* img1, const fl
   const int rc = make_params(p, B, C, in_dhw, D, H, W);
   if (rc != FS_OK) return rc;
   W3Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
-  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6, nullptr, p, stream);
+  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6, W3Add{}, p, stream);
 }
 
 // fs_warp3d_pair_bwd with the gradient that reaches the flow from its OTHER consumers (`grad_flow_add`,
@@ -696,7 +723,34 @@ extern "C" int fs_warp3d_pair_bwd_acc(const float* img0, const float* img1, cons
   const int rc = make_params(p, B, C, in_dhw, D, H, W);
   if (rc != FS_OK) return rc;
   W3Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
-  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6, grad_flow_add, p, stream);
+  const long long bs = (long long)6 * D * H * W;
+  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6, W3Add{{grad_flow_add, nullptr, nullptr}, {bs, 0, 0}}, p,
+                    stream);
+}
+
+// The same with up to THREE such gradients, each a [B,6,D,H,W] tensor or a 6-channel slice of a wider one
+// (`batch_stride*` in floats): the flow of an IFNet block is consumed by the next block's input concatenation
+// (its gradient arrives as channels 5..10 of the 11-channel input gradient), the next block's accumulation and
+// the distillation term; handing each consumer its own alias of the flow keeps autograd from summing them in
+// two extra passes over 805 MB tensors (opticalflowscivis_amd/ops.py::_WarpPairAcc).
+extern "C" int fs_warp3d_pair_bwd_acc3(const float* img0, const float* img1, const float* flow6,
+                                       const float* grad_out0, const float* grad_out1, float* grad_img0,
+                                       float* grad_img1, const float* add0, long long batch_stride0,
+                                       const float* add1, long long batch_stride1, const float* add2,
+                                       long long batch_stride2, float* grad_flow6, int B, int C, const int* in_dhw,
+                                       int D, int H, int W, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(img0); FS_REQUIRE_PTR(img1); FS_REQUIRE_PTR(flow6);
+  FS_REQUIRE_PTR(grad_out0); FS_REQUIRE_PTR(grad_out1); FS_REQUIRE_PTR(grad_flow6);
+  if ((grad_img0 == nullptr) != (grad_img1 == nullptr)) return FS_ERR_NULLPTR;
+  W3P p;
+  const int rc = make_params(p, B, C, in_dhw, D, H, W);
+  if (rc != FS_OK) return rc;
+  const long long fl = (long long)6 * D * H * W;
+  if ((add0 && batch_stride0 < fl) || (add1 && batch_stride1 < fl) || (add2 && batch_stride2 < fl)) return FS_ERR_ARG;
+  W3Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
+  return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6,
+                    W3Add{{add0, add1, add2}, {batch_stride0, batch_stride1, batch_stride2}}, p, stream);
 }
 
 // "upsample flow x scale -> warp" in one kernel.  flow_out = prev_flow + scale *
@@ -727,6 +781,24 @@ extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, flo
 // Backward of the fused node: grad_flow_total = d(warps)/d(flow) + grad_flow_add (the gradient reaching
 // flow_out from its other consumers, nullable; may alias grad_flow_total) -- which is also the gradient of
 // prev_flow -- and grad_delta = scale * adjoint_upsample(grad_flow_total).  ws: B*6*(D*H*Ws + D*Hs*Ws) floats.
+extern "C" int fs_upsample_warp3d_pair_bwd3(const float* img0, const float* img1, const float* flow6,
+                                            const float* grad_out0, const float* grad_out1, const float* add0,
+                                            long long batch_stride0, const float* add1, long long batch_stride1,
+                                            const float* add2, long long batch_stride2, float* grad_flow_total,
+                                            float* grad_delta, float* ws, int B, int C, const int* in_dhw, int Ds,
+                                            int Hs, int Ws, int factor, float scale, fs_stream_t stream) {
+  FS_REQUIRE_PTR(grad_delta); FS_REQUIRE_PTR(ws);
+  if (factor != 2 && factor != 4) return FS_ERR_ARG;
+  if (Ds < 1 || Hs < 1 || Ws < 1) return FS_ERR_SHAPE;
+  if ((long long)Ds * Hs * Ws * factor * factor * factor >= (1ll << 31)) return FS_ERR_SHAPE;
+  const int D = Ds * factor, H = Hs * factor, W = Ws * factor;
+  int rc = fs_warp3d_pair_bwd_acc3(img0, img1, flow6, grad_out0, grad_out1, nullptr, nullptr, add0, batch_stride0, add1,
+                                   batch_stride1, add2, batch_stride2, grad_flow_total, B, C, in_dhw, D, H, W, stream);
+  if (rc != FS_OK) return rc;
+  return fs_interp3d_bwd_scaled(grad_flow_total, grad_delta, ws, B, 6, Ds, Hs, Ws, D, H, W, factor, 1, scale,
+                                stream);
+}
+
 extern "C" int fs_upsample_warp3d_pair_bwd(const float* img0, const float* img1, const float* flow6,
                                            const float* grad_out0, const float* grad_out1,
                                            const float* grad_flow_add, float* grad_flow_total, float* grad_delta,

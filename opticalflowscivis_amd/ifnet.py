@@ -154,6 +154,11 @@ class IFNet(nn.Module):
         flow_list, merged, mask_list, mask_logits = [], [], [], []
         warped_img0, warped_img1 = img0, img1
         flow = mask = None
+        # In 3-D every block's flow is handed to its three other consumers through three aliases (f_in: the next
+        # block's input concatenation, f_base: the next block's accumulation, f_dist: the distillation term), so
+        # that their gradients reach the warp's backward launch one by one and are summed there
+        # (ops._WarpPairAcc) instead of by autograd `add`s over the full-size flow.
+        f_in = f_base = f_dist = None
         loss_distill = 0
         stu = [self.block0, self.block1, self.block2]
         for i in range(3):
@@ -163,26 +168,28 @@ class IFNet(nn.Module):
                 sp = _min_spatial(img0, warped_img0)
                 img0, img1 = _crop(img0, sp), _crop(img1, sp)
                 warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
-                mask, flow = _crop(mask, sp), _crop(flow, sp)
+                mask, f_in, f_base = _crop(mask, sp), _crop(f_in, sp), _crop(f_base, sp)
                 flow_d, mask_d, kind = stu[i]((img0, img1, warped_img0, warped_img1, mask),
-                                              flow, scale[i], flow, mask, accumulate=True)
+                                              f_in, scale[i], f_base, mask, accumulate=True)
             else:
                 flow_d, mask_d, kind = stu[i](torch.cat((img0, img1), 1), None, scale[i], accumulate=True)
             warped = None
+            aliases = None
             if kind == "lowres":
                 full = tuple(scale[i] * n for n in flow_d.shape[2:])
                 if all(f <= n for f, n in zip(full, img0.shape[2:])):
                     # §8f.1: up-sample x scale, accumulate onto the running flow and warp both frames in ONE
                     # launch (no crop can follow: the flow is not larger than the frames)
-                    flow, w0, w1 = ops.upsample_warp_pair(img0, img1, flow_d, flow, scale[i])
+                    aliases, w0, w1 = ops.upsample_warp_pair(img0, img1, flow_d, f_base, scale[i])
+                    flow = aliases[0]
                     warped = (w0, w1)
                 else:
-                    flow = ops.upsample3d_scale_add(flow_d, flow, scale[i], float(scale[i]))
+                    flow = ops.upsample3d_scale_add(flow_d, f_base, scale[i], float(scale[i]))
                 mask = mask_d
             elif kind == "sum":  # flow + flow_d, mask + mask_d formed inside the producing kernels
                 flow, mask = flow_d, mask_d
             elif flow is not None:
-                flow = flow + _crop(flow_d, img0.shape[2:])
+                flow = f_base + _crop(flow_d, img0.shape[2:])
                 mask = mask + _crop(mask_d, img0.shape[2:])
             else:
                 flow, mask = flow_d, mask_d
@@ -191,32 +198,35 @@ class IFNet(nn.Module):
             sp = _min_spatial(img0, warped_img0)
             if self.nd == 3:
                 flow, mask = _crop(flow, sp), _crop(mask, sp)
+                if aliases is not None:
+                    aliases = tuple(_crop(a, sp) for a in aliases)
             img0, img1 = _crop(img0, sp), _crop(img1, sp)
             mask_logits.append(mask)
             # hot path: both backward warps of this block in one HIP launch.  In 3-D the launch also
-            # hands the flow on to its other consumers (next block, distillation), so that their summed
-            # gradient is folded into the warp's backward launch instead of a separate autograd add.
+            # hands the flow on to its other consumers (next block, distillation), so that their
+            # gradients are folded into the warp's backward launch instead of separate autograd adds.
             if warped is None:
                 if self.nd == 3:
-                    w0, w1, flow = ops.warp_pair_acc(img0, img1, flow)
+                    w0, w1, aliases = ops.warp_pair_acc(img0, img1, flow)
                     warped = (w0, w1)
                 else:
                     warped = ops.warp_pair(img0, img1, flow)
+            f_in, f_base, f_dist = aliases if aliases is not None else (flow, flow, flow)
             warped_img0, warped_img1 = warped
-            flow_list.append(flow)
+            flow_list.append(f_dist)
             merged.append((warped_img0, warped_img1))
 
         if gt.shape[1] == 1:
             sp = _min_spatial(img0, warped_img0)
             img0, img1 = _crop(img0, sp), _crop(img1, sp)
             warped_img0, warped_img1 = _crop(warped_img0, sp), _crop(warped_img1, sp)
-            mask, flow, gt = _crop(mask, sp), _crop(flow, sp), _crop(gt, sp)
+            mask, f_in, f_base, gt = _crop(mask, sp), _crop(f_in, sp), _crop(f_base, sp), _crop(gt, sp)
             flow_d, mask_d, kind = self.block_tea(
-                (img0, img1, warped_img0, warped_img1, mask, gt), flow, 1, flow, mask, accumulate=True)
+                (img0, img1, warped_img0, warped_img1, mask, gt), f_in, 1, f_base, mask, accumulate=True)
             if kind == "sum":
                 flow_teacher, mask_teacher = flow_d, mask_d
             else:
-                flow_teacher, mask_teacher = flow + _crop(flow_d, sp), mask + _crop(mask_d, sp)
+                flow_teacher, mask_teacher = f_base + _crop(flow_d, sp), mask + _crop(mask_d, sp)
             w0t, w1t = ops.warp_pair(img0, img1, flow_teacher)
             merged_teacher, _ = ops.merge(w0t, w1t, mask_teacher)
         else:

@@ -31,6 +31,16 @@ def _need_cuda_f32(name, t, ndim):
     return t.contiguous()
 
 
+def _need_cuda_f32_strided(name, t, ndim):
+    """_need_cuda_f32 without the `.contiguous()`: for operands whose strides are handed to the kernel."""
+    if not isinstance(t, torch.Tensor):
+        raise ValueError("%s must be a tensor" % name)
+    if t.dtype != torch.float32 or t.dim() != ndim or not t.is_cuda:
+        raise ValueError("%s must be a %d-D float32 GPU tensor, got %s %s on %s" %
+                         (name, ndim, t.dtype, tuple(t.shape), t.device))
+    return t
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -279,10 +289,42 @@ def _pair_forward(img0, img1, flow, nd):
     return out0, out1
 
 
+def _flow_addends(grads, flow):
+    """The (pointer, batch stride) pairs fs_*_bwd*3 take for up to three gradients of a [B,C,D,H,W] flow:
+    contiguous tensors or channel slices of wider contiguous ones (what `torch.cat`'s backward hands out) go
+    through as they are; anything else is made contiguous.  Returns (flat argument list, tensors to keep alive,
+    bytes read)."""
+    vol = flow.shape[2] * flow.shape[3] * flow.shape[4]
+    want_inner = (vol, flow.shape[3] * flow.shape[4], flow.shape[4], 1)
+    keep, args, nbytes = [], [], 0
+    for g in grads:
+        if g is None:
+            continue
+        g = _need_cuda_f32_strided("grad_flow", g, 5)
+        if tuple(g.shape) != tuple(flow.shape):
+            raise ValueError("gradient %s does not match the flow %s" % (tuple(g.shape), tuple(flow.shape)))
+        if tuple(g.stride()[1:]) != want_inner or g.stride(0) < flow.shape[1] * vol or g.data_ptr() % 16 or g.stride(0) % 4:
+            g = g.contiguous()
+        keep.append(g)
+        args += [g.data_ptr(), int(g.stride(0))]
+        nbytes += 4 * g.numel()
+    if len(keep) > 3:  # (never in IFNet: three consumers per flow)
+        extra = keep[3]
+        for g in keep[4:]:
+            extra = extra + g
+        keep = keep[:2] + [keep[2] + extra]
+        args = []
+        for g in keep:
+            g = g.contiguous()
+            args += [g.data_ptr(), int(g.stride(0))]
+    while len(args) < 6:
+        args += [None, 0]
+    return args, keep, nbytes
+
+
 def _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow, gflow_add=None):
-    """(grad_img0, grad_img1, grad_flow); `gflow_add` (3-D only): the gradient reaching the flow from its
-    other consumers, summed into grad_flow by the same launch (in place: the result IS gflow_add's buffer
-    when that tensor is contiguous and owned by this call)."""
+    """(grad_img0, grad_img1, grad_flow); `gflow_add` (3-D only): a gradient, or a list of up to three, reaching
+    the flow from its other consumers, summed into grad_flow by the same launch."""
     g0, g1 = g0.contiguous(), g1.contiguous()
     gi0 = torch.zeros_like(img0) if need_img else None
     gi1 = torch.zeros_like(img1) if need_img else None
@@ -293,11 +335,13 @@ def _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow, gflow_add=None
             D, H, W = flow.shape[2:]
             nb = 8 * flow.numel() + 8 * g0.numel() * 2 + (8 * img0.numel() if need_img else 0)
             if gflow_add is not None:
-                gflow_add = _need_cuda_f32("grad_flow", gflow_add, 5)
+                adds = gflow_add if isinstance(gflow_add, (list, tuple)) else [gflow_add]
+                aargs, keep, abytes = _flow_addends(adds, flow)
                 gflow = torch.empty_like(flow)
-                _call("fs_warp3d_pair_bwd_acc", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
-                      g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), gflow_add.data_ptr(), gflow.data_ptr(),
-                      B, C, _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb + 4 * flow.numel())
+                _call("fs_warp3d_pair_bwd_acc3", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
+                      g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), *aargs, gflow.data_ptr(),
+                      B, C, _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb + abytes)
+                del keep
             else:
                 gflow = torch.empty_like(flow) if need_flow else None
                 _call("fs_warp3d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
@@ -310,7 +354,9 @@ def _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow, gflow_add=None
                   g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), _ptr(gflow), B, C,
                   _in_hw(img0, flow), H, W, WARP2D_RIFE, _stream(flow))
             if gflow_add is not None and gflow is not None:
-                gflow = gflow + gflow_add
+                for g in (gflow_add if isinstance(gflow_add, (list, tuple)) else [gflow_add]):
+                    if g is not None:
+                        gflow = gflow + g
     return gi0, gi1, gflow
 
 
@@ -335,10 +381,11 @@ class _WarpPair(torch.autograd.Function):
 
 
 class _WarpPairAcc(torch.autograd.Function):
-    """(w0, w1, flow_out) with flow_out an alias of `flow`: the caller hands flow_out (not flow) to the
-    flow's other consumers, so autograd delivers THEIR summed gradient to this node, and the warp's
-    backward launch adds it to its own result (fs_warp3d_pair_bwd_acc) instead of autograd running a
-    separate add over the full-size flow."""
+    """(w0, w1, flow_a, flow_b, flow_c) with flow_* three aliases of `flow`: the caller hands ONE alias to each
+    of the flow's other consumers (next block's input, next block's accumulation, distillation), so autograd
+    delivers their gradients to this node one by one, and the warp's backward launch adds all of them to its own
+    result (fs_warp3d_pair_bwd_acc3) -- no autograd `add` over the full-size flow, and the 6-channel slice of the
+    next block's 11-channel input gradient is read in place."""
 
     @staticmethod
     def forward(ctx, img0, img1, flow):
@@ -346,17 +393,22 @@ class _WarpPairAcc(torch.autograd.Function):
         out0, out1 = _pair_forward(img0, img1, flow_c, nd)
         ctx.save_for_backward(img0, img1, flow_c)
         ctx.set_materialize_grads(False)
-        return out0, out1, flow_c.view_as(flow_c)
+        return out0, out1, flow_c.view_as(flow_c), flow_c.view_as(flow_c), flow_c.view_as(flow_c)
 
     @staticmethod
-    def backward(ctx, g0, g1, gflow_out):
+    def backward(ctx, g0, g1, ga, gb, gc):
         img0, img1, flow = ctx.saved_tensors
         need_img = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         need_flow = ctx.needs_input_grad[2]
         if not (need_img or need_flow):
             return None, None, None
+        adds = [g for g in (ga, gb, gc) if g is not None]
+        gflow_out = adds if adds else None
         if g0 is None and g1 is None:
-            return None, None, (gflow_out if need_flow else None)
+            tot = None
+            for g in adds:
+                tot = g if tot is None else tot + g
+            return None, None, (tot if need_flow else None)
         oshape = tuple(img0.shape[:2]) + tuple(flow.shape[2:])
         g0 = flow.new_zeros(oshape) if g0 is None else g0
         g1 = flow.new_zeros(oshape) if g1 is None else g1
@@ -375,11 +427,13 @@ def warp_pair(img0, img1, flow):
 
 
 def warp_pair_acc(img0, img1, flow):
-    """warp_pair that also returns the flow for its OTHER consumers: (w0, w1, flow_out).  Use flow_out
-    downstream instead of `flow`; the gradient arriving there is folded into the warp's backward launch."""
+    """warp_pair that also returns the flow for its OTHER consumers: (w0, w1, (flow_a, flow_b, flow_c)).  Use one
+    alias per downstream consumer instead of `flow`; the gradients arriving there are folded into the warp's
+    backward launch."""
     if img0.shape[0] == 0 and img1.shape[0] == 0 and flow.shape[0] == 0 and flow.dim() in (4, 5):
-        return warp_pair(img0, img1, flow) + (flow,)
-    return _WarpPairAcc.apply(img0, img1, flow)
+        return warp_pair(img0, img1, flow) + ((flow, flow, flow),)
+    w0, w1, fa, fb, fc = _WarpPairAcc.apply(img0, img1, flow)
+    return w0, w1, (fa, fb, fc)
 
 
 class _UpsampleWarpPair(torch.autograd.Function):
@@ -412,10 +466,10 @@ class _UpsampleWarpPair(torch.autograd.Function):
         ctx.save_for_backward(img0, img1, flow)
         ctx.cfg = (tuple(delta.shape), int(factor), float(scale), prev is not None)
         ctx.set_materialize_grads(False)
-        return flow, out0, out1
+        return flow, flow.view_as(flow), flow.view_as(flow), out0, out1
 
     @staticmethod
-    def backward(ctx, gflow_out, g0, g1):
+    def backward(ctx, gfa, gfb, gfc, g0, g1):
         img0, img1, flow = ctx.saved_tensors
         dshape, factor, scale, has_prev = ctx.cfg
         need_delta, need_prev = ctx.needs_input_grad[2], has_prev and ctx.needs_input_grad[3]
@@ -424,30 +478,34 @@ class _UpsampleWarpPair(torch.autograd.Function):
         B, C = img0.shape[:2]
         Ds, Hs, Ws = dshape[2:]
         D, H, W = flow.shape[2:]
-        if g0 is None and g1 is None and gflow_out is None:
+        adds = [g for g in (gfa, gfb, gfc) if g is not None]
+        if g0 is None and g1 is None and not adds:
             return (None,) * 6
         oshape = (B, C, D, H, W)
         g0 = flow.new_zeros(oshape) if g0 is None else g0.contiguous()
         g1 = flow.new_zeros(oshape) if g1 is None else g1.contiguous()
-        gadd = None if gflow_out is None else _need_cuda_f32("grad_flow", gflow_out, 5)
+        aargs, keep, abytes = _flow_addends(adds, flow)
         gtot = torch.empty_like(flow)
         gdelta = flow.new_empty(dshape)
         ws = flow.new_empty(B * 6 * (D * H * Ws + D * Hs * Ws))
         with torch.cuda.device(flow.device):
-            _call("fs_upsample_warp3d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(), g0.data_ptr(),
-                  g1.data_ptr(), _ptr(gadd), gtot.data_ptr(), gdelta.data_ptr(), ws.data_ptr(), B, C,
+            _call("fs_upsample_warp3d_pair_bwd3", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(), g0.data_ptr(),
+                  g1.data_ptr(), *aargs, gtot.data_ptr(), gdelta.data_ptr(), ws.data_ptr(), B, C,
                   _in_dhw(img0, flow), Ds, Hs, Ws, factor, scale, _stream(flow),
-                  algo_bytes=8 * flow.numel() + 8 * g0.numel() * 2 + (4 * flow.numel() if gadd is not None else 0)
-                  + 4 * (flow.numel() + gdelta.numel()))
+                  algo_bytes=8 * flow.numel() + 8 * g0.numel() * 2 + abytes + 4 * (flow.numel() + gdelta.numel()))
+        del keep
         return None, None, (gdelta if need_delta else None), (gtot if need_prev else None), None, None
 
 
 def upsample_warp_pair(img0, img1, delta, prev, factor, scale=None):
-    """(flow, w0, w1) with flow = prev + scale * F.interpolate(delta, scale_factor=factor, trilinear,
-    align_corners=False) (prev may be None; scale defaults to factor, Flow-3D/model/IFNet.py:118) and
+    """((flow_a, flow_b, flow_c), w0, w1) with flow = prev + scale * F.interpolate(delta, scale_factor=factor,
+    trilinear, align_corners=False) (prev may be None; scale defaults to factor, Flow-3D/model/IFNet.py:118) and
     (w0, w1) = warp_pair(img0, img1, flow): IFBlock's flow up-scaling, the running-flow accumulation and the
-    two backward warps in one launch."""
-    return _UpsampleWarpPair.apply(img0, img1, delta, prev, int(factor), float(factor if scale is None else scale))
+    two backward warps in one launch.  flow_* are three aliases of the flow, one per downstream consumer (see
+    _WarpPairAcc): their gradients are summed inside the backward warp launch."""
+    fa, fb, fc, w0, w1 = _UpsampleWarpPair.apply(img0, img1, delta, prev, int(factor),
+                                                 float(factor if scale is None else scale))
+    return (fa, fb, fc), w0, w1
 
 
 # --------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ def _patch_ops_with_oracle():
     from oracle import losses as ol
     from oracle import warps as ow
     ops.warp_pair = lambda a, b, f: (ow.warp3d_ref(a, f[:, :3]), ow.warp3d_ref(b, f[:, 3:6]))
-    ops.warp_pair_acc = lambda a, b, f: ops.warp_pair(a, b, f) + (f,)
+    ops.warp_pair_acc = lambda a, b, f: ops.warp_pair(a, b, f) + ((f, f, f),)
     ops.merge = lambda w0, w1, m: (ol.merge(w0, w1, m), torch.sigmoid(m))
     ops.distill_term = ol.distill_term
     ops.l1_loss = F.l1_loss

@@ -117,8 +117,9 @@ def test_upsample_warp_pair_vs_composition_and_oracle(ops, small, factor, with_p
     p1 = prev.to(DEV).requires_grad_() if with_prev else None
     p2 = prev.to(DEV).requires_grad_() if with_prev else None
     i0, i1 = img0.to(DEV), img1.to(DEV)
-    f_f, a0, a1 = ops.upsample_warp_pair(i0, i1, d1, p1, factor)
+    (f_f, f_f2, f_f3), a0, a1 = ops.upsample_warp_pair(i0, i1, d1, p1, factor)
     f_c, c0, c1 = _composed(ops, i0, i1, d2, p2, factor)
+    assert torch.equal(f_f2, f_c) and torch.equal(f_f3, f_c)
     assert torch.equal(f_f, f_c) and torch.equal(a0, c0) and torch.equal(a1, c1)
     # oracle
     fo = F.interpolate(delta, scale_factor=factor, mode="trilinear", align_corners=False,
@@ -132,9 +133,15 @@ def test_upsample_warp_pair_vs_composition_and_oracle(ops, small, factor, with_p
     Gf = _rnd(f_f.shape, 37, 0.3).to(DEV)
     ins1 = [d1] + ([p1] if with_prev else [])
     ins2 = [d2] + ([p2] if with_prev else [])
+    other = _rnd((B, 5) + full, 38).to(DEV)
+    Gc = _rnd((B, 11) + full, 39, 0.2).to(DEV)
+
+    def consumers(fa, fb, fc):  # next block's input concatenation, its accumulation, the distillation term
+        return (torch.cat((other, fa), 1) * Gc).sum() + (fb * Gf).sum() + (fc.square() * 0.25).sum()
+
     for use_flow in (True, False):
-        l1 = (a0 * G0).sum() + (a1 * G1).sum() + ((f_f * Gf).sum() if use_flow else 0)
-        l2 = (c0 * G0).sum() + (c1 * G1).sum() + ((f_c * Gf).sum() if use_flow else 0)
+        l1 = (a0 * G0).sum() + (a1 * G1).sum() + (consumers(f_f, f_f2, f_f3) if use_flow else 0)
+        l2 = (c0 * G0).sum() + (c1 * G1).sum() + (consumers(f_c, f_c, f_c) if use_flow else 0)
         g1 = torch.autograd.grad(l1, ins1, retain_graph=True)
         g2 = torch.autograd.grad(l2, ins2, retain_graph=True)
         for x, y in zip(g1, g2):
@@ -152,15 +159,24 @@ def test_warp_pair_acc_folds_in_the_other_consumers_gradient(ops):
     img0, img1 = torch.rand(B, 1, D, H, W, generator=g).to(DEV), torch.rand(B, 1, D, H, W, generator=g).to(DEV)
     flow = ((torch.rand(B, 6, D, H, W, generator=g) * 2 - 1) * 2.0)
     fa, fb = flow.to(DEV).requires_grad_(), flow.to(DEV).requires_grad_()
-    w0, w1, fout = ops.warp_pair_acc(img0, img1, fa)
+    w0, w1, (fout, fout2, fout3) = ops.warp_pair_acc(img0, img1, fa)
     r0, r1 = ops.warp_pair(img0, img1, fb)
-    assert torch.equal(w0, r0) and torch.equal(w1, r1) and torch.equal(fout, fa)
+    assert torch.equal(w0, r0) and torch.equal(w1, r1) and torch.equal(fout, fa) and torch.equal(fout3, fa)
     G0, G1 = torch.randn(w0.shape, generator=g).to(DEV), torch.randn(w1.shape, generator=g).to(DEV)
     Gf = torch.randn(flow.shape, generator=g).to(DEV)
     (ga,) = torch.autograd.grad((w0 * G0).sum() + (w1 * G1).sum() + (fout * Gf).sum() + (fout.square() * 0.5).sum(),
                                 [fa], retain_graph=True)
     (gb,) = torch.autograd.grad((r0 * G0).sum() + (r1 * G1).sum() + (fb * Gf).sum() + (fb.square() * 0.5).sum(),
                                 [fb], retain_graph=True)
+    assert float((ga - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
+    # three consumers through the three aliases; one through torch.cat: its gradient is a channel slice of an
+    # 11-channel tensor and is read in place (batch stride 11 * D*H*W)
+    other = torch.randn(B, 5, D, H, W, generator=g).to(DEV)
+    Gc = torch.randn(B, 11, D, H, W, generator=g).to(DEV)
+    (ga,) = torch.autograd.grad((w0 * G0).sum() + (w1 * G1).sum() + (torch.cat((other, fout), 1) * Gc).sum() +
+                                (fout2 * Gf).sum() + (fout3.square() * 0.5).sum(), [fa], retain_graph=True)
+    (gb,) = torch.autograd.grad((r0 * G0).sum() + (r1 * G1).sum() + (torch.cat((other, fb), 1) * Gc).sum() +
+                                (fb * Gf).sum() + (fb.square() * 0.5).sum(), [fb], retain_graph=True)
     assert float((ga - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
     # each path alone
     (ga,) = torch.autograd.grad((w0 * G0).sum(), [fa], retain_graph=True)
