@@ -558,6 +558,14 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
       if (wide) return launch<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
       return launch<3, 1, 4, 2, 4, 2, 8, 16>(x, ws, bias, y, p, st);
     }
+    // fewer than one 64-channel workgroup per CU (block0's 128-channel layers at 16^3: 64 bricks x 2): 32 output
+    // channels per workgroup instead -- twice the workgroups, half the serial MFMA chain of each
+    const long long small = (long long)B * Do * fs::cdiv(Ho, wide ? 4 : 8) * fs::cdiv(Wo, wide ? 32 : 16) * (p.CoutP / 64);
+    if (small < 256) {
+      if (!wide && Cin % 8 == 0) return launch<3, 1, 8, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);  // 8-channel chunks
+      if (wide) return launch<3, 1, 4, 1, 1, 1, 4, 32>(x, ws, bias, y, p, st);
+      return launch<3, 1, 4, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
+    }
     if (wide) return launch<3, 1, 4, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
     return launch<3, 1, 4, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
   }

@@ -1405,7 +1405,10 @@ def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
     if k == 3:
         mg = cd(Cout, 64)
         big = B * cd(Do, 2) * cd(Ho, 8 * r) * cd(Wo, tw) * mg
-        return big if big >= 512 else B * Do * cd(Ho, 4 * r) * cd(Wo, tw) * mg
+        if big >= 512:
+            return big
+        small = B * Do * cd(Ho, 4 * r) * cd(Wo, tw) * mg
+        return small if small >= 256 else 2 * small  # 32-channel workgroups when 64-channel ones cannot fill the chip
     mg = 1 if Cout <= 32 else cd(Cout, 64)
     return B * Do * cd(Ho, 8 * r) * cd(Wo, tw) * mg
 
