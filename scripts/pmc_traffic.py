@@ -1,0 +1,85 @@
+"""HBM bytes per launch of every C-ABI entry point of the bench step, from two rocprofv3 --pmc passes.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/f -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/w -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline
+    python scripts/pmc_traffic.py <f/..counter_collection.csv> <w/..counter_collection.csv> <bench.json> > profiles/rNN_pmc_traffic.json
+
+Counters are collected in their own passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass);
+both are in KB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests of wide coalesced reads at 64 B), WRITE_SIZE is
+exact for 16-byte streaming stores and float atomics.  A kernel is filed under the entry point that launches it
+(the forward convolution entry point also launches `wprep_kernel`; the three backward-warp entry points share one
+kernel and are told apart by their order inside a step: teacher warp, block 2 (three addends), blocks 1 and 0
+(fused up-sampling)).  Only the LAST step of each pass is used (the first steps contain MIOpen find kernels).
+`algorithmic_bytes` per launch = algo_GBps x avg_ms of the bench line (the figures ops.py supplies).
+"""
+import collections
+import csv
+import json
+import sys
+
+RULES = [  # (substring of the kernel name, entry point, counts as a launch of the entry point)
+    ("conv3d_fwd_kernel", "fs_conv3d_fwd", True), ("conv3d_fwd_ws_kernel", "fs_conv3d_fwd", True),
+    ("wprep_kernel", "fs_conv3d_fwd", False),
+    ("conv3d_wrw_", "fs_conv3d_wrw", True),
+    ("convtr_", "fs_conv3d_tr", True), ("wprep_tr", "fs_conv3d_tr", False),
+    ("warp3d_fwd_kernel<512, true, true>", "fs_upsample_warp3d_pair_fwd", True),
+    ("warp3d_fwd_kernel<512, true, false>", "fs_warp3d_pair_fwd", True),
+    ("prelu_bwd_kernel", "fs_prelu_bwd", True), ("prelu_ga_kernel", "fs_prelu_bwd", False),
+    ("merge_fwd_kernel", "fs_merge_fwd", True), ("merge_bwd_kernel", "fs_merge_bwd", True),
+    ("distill3_fwd_kernel", "fs_distill3_fwd", True), ("distill3_bwd_kernel", "fs_distill3_bwd", True),
+]
+WARP_BWD_ORDER = ["fs_warp3d_pair_bwd", "fs_warp3d_pair_bwd_acc3", "fs_upsample_warp3d_pair_bwd3",
+                  "fs_upsample_warp3d_pair_bwd3"]
+
+
+def last_step(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    ends = [i for i, r in enumerate(rows) if "multi_tensor" in r["Kernel_Name"]]  # fused AdamW ends a step
+    marks, prev = [], None
+    for i in ends:
+        if prev is None or i - prev > 50:
+            marks.append(i)
+        prev = i
+    seg = rows[marks[-2]:marks[-1]] if len(marks) >= 2 else rows
+    out = collections.defaultdict(lambda: [0.0, 0])
+    nwarp = 0
+    for r in seg:
+        name, val = r["Kernel_Name"], float(r["Counter_Value"])
+        if "warp3d_bwd_kernel" in name:
+            ep = WARP_BWD_ORDER[nwarp % 4]
+            nwarp += 1
+            out[ep][0] += val
+            out[ep][1] += 1
+            continue
+        for sub, ep, counts in RULES:
+            if sub in name:
+                out[ep][0] += val
+                out[ep][1] += 1 if counts else 0
+                break
+    return out
+
+
+def main():
+    fetch = last_step(sys.argv[1], "FETCH_SIZE")
+    write = last_step(sys.argv[2], "WRITE_SIZE")
+    bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    kern = {}
+    for ep in sorted(set(fetch) | set(write)):
+        n = max(fetch[ep][1], write[ep][1], 1)
+        f_kb, w_kb = fetch[ep][0] / n, write[ep][0] / n
+        rec = {"launches_per_step": n, "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
+               "hbm_bytes_corrected": (2.0 * f_kb + w_kb) * 1024.0}
+        b = bench.get("kernels", {}).get(ep)
+        if b:
+            rec["algorithmic_bytes"] = b["algo_GBps"] * 1e9 * b["avg_ms"] * 1e-3
+            rec["ratio"] = round(rec["hbm_bytes_corrected"] / rec["algorithmic_bytes"], 3)
+        kern[ep] = rec
+    json.dump({"workload": "bench.py default: %s; per launch of the entry point, last step of each pass"
+               % bench["config"]["workload"],
+               "correction": "FETCH_SIZE x2 (gfx950 half-count of wide coalesced reads), WRITE_SIZE x1, KB units",
+               "kernels": kern}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
