@@ -9,6 +9,7 @@ Usage (each group imports a different reference package layout, so one process p
     python tests/golden/make_golden.py flow3d_e2e   # Flow-3D Model.update / inference
     python tests/golden/make_golden.py flow2d_e2e   # Flow-2D Model.update / inference
     python tests/golden/make_golden.py upflow_e2e   # UPFlow_net forward losses / flows / grads
+    python tests/golden/make_golden.py upflow_levels  # per pyramid level: decode_level_res inputs / outputs / grads
     python tests/golden/make_golden.py rife_next    # Flow-2D LapLoss
     python tests/golden/make_golden.py upflow_next  # occ_check_model, normalize_features
     python tests/golden/make_golden.py ckpt         # Model.save_model / load_model on-disk format
@@ -324,6 +325,91 @@ def upflow_e2e():
 
 
 # ------------------------------------------------------------------------------------------
+def _proj(t, seed):
+    """Two numbers that pin a gradient tensor without storing it: its dot product with a seeded Gaussian
+    tensor of the same shape, and its absolute sum."""
+    if t is None:
+        return np.array([0.0, 0.0])
+    R = torch.randn(t.shape, generator=torch.Generator().manual_seed(seed))
+    return np.array([float((t.double() * R.double()).sum()), float(t.double().abs().sum())])
+
+
+def upflow_levels():
+    """Teacher-forcing fixture: for every pyramid level of one reference forward pass, the
+    inputs the reference fed to `decode_level_res` (UPFlow/model/upflow.py:621-663), the two warped feature maps
+    its `warping_layer` produced (the fp32-borderline validity-mask decisions included), its four outputs, and
+    -- for the cotangents G1, G2 = seeded Gaussians on the two residual flows -- projections of the gradients
+    w.r.t. every level input and every parameter of the estimator / context networks."""
+    _install_stubs()
+    sys.path[:0] = [REF + "/UPFlow"]
+    import model.upflow as U
+    U.device = torch.device("cpu")
+    conf = U.UPFlow_net.config()
+    _quiet(conf.update, {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+                         'norm_moments_across_images': False, 'if_use_cor_pytorch': True,
+                         'if_sgu_upsample': False, 'photo_loss_census_weight': 1,
+                         'multi_scale_distillation_weight': 1})
+    torch.manual_seed(0)
+    net = _quiet(conf)
+    gen = torch.Generator().manual_seed(4)
+    H, W = 128, 192
+    base = torch.nn.functional.interpolate(torch.rand(1, 3, H // 8, W // 8 + 2, generator=gen), size=(H, W + 16),
+                                           mode="bicubic", align_corners=True).clamp(0, 1)
+    im1, im2 = base[:, :, :, :W].contiguous(), base[:, :, :, 3:W + 3].contiguous()
+    store = dict(im1=_np(im1), im2=_np(im2))
+    store["param_sums"] = np.array([float(p.detach().double().sum()) for p in net.parameters()])
+    pnames = [n for n, _ in net.named_parameters() if n.startswith(("flow_estimators.", "context_networks."))]
+    store["param_names"] = np.array(pnames)
+    params = dict(net.named_parameters())
+    orig_decode = net.decode_level_res
+    orig_warp = net.warping_layer.forward
+    names = ["flow_1", "flow_2", "feature_1", "feature_1_1x1", "feature_2", "feature_2_1x1"]
+
+    def decode(level, flow_1, flow_2, feature_1, feature_1_1x1, feature_2, feature_2_1x1, img_ori_1, img_ori_2):
+        ins = [t.detach().clone().requires_grad_() for t in (flow_1, flow_2, feature_1, feature_1_1x1, feature_2,
+                                                              feature_2_1x1)]
+        warped = []
+
+        def warp(x, flow):
+            out = orig_warp(x, flow)
+            warped.append(out)
+            return out
+
+        net.warping_layer.forward = warp
+        try:
+            outs = orig_decode(level=level, flow_1=ins[0], flow_2=ins[1], feature_1=ins[2], feature_1_1x1=ins[3],
+                               feature_2=ins[4], feature_2_1x1=ins[5], img_ori_1=img_ori_1, img_ori_2=img_ori_2)
+        finally:
+            net.warping_layer.forward = orig_warp
+        tag = "L%d_" % level
+        for n, t in zip(names, ins):
+            store[tag + n] = _np(t)
+        for n, t in zip(["flow_1_up", "flow_2_up", "res_1", "res_2"], outs):
+            store[tag + "out_" + n] = _np(t)
+        if warped:
+            store[tag + "feature_2_warp"] = _np(warped[0])
+            store[tag + "feature_1_warp"] = _np(warped[1])
+        G1 = torch.randn(outs[2].shape, generator=torch.Generator().manual_seed(100 + level))
+        G2 = torch.randn(outs[3].shape, generator=torch.Generator().manual_seed(200 + level))
+        loss = (outs[2] * G1).sum() + (outs[3] * G2).sum()
+        wrt = ins + [params[n] for n in pnames]
+        grads = torch.autograd.grad(loss, wrt, allow_unused=True)
+        store[tag + "gin"] = np.stack([_proj(g, 300 + 10 * level + i) for i, g in enumerate(grads[:6])])
+        store[tag + "gparam"] = np.stack([_proj(g, 1000 + i) for i, g in enumerate(grads[6:])])
+        return tuple(t.detach() for t in outs)
+
+    net.decode_level_res = decode
+    with torch.no_grad():
+        pass
+    flow_f, flow_b, flows = _quiet(net.forward_2_frame_v3, im1, im2)
+    store["flow_f_out"] = _np(flow_f)
+    store["nlevels"] = np.int64(len(flows))
+    np.savez_compressed(os.path.join(OUT, "upflow_levels.npz"), **store)
+    print("wrote upflow_levels.npz:", len(flows), "levels,", len(store), "arrays,",
+          os.path.getsize(os.path.join(OUT, "upflow_levels.npz")) // 1024, "KB")
+
+
+# ------------------------------------------------------------------------------------------
 def rife_next():
     """the Flow-2D Laplacian-pyramid loss (Flow-2D/model/laplacian.py)."""
     lap = _load_file("ref_lap2d", REF + "/Flow-2D/model/laplacian.py")
@@ -440,7 +526,7 @@ def ckpt():
 
 
 GROUPS = dict(ckpt=ckpt, rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
-              upflow_e2e=upflow_e2e)
+              upflow_e2e=upflow_e2e, upflow_levels=upflow_levels)
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
