@@ -15,8 +15,11 @@ import os as _os
 # kernels, csrc/conv{fwd,tr,wrw}.hip; for the 2-D nets the igemm / Winograd solvers are picked with
 # or without them: C2 13.6 ms and C3 88 ms per step either way).  The package's entry points must
 # start in bounded time, so the naive solvers are taken out of the search unless the user has already
-# chosen otherwise.
-for _k in ("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD",
-           "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW"):
-    _os.environ.setdefault(_k, "0")
-del _k
+# chosen otherwise.  This is PROCESS-WIDE (it changes MIOpen's solver search for every model in the process):
+# `FLOWSCI_KEEP_MIOPEN_DEFAULTS=1` in the environment before the import leaves MIOpen untouched, and any of the
+# three variables set by the user wins.
+if _os.environ.get("FLOWSCI_KEEP_MIOPEN_DEFAULTS") != "1":
+    for _k in ("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD",
+               "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW"):
+        _os.environ.setdefault(_k, "0")
+    del _k

@@ -96,7 +96,13 @@ class ModelBase:
         the ~660 launches' CPU cost and the gaps between short kernels.  Single-process models only
         (capturing through DDP's reducer needs its own warm-up protocol and is not attempted).
         Model2D keeps the reference's per-step host check of the distillation loss (RIFE.py:295) and is
-        therefore not capturable."""
+        therefore not capturable.
+
+        Side effects on the optimiser, which outlive the returned `step` (graph capture needs device-resident
+        optimiser scalars): every param group becomes `capturable=True`, its `'lr'` a 0-dim device tensor and
+        the AdamW step counters device tensors.  Later eager `update()` calls keep working (they write the new
+        rate into that tensor), but code that reads `param_group['lr']` as a Python float -- schedulers,
+        loggers, `state_dict()` consumers -- now receives a tensor: use `float(group['lr'])`."""
         if self.dev.type != "cuda":
             raise RuntimeError("HIP graphs need a GPU")
         if isinstance(self.flownet, DDP):
