@@ -616,6 +616,291 @@ __global__ __launch_bounds__(512, 2) void convtr_mfma16_ws_kernel(const float* _
   }
 }
 
+// ---- 4..8 output channels (the 6-channel flow head): v_mfma_f32_16x16x4_f32 with the x parity in the rows ------
+// Padding 6 channels to a 16-row tile wastes 10 rows; but the two x parities of an output row can share one B
+// operand if they are paired across neighbouring positions: output x = 2q (parity 0 of input position q: taps
+// (q, kx 1), (q-1, kx 3)) and output x = 2q - 1 (parity 1 of position q-1: taps (q, kx 0), (q-1, kx 2)) both read
+// inputs q and q-1 only.  Rows 0..7 = channels of x = 2q, rows 8..15 = channels of x = 2q - 1: 12 of 16 rows
+// useful for 6 channels (75 %, against 37.5 % for a channels-only tile and 28 % measured on the vector ALUs).
+// Positions run over q = 0..Wi (Wi + 1 of them: the last odd output comes from q = Wi).  Per (z, y) parity class
+// and tap pair there are two MFMAs per 4-channel chunk and 16-position tile (dx = 0, -1).  The re-laid-out weights
+// W'[ci][kz*4+ky][dx][row] of ALL input channels stay in LDS (64 KB for 32 channels); the loader waves stream only
+// the input bricks (4 channels x 4 x 4 rows x 136 floats per chunk).  A matrix wave owns one (z, y) row of the 2x2
+// brick and up to 9 position tiles of it: 4 classes x 9 tiles x 4 accumulator registers.
+constexpr int PX16_WS = 512 + 16;
+
+__global__ __launch_bounds__(256) void wprep_px16_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin,
+                                                         int Cout, int CinP) {
+  const int total = CinP * PX16_WS;  // per input channel: 512 entries + 16 floats of padding (LDS bank spread)
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int ci = e / PX16_WS, i = e - ci * PX16_WS;
+    const int row = i & 15, dxi = (i >> 4) & 1, kzky = (i >> 5) & 15;
+    const int px = row >> 3, co = row & 7;
+    const int kx = px == 0 ? (dxi == 0 ? 1 : 3) : (dxi == 0 ? 0 : 2);
+    wt[e] = (i < 512 && co < Cout && ci < Cin) ? w[((size_t)ci * Cout + co) * 64 + kzky * 4 + kx] : 0.f;
+  }
+}
+
+#ifdef FS_TR_STAMPS
+__device__ unsigned long long fs_tr_dbg[4 * 8];
+#define TSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dt[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
+// NT position tiles per wave: an x brick is 16 (NT - 1) positions plus one more tile that only the LAST brick of a row
+// needs (q = Wi); NT is a compile-time constant so that a chunk is straight-line code (with a run-time tile count
+// the compiler waited for every operand prefetch right where it was issued and shuffled the two operand sets
+// through 20 moves per tile: 40 instead of 32 cycles per MFMA)
+template <int CINP, int NT>
+__global__ __launch_bounds__(512, 2) void convtr_px16_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                          const float* __restrict__ bias, float* __restrict__ Y,
+                                                          TP p, int per) {
+  constexpr int CI = 4, NTMAX = NT, XB = 16 * (NT - 1);  // channels per chunk, tiles per wave, positions per x brick
+  constexpr int ZT = 4, YT = 4, XP = XB + 8 + 8;      // 2x2 rows + halo; row = [q0 - 4, q0 + XB + 12)
+  constexpr int PS = YT * XP, CHS = ZT * PS + 16;      // + 16: the two channel groups of a half-wave read different banks
+  constexpr int NX = CI * CHS;                         // 8768 floats = 35 pieces
+  constexpr int NXL = (NX + 255) / 256 * 256;
+  constexpr int NW = CINP * PX16_WS;                   // whole weight table
+  constexpr int NWL = (NW + 255) / 256 * 256;
+  static_assert((NWL + 2 * NXL) * 4 <= 160 * 1024, "weights + two input buffers fit the CU's LDS");
+  __shared__ __attribute__((aligned(16))) float lds[NWL + 2 * NXL];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wv = wave & 3;
+  // persistent: this workgroup owns the bricks [t0, t1) (a contiguous range: neighbouring bricks share halo rows in
+  // the XCD's L2); the loader waves run one (brick, chunk) item ahead of the matrix waves across brick boundaries,
+  // so a brick's epilogue stores overlap the next brick's first loads and the weight table is loaded once
+  const long long t0 = (long long)blockIdx.x * per, t1 = min(t0 + per, p.tiles);
+  const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
+  auto decode = [&](long long tile, int& b, int& qz0, int& qy0, int& q0) {
+    const int txi = (int)(tile % p.tx); tile /= p.tx;
+    const int tyi = (int)(tile % p.ty); tile /= p.ty;
+    const int tzi = (int)(tile % p.tz);
+    b = (int)(tile / p.tz);
+    qz0 = tzi * 2; qy0 = tyi * 2; q0 = txi * XB;
+  };
+
+  if (wave >= 4) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
+    constexpr int NXW = (NXL / 256 + 3) / 4, NWW = (NWL / 256 + 3) / 4;
+    {  // the whole weight table, once
+      __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, (short)0, NW * 4, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < NWW; ++k)
+        if (256 * (wv + 4 * k) < NWL)  // wave-uniform
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + 256 * (wv + 4 * k)), 16,
+                                                   (unsigned)(256 * (wv + 4 * k) + 4 * lane) * 4u, 0, 0, 0);
+    }
+    unsigned xoff[NXW];
+    int b = 0;
+    auto offsets = [&](long long tile) {
+      int qz0, qy0, q0;
+      decode(tile, b, qz0, qy0, q0);
+#pragma unroll
+      for (int k = 0; k < NXW; ++k) {
+        const int i = 256 * (wv + 4 * k) + 4 * lane;
+        const int c = i / CHS, r1 = i - c * CHS;
+        const int z = r1 / PS, r2 = r1 - z * PS;
+        const int y = r2 / XP, x = r2 - y * XP;
+        const int gz = qz0 - 1 + z, gy = qy0 - 1 + y, gx = q0 - 4 + x;
+        const bool ok = i < NX && z < ZT && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+        xoff[k] = ok ? ((unsigned)c * (unsigned)xvol + ((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u : DMA_OOB;
+      }
+    };
+    auto stage = [&](int c0, int buf) {
+      const int nch = (p.Cin - c0 < CI) ? (p.Cin - c0) : CI;  // channels past Cin read as zero
+      __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(X + ((size_t)b * p.Cin + c0) * xvol), (short)0, (int)((unsigned)nch * (unsigned)xvol * 4u), 0x00020000);
+      float* base = lds + NWL + buf * NXL;
+#pragma unroll
+      for (int k = 0; k < NXW; ++k)
+        if (256 * (wv + 4 * k) < NXL)  // wave-uniform
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + 256 * (wv + 4 * k)), 16, xoff[k], 0, 0, 0);
+    };
+    int buf = 0;
+    if (t0 < t1) {
+      offsets(t0);
+      stage(0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // weights and the first item have landed
+    for (long long tile = t0; tile < t1; ++tile) {
+      for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+        // stage the NEXT item of the (brick, chunk) stream
+        if (c0 + CI < p.Cin) {
+          stage(c0 + CI, buf ^ 1);
+        } else if (tile + 1 < t1) {
+          offsets(tile + 1);
+          stage(0, buf ^ 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+      }
+    }
+#else
+    (void)xvol;
+#endif
+    return;
+  }
+
+  // ---- matrix waves
+  const int col = lane & 15, kq = lane >> 4;
+  const int wz = wv >> 1, wy = wv & 1;
+  const int bBo = NWL + kq * CHS + (wz + 1) * PS + (wy + 1) * XP + (col + 4);
+  __builtin_amdgcn_s_barrier();  // weights and the first item have landed
+  int buf = 0;
+#ifdef FS_TR_STAMPS
+  unsigned long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+  for (long long tile = t0; tile < t1; ++tile) {
+    int b, qz0, qy0, q0;
+    decode(tile, b, qz0, qy0, q0);
+    // positions of this x brick that are stored: [q0, q0 + XB), plus q = Wi in the last brick of the row (the last
+    // odd output column); the tiles beyond are computed on zeros / the neighbour's columns and dropped
+    const int qend = (q0 + XB >= p.Wi) ? p.Wi + 1 : q0 + XB;
+    f32x4 acc[4][NTMAX];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int n = 0; n < NTMAX; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[c][n][r] = 0.f;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+      // A operands of the chunk: W'[c0 + kq][kz*4+ky][dx][row = lane & 15], one per (class, tap pair, dx)
+      const float* aB = lds + (size_t)(c0 + kq) * PX16_WS + col;
+      float av[4][4][2];  // [class][tap pair][dx]
+#pragma unroll
+      for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+          for (int dxi = 0; dxi < 2; ++dxi) {
+            const int pz = cls >> 1, py = cls & 1, a = tp >> 1, bb = tp & 1;
+            av[cls][tp][dxi] = aB[((tap_k(pz, a) * 4 + tap_k(py, bb)) * 2 + dxi) * 16];
+          }
+      const float* bB = lds + bBo + buf * NXL;
+      // B operands: the 3 x 3 x 2 neighbourhood of every position tile, read one tile ahead of the MFMAs that
+      // use it (with all 36 accumulator tiles live there is exactly room for two sets)
+      float xa[3][3][2], xb[3][3][2];
+      auto load_x = [&](int n, float (&xn)[3][3][2]) {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dxi = 0; dxi < 2; ++dxi) xn[dz][dy][dxi] = bB[16 * n + (dz - 1) * PS + (dy - 1) * XP - dxi];
+      };
+      auto mma_tile = [&](int n, const float (&xn)[3][3][2]) {
+        // tap-major: consecutive MFMAs go to different accumulators (40-cycle dependent latency, 32-cycle issue)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+          for (int dxi = 0; dxi < 2; ++dxi)
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls) {
+              const int pz = cls >> 1, py = cls & 1, a = tp >> 1, bb = tp & 1;
+              acc[cls][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cls][tp][dxi],
+                                                                  xn[tap_d(pz, a) + 1][tap_d(py, bb) + 1][dxi],
+                                                                  acc[cls][n], 0, 0, 0);
+            }
+      };
+      load_x(0, xa);
+#pragma unroll
+      for (int n = 0; n < NTMAX; n += 2) {
+        if (n + 1 < NTMAX) load_x(n + 1, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(n, xa);
+        if (n + 1 < NTMAX) {
+          if (n + 2 < NTMAX) load_x(n + 2, xa);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_tile(n + 1, xb);
+        }
+      }
+      TSTAMP(0);
+      __builtin_amdgcn_s_barrier();  // the next item has landed, everyone is done reading `buf`
+      TSTAMP(1);
+      buf ^= 1;
+    }
+
+    // D row = 4 kq + r: x parity = kq >> 1 (0: x = 2q, 1: x = 2q - 1), channel = 4 (kq & 1) + r; column = position.
+    // The epilogue is store-ISSUE-bound (s_memtime stamps: ~75 cycles per store wave-instruction and CU whatever
+    // its width -- 144 dword stores per lane were 30 % of a brick's time), so the stores are made as wide as the
+    // layout allows: (1) one v_permlane32_swap per register pair (r, r + 2) brings both x parities of a channel into
+    // one lane -- lanes 0-31 hold (x = 2q - 1, x = 2q) of channel 4 (kq & 1) + r, lanes 32-63 the same for r + 2;
+    // (2) neighbouring lanes swap one (odd, even) pair (DPP quad_perm [1,0,3,2]): an even lane ends up with the four
+    // consecutive outputs 2q - 1 .. 2q + 2 of the y-parity-0 row, its odd neighbour with 2q - 3 .. 2q of the
+    // y-parity-1 row: one 16-byte store per lane and two classes, 36 per lane and brick.
+    const int qz = qz0 + wz, qy = qy0 + wy;
+    if (qz < p.Di && qy < p.Hi) {
+      const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
+      const int hi = lane >> 5;
+      const bool evn = (col & 1) == 0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int co = 4 * (kq & 1) + r + 2 * hi;
+        const bool cok = co < p.Cout;
+        const float bv = (bias && cok) ? bias[co] : 0.f;
+        float* __restrict__ yc = Y + ((size_t)b * p.Cout + (cok ? co : 0)) * yvol;
+        const float* __restrict__ ac = p.addend ? p.addend + ((size_t)b * p.Cout + (cok ? co : 0)) * yvol : nullptr;
+#pragma unroll
+        for (int n = 0; n < NTMAX; ++n) {
+          const int q = q0 + 16 * n + col;
+#pragma unroll
+          for (int pz = 0; pz < 2; ++pz) {
+            // classes (pz, py = 0) and (pz, py = 1): output rows y = 2 qy and 2 qy + 1
+            const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[2 * pz][n][r]),
+                                                             __float_as_uint(acc[2 * pz][n][r + 2]), false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[2 * pz + 1][n][r]),
+                                                             __float_as_uint(acc[2 * pz + 1][n][r + 2]), false, false);
+            // s*[0] = x 2q (even), s*[1] = x 2q - 1 (odd).  Keep the class of this lane's parity, send the other
+            const unsigned keep_e = evn ? s0[0] : s1[0], keep_o = evn ? s0[1] : s1[1];
+            const unsigned send_e = evn ? s1[0] : s0[0], send_o = evn ? s1[1] : s0[1];
+            const float re = __uint_as_float(__builtin_amdgcn_update_dpp(0u, send_e, 0xB1, 0xF, 0xF, false)) + bv;
+            const float ro = __uint_as_float(__builtin_amdgcn_update_dpp(0u, send_o, 0xB1, 0xF, 0xF, false)) + bv;
+            const float ke = __uint_as_float(keep_e) + bv, ko = __uint_as_float(keep_o) + bv;
+            // even lane: x = 2q - 1 .. 2q + 2 of row py = 0;  odd lane: x = 2q - 3 .. 2q of row py = 1
+            const int qa = evn ? q : q - 1;                   // first of the two positions in this lane's quad
+            float4 v = evn ? make_float4(ko, ke, ro, re) : make_float4(ro, re, ko, ke);
+            if (cok) {
+              float* row = yc + ((size_t)(2 * qz + pz) * p.Hout + (2 * qy + (evn ? 0 : 1))) * p.Wout;
+              const float* arow = ac ? ac + (row - yc) : nullptr;
+              const int x0 = 2 * qa - 1;                      // outputs x0 .. x0 + 3 <- positions qa, qa, qa + 1, qa + 1
+              // output x is stored iff its position is < qend and 0 <= x < Wout
+              const bool full = qa >= 1 && qa + 1 < qend && x0 + 3 < p.Wout;
+              if (full) {
+                if (arow) {
+                  const float4 a4 = *reinterpret_cast<const float4*>(arow + x0);
+                  v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                }
+                *reinterpret_cast<float4*>(row + x0) = v;      // 4-byte aligned 16-byte store
+              } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const int x = x0 + e, pos = qa + (e >> 1);
+                  if (pos >= 0 && pos < qend && x >= 0 && x < p.Wout) row[x] = vv[e] + (arow ? arow[x] : 0.f);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    TSTAMP(2);
+  }
+#ifdef FS_TR_STAMPS
+  if (blockIdx.x == 3 && lane == 0) {
+    for (int i = 0; i < 8; ++i) fs_tr_dbg[wv * 8 + i] = dt[i];
+    fs_tr_dbg[wv * 8 + 7] = (unsigned long long)(t1 - t0);
+  }
+#endif
+}
+
 // NP input-grid positions (consecutive qy) per thread: every scalar-loaded weight feeds NP FMAs.  The
 // kernel is bound by the scalar weight stream (64*CO dwords per input channel and wave through ~100
 // SGPRs), not by the vector ALUs or the address path -- packed FMAs / an LDS-staged input brick did not
@@ -705,9 +990,16 @@ void launch_valu(const float* x, const float* w, const float* bias, float* y, co
 
 }  // namespace
 
+#ifdef FS_TR_STAMPS
+extern "C" int fs_debug_tr_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs_tr_dbg), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   if (Cin < 1 || Cout < 1 || Cout > 32) return -1;
-  if (Cout <= 6) return 0;
+  if (Cout < 4) return 0;
+  if (Cout <= 6) return (long long)((Cin + 3) / 4 * 4) * PX16_WS;  // W'[ci][kz*4+ky][dx][row] (+ pad) of the px16 kernel
   return (long long)((Cin + 3) / 4 * 4) * 64 * (Cout <= 16 ? 16 : 32);
 }
 
@@ -733,6 +1025,34 @@ static int conv3d_tr_impl(const float* x, const float* w, const float* bias, con
   p.addend = addend; p.Ybase = y;
   hipStream_t st = (hipStream_t)stream;
   if ((long long)B * p.Dq * p.Hq * p.Wq >= (1ll << 31) * 256) return FS_ERR_SHAPE;
+  static const bool reg_only = getenv("FLOWSCI_TR_REG") != nullptr;
+  if (Cout >= 4 && Cout <= 6 && !reg_only && z == nullptr && ws != nullptr && Cin <= 32 && Dout == 2 * Di &&
+      Hout == 2 * Hi && Wout == 2 * Wi && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 &&
+      (long long)4 * Di * Hi * Wi * 4 < (1ll << 31)) {
+    // the x-parity-in-rows MFMA kernel: 2x2 rows x 128 positions per workgroup
+    const bool wide = Wi > 64;  // 128- or 64-position x bricks
+    p.tz = fs::cdiv(Di, 2); p.ty = fs::cdiv(Hi, 2); p.tx = fs::cdiv(Wi, wide ? 128 : 64);
+    p.tiles = (long long)B * p.tz * p.ty * p.tx;
+    if (p.tiles >= 16 && p.tiles < (1ll << 31)) {
+      const int cinp = (Cin + 3) / 4 * 4;
+      hipLaunchKernelGGL(wprep_px16_kernel, dim3((cinp * PX16_WS + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout, cinp);
+      static int ncu = 0;  // one persistent workgroup per CU
+      if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+          n = 256;
+        ncu = n;
+      }
+      const long long nwg = p.tiles < ncu ? p.tiles : ncu;
+      const int per = (int)((p.tiles + nwg - 1) / nwg);
+      const unsigned grid = (unsigned)((p.tiles + per - 1) / per);
+      if (wide) hipLaunchKernelGGL((convtr_px16_kernel<32, 9>), dim3(grid), dim3(512), 0, st, x, ws, bias, y, p, per);
+      else hipLaunchKernelGGL((convtr_px16_kernel<32, 5>), dim3(grid), dim3(512), 0, st, x, ws, bias, y, p, per);
+      FS_LAUNCH_CHECK();
+      return FS_OK;
+    }
+  }
   if (Cout <= 6) {
     if (Cout == 1) launch_valu<1>(x, w, bias, y, p, st);
     else if (Cout <= 2) launch_valu<2>(x, w, bias, y, p, st);
@@ -748,7 +1068,6 @@ static int conv3d_tr_impl(const float* x, const float* w, const float* bias, con
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
   // loader-wave kernels: 16-byte pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets
   // inside a staged 4-channel chunk, at least two bricks per CU.  `FLOWSCI_TR_REG=1`: the register-staged kernels.
-  static const bool reg_only = getenv("FLOWSCI_TR_REG") != nullptr;
   const bool ws_ok = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && p.tiles >= 512 &&
                      (long long)4 * Di * Hi * Wi * 4 < (1ll << 31);
   if (Cout <= 16) {

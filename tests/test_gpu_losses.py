@@ -265,6 +265,8 @@ def test_corr3d_vs_oracle(ops, shape, md):
     dict(cin=12, cout=32, k=4, s=2, size=(6, 10, 136), tr=False),   # k4, 32 G channels, 6-channel chunks (teacher conv0)
     dict(cin=64, cout=32, k=4, s=2, size=(3, 5, 36), tr=True),      # deconv: G = the layer input
     dict(cin=32, cout=6, k=4, s=2, size=(5, 6, 40), tr=True),       # flow head through the 6-channel chunk kernel
+    dict(cin=30, cout=5, k=4, s=2, size=(5, 7, 132), tr=True),      # x-parity-in-rows MFMA head: two x bricks, ragged rows / channels
+    dict(cin=8, cout=4, k=4, s=2, size=(6, 6, 128), tr=True),       # ... exactly one x brick + the q = Wi column
     dict(cin=24, cout=72, k=3, s=1, size=(5, 7, 68), tr=False),     # k3: Cg = 72 (two M groups, ragged), Cs = 24 (ragged chunk)
 ])
 def test_conv3d_wrw_mfma_vs_autograd(ops, cfg):
