@@ -1,4 +1,4 @@
-"""Where one brick of the x-parity-in-rows flow-head kernel (convtr_px16_kernel) spends its cycles: s_memtime stamps of
+"""Where one brick of the parities-in-rows heads kernel (convtr_p8_kernel) spends its cycles: s_memtime stamps of
 the matrix waves (library built with -DFS_TR_STAMPS; csrc/convtr.hip).  GPU box only."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -267,6 +267,8 @@ def test_corr3d_vs_oracle(ops, shape, md):
     dict(cin=32, cout=6, k=4, s=2, size=(5, 6, 40), tr=True),       # flow head through the 6-channel chunk kernel
     dict(cin=30, cout=5, k=4, s=2, size=(5, 7, 132), tr=True),      # x-parity-in-rows MFMA head: two x bricks, ragged rows / channels
     dict(cin=8, cout=4, k=4, s=2, size=(6, 6, 128), tr=True),       # ... exactly one x brick + the q = Wi column
+    dict(cin=20, cout=1, k=4, s=2, size=(5, 6, 72), tr=True),       # mask head: 8 parity rows of one 16-row tile
+    dict(cin=12, cout=32, k=4, s=2, size=(10, 12, 136), tr=False),  # its input gradient: 12 channels x 8 parities = 6 row tiles
     dict(cin=24, cout=72, k=3, s=1, size=(5, 7, 68), tr=False),     # k3: Cg = 72 (two M groups, ragged), Cs = 24 (ragged chunk)
 ])
 def test_conv3d_wrw_mfma_vs_autograd(ops, cfg):
@@ -282,13 +284,16 @@ def test_conv3d_wrw_mfma_vs_autograd(ops, cfg):
     xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
     yr = fn(xr, wr, None, s3, p3)
     G = torch.randn(yr.shape, generator=g)
-    (gw_ref,) = torch.autograd.grad((yr * G.double()).sum(), [wr])
+    gx_ref, gw_ref = torch.autograd.grad((yr * G.double()).sum(), [xr, wr])
     xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
     y = convgrad._ConvFn.apply(xd, wd, None, s3, p3, cfg["tr"])
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-5 * float(yr.abs().max())
     gx, gw = torch.autograd.grad((y * G.to(DEV)).sum(), [xd, wd])
     scale = float(gw_ref.abs().max())
     assert gw.shape == gw_ref.shape
     assert float((gw.cpu().double() - gw_ref).abs().max()) < 2e-5 * scale
+    # the input gradient goes through fs_conv3d_tr (k4 s2 convolutions) / fs_conv3d_fwd (the others)
+    assert float((gx.cpu().double() - gx_ref).abs().max()) < 2e-5 * float(gx_ref.abs().max())
 
 
 def test_laploss2d_golden(ops, golden):
