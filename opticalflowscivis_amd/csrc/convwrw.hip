@@ -320,7 +320,9 @@ __device__ unsigned long long fs_wrw_dbg[4 * 8];
 
 constexpr int up4(int n) { return (n + 3) / 4 * 4; }
 
-template <int K, int S, int NC, int MT, int TZ, int TY, int FULL, int HALF>
+// KWX = x extent of a brick (32, or 16 for layers with 16 output columns: a 32-element reduction row is then two
+// consecutive y rows of 16, which are contiguous in G when Wo == 16); TY counts 32-element rows per z slice
+template <int K, int S, int NC, int MT, int TZ, int TY, int FULL, int HALF, int KWX = 32>
 __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __restrict__ G,
                                                              const float* __restrict__ Src,
                                                              float* __restrict__ dW, WB p) {
@@ -331,9 +333,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
   static_assert(HALF == 0 || MT == 2, "a shared column tile is split by row tile");
   constexpr int NB = FULL + HALF;  // B operands per reduction pair
   constexpr int ROWS = TZ * TY;
-  constexpr int ZT = (TZ - 1) * S + K, YT = (TY - 1) * S + K;
+  static_assert(KWX == 32 || KWX == 16, "brick x extent");
+  constexpr int YR = KW / KWX;                           // y rows per 32-element reduction row
+  constexpr int TYB = TY * YR;                           // y rows of the brick
+  constexpr int ZT = (TZ - 1) * S + K, YT = (TYB - 1) * S + K;
   constexpr int XL = 4;                                  // floats between the row start and output column 0's tap 0 + pad
-  constexpr int XP = up4(XL + (KW - 1) * S + K);         // row pitch = staged row length (the pad shifts taps, not rows)
+  constexpr int XP = up4(XL + (KWX - 1) * S + K);        // row pitch = staged row length (the pad shifts taps, not rows)
   constexpr int PSP = YT * XP, CHSP = ZT * PSP;
   constexpr int GP = ROWS * KW + 4;
   constexpr int NGF = 32 * MT * GP;                      // floats of the G image
@@ -364,8 +369,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
     // source image: byte offset from the brick origin and border class (bit 0/1: low / high z halo, 2/3: y,
     // 4/5: x); pad slots and channels past Cs are permanently out of range
     unsigned soff[NSW], scls[NSW];
-    const int zhi = p.Di + p.pad - (p.bz - 1) * TZ * S, yhi = p.Hi + p.pad - (p.by - 1) * TY * S,
-              xhi = p.Wi + XL - (p.bx - 1) * KW * S;  // first invalid brick coordinate in the LAST brick of an axis
+    const int zhi = p.Di + p.pad - (p.bz - 1) * TZ * S, yhi = p.Hi + p.pad - (p.by - 1) * TYB * S,
+              xhi = p.Wi + XL - (p.bx - 1) * KWX * S;  // first invalid brick coordinate in the LAST brick of an axis
 #pragma unroll
     for (int k = 0; k < NSW; ++k) {
       const int q = 256 * (wv + 4 * k) + 4 * lane;
@@ -384,12 +389,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
     for (int k = 0; k < NGW; ++k) {
       const int f = 256 * (wv + 4 * k) + 4 * lane;
       const int r = f / GP, w = f - r * GP;
-      const int row = w / KW, col = w % KW;
+      const int row = w / KW, e = w % KW;
+      const int rz = row / TY, ry = (row % TY) * YR + e / KWX, col = e % KWX;
       const bool ok = f < NGF && w < ROWS * KW && g0 + r < p.Cg;
-      goff[k] = ok ? ((unsigned)r * (unsigned)gvol + (unsigned)(((row / TY) * p.Ho + (row % TY)) * p.Wo + col)) * 4u : DMA_OOB;
-      gpk[k] = (unsigned)(row / TY) | ((unsigned)(row % TY) << 8) | ((unsigned)col << 16);
+      goff[k] = ok ? ((unsigned)r * (unsigned)gvol + (unsigned)((rz * p.Ho + ry) * p.Wo + col)) * 4u : DMA_OOB;
+      gpk[k] = (unsigned)rz | ((unsigned)ry << 8) | ((unsigned)col << 16);
     }
-    const bool g_exact = p.Do % TZ == 0 && p.Ho % TY == 0 && p.Wo % KW == 0;
+    const bool g_exact = p.Do % TZ == 0 && p.Ho % TYB == 0 && p.Wo % KWX == 0;
     int bxi, byi, bzi, b;  // the brick to stage next (decoded once, then advanced like an odometer)
     {
       long long q = s0;
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
       b = (int)(q / p.bz);
     }
     auto stage = [&](int buf) {
-      const int oz0 = bzi * TZ, oy0 = byi * TY, ox0 = bxi * KW;
+      const int oz0 = bzi * TZ, oy0 = byi * TYB, ox0 = bxi * KWX;
       float* dbase = lds + buf * BUF;
       __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(G + ((size_t)b * p.Cg + g0) * gvol), (short)0,
                                                                      0x7fffffff, 0x00020000);
@@ -492,7 +498,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
       if (HALF) ah = sG[((wv & 1) * 32 + l31) * GP + row * KW + ox];
 #pragma unroll
       for (int n = 0; n < NB; ++n)
-        bq[n] = sS[boff[n] + (row / TY) * S * PSP + (row % TY) * S * XP + ox * S];
+        bq[n] = sS[boff[n] + (row / TY) * S * PSP + ((row % TY) * YR + (2 * kk) / KWX) * S * XP +
+                   ((2 * kk) % KWX + kh) * S];
     };
     auto mma = [&](const float (&a)[MT], const float& ah, const float (&bq)[NB]) {
 #pragma unroll
@@ -542,12 +549,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
   if (HALF) flush(acch, 4 * FULL + (wv >> 1), wv & 1);
 }
 
-template <int K, int S, int NC, int MT, int TZ, int TY, int FULL, int HALF>
+template <int K, int S, int NC, int MT, int TZ, int TY, int FULL, int HALF, int KWX = 32>
 int launch_dma(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st) {
   WB p;
   p.B = w.B; p.Cg = w.Cg; p.Cs = w.Cs; p.Do = w.Do; p.Ho = w.Ho; p.Wo = w.Wo;
   p.Di = w.Di; p.Hi = w.Hi; p.Wi = w.Wi; p.pad = w.pad;
-  p.bz = fs::cdiv(p.Do, TZ); p.by = fs::cdiv(p.Ho, TY); p.bx = fs::cdiv(p.Wo, KW);
+  p.bz = fs::cdiv(p.Do, TZ); p.by = fs::cdiv(p.Ho, TY * (KW / KWX)); p.bx = fs::cdiv(p.Wo, KWX);
   p.bricks = (long long)p.B * p.bz * p.by * p.bx;
   const int mtiles = fs::cdiv(p.Cg, 32 * MT);
   const int nchunks = fs::cdiv(p.Cs, NC);
@@ -559,7 +566,7 @@ int launch_dma(const float* G, const float* Src, float* dW, const WP& w, hipStre
   p.spw = (int)(spw > (1 << 20) ? (1 << 20) : spw);
   const long long gx = (p.bricks + p.spw - 1) / p.spw;
   if (gx >= (1ll << 31) || nchunks > 65535 || mtiles > 65535) return FS_ERR_SHAPE;
-  hipLaunchKernelGGL((conv3d_wrw_dma_kernel<K, S, NC, MT, TZ, TY, FULL, HALF>), dim3((unsigned)gx, nchunks, mtiles),
+  hipLaunchKernelGGL((conv3d_wrw_dma_kernel<K, S, NC, MT, TZ, TY, FULL, HALF, KWX>), dim3((unsigned)gx, nchunks, mtiles),
                      dim3(512), 0, st, G, Src, dW, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
@@ -599,13 +606,15 @@ extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B,
   // pad <= stride, 31-bit byte offsets inside one (b, chunk) slab.  `FLOWSCI_WRW_REG=1`: the register-staged
   // kernel everywhere (scripts/wrwbench.py compares the two).
   static const bool reg_only = getenv("FLOWSCI_WRW_REG") != nullptr;
-  const bool dma_ok = !reg_only && pad <= stride && Wo >= KW && Wo % 4 == 0 && Wi % 4 == 0 &&
+  const bool dma_ok = !reg_only && pad <= stride && (Wo >= KW || Wo == 16) && Wo % 4 == 0 && Wi % 4 == 0 &&
                       (((uintptr_t)g | (uintptr_t)src) & 15) == 0 && (long long)64 * Do * Ho * Wo * 4 < (1ll << 31) &&
                       (long long)16 * Di * Hi * Wi * 4 < (1ll << 31);
   if (dma_ok) {
+    if (kernel == 3 && Cg > 32 && Cs >= 8 && Wo == 16) return launch_dma<3, 1, 16, 2, 1, 4, 3, 1, 16>(g, src, dw, p, st);
     if (kernel == 3 && Cg > 32 && Cs >= 8) return launch_dma<3, 1, 16, 2, 1, 4, 3, 1>(g, src, dw, p, st);
-    if (kernel == 4 && Cg > 32 && Cs >= 4) return launch_dma<4, 2, 8, 2, 1, 2, 4, 0>(g, src, dw, p, st);
-    if (kernel == 4 && Cg <= 32 && Cs >= 3) return launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st);
+    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo == 16) return launch_dma<4, 2, 8, 2, 1, 2, 4, 0, 16>(g, src, dw, p, st);
+    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo >= KW) return launch_dma<4, 2, 8, 2, 1, 2, 4, 0>(g, src, dw, p, st);
+    if (kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) return launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st);
   }
   if (kernel == 3) return launch_brick<3, 1, 8, 1, 4>(g, src, dw, p, st);
   // k = 4: 64 columns per source channel.  NC = 4 gives every wave two 32-column tiles, NC = 2 one;

@@ -270,6 +270,8 @@ def test_corr3d_vs_oracle(ops, shape, md):
     dict(cin=20, cout=1, k=4, s=2, size=(5, 6, 72), tr=True),       # mask head: 8 parity rows of one 16-row tile
     dict(cin=12, cout=32, k=4, s=2, size=(10, 12, 136), tr=False),  # its input gradient: 12 channels x 8 parities = 6 row tiles
     dict(cin=24, cout=72, k=3, s=1, size=(5, 7, 68), tr=False),     # k3: Cg = 72 (two M groups, ragged), Cs = 24 (ragged chunk)
+    dict(cin=24, cout=40, k=3, s=1, size=(5, 12, 16), tr=False),    # 16 output columns: two y rows per 32-element reduction row
+    dict(cin=20, cout=48, k=4, s=2, size=(6, 12, 32), tr=False),    # the same for k4 (block0's conv0b: 32 -> 16 columns)
 ])
 def test_conv3d_wrw_mfma_vs_autograd(ops, cfg):
     import torch.nn.functional as F
