@@ -32,6 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct TP {
   int B, Cin, Cout;
+  int CoutT;             // channels of the whole output tensor (> Cout when a launch covers a 32-channel slice of it)
   int Di, Hi, Wi;        // input extent
   int Dout, Hout, Wout;  // output extent (2*in or 2*in + 1 per axis)
   int Dq, Hq, Wq;        // input-grid positions that own outputs: ceil(out / 2)
@@ -51,12 +52,13 @@ __device__ __forceinline__ constexpr int tap_d(int p, int a) { return p == 0 ? (
 __device__ __forceinline__ constexpr int tap_k(int p, int a) { return p == 0 ? (a == 0 ? 1 : 3) : (a == 0 ? 0 : 2); }
 
 // Wt[ci][tap 0..63][co 0..31] <- W[ci][co][tap]  (zero for co >= Cout, ci >= Cin)
+// (`w` may point at a 32-channel slice of a [Cin][CoutT][64] tensor)
 __global__ __launch_bounds__(256) void wprep_tr_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin,
-                                                       int Cout, int CinP) {
+                                                       int Cout, int CinP, int CoutT) {
   const int total = CinP * 64 * 32;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     const int co = e & 31, tap = (e >> 5) & 63, ci = e >> 11;
-    wt[e] = (co < Cout && ci < Cin) ? w[((size_t)ci * Cout + co) * 64 + tap] : 0.f;
+    wt[e] = (co < Cout && ci < Cin) ? w[((size_t)ci * CoutT + co) * 64 + tap] : 0.f;
   }
 }
 
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __rest
       float v[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = acc[c][r] + bv;
-      store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p,
-             p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
+      store8(Y + ((size_t)b * p.CoutT + co) * yvol, v, qz, qy, qx, p,
+             p.Z ? p.Z + ((size_t)b * p.CoutT + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
     }
   }
 }
@@ -511,8 +513,8 @@ __global__ __launch_bounds__(512, 2) void convtr_mfma_ws_kernel(const float* __r
       float v[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = acc[c][r] + bv;
-      store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p,
-             p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
+      store8(Y + ((size_t)b * p.CoutT + co) * yvol, v, qz, qy, qx, p,
+             p.Z ? p.Z + ((size_t)b * p.CoutT + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
     }
   }
 }
@@ -1010,7 +1012,8 @@ extern "C" int fs_debug_tr_stamps(unsigned long long* out) {
 #endif
 
 extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
-  if (Cin < 1 || Cout < 1 || Cout > 32) return -1;
+  if (Cin < 1 || Cout < 1 || (Cout > 32 && (Cout % 32 != 0 || Cout > 128))) return -1;
+  if (Cout > 32) Cout = 32;  // 32-channel slices, one after the other
   const long long cinp = (Cin + 3) / 4 * 4;
   // W'[ci][neighbour][row] (+ pad) of the all-parities kernel (<= 12 channels), or the slabs of the class kernels
   const long long p8 = Cout <= 12 ? cinp * p8_ws_ci(Cout <= 2 ? 1 : (Cout <= 6 ? 3 : 6)) : 0;
@@ -1018,13 +1021,14 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   return p8 > cls ? p8 : cls;
 }
 
-static int conv3d_tr_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
+static int conv3d_tr_slice(const float* x, const float* w, const float* bias, const float* slope, int nslope,
                           const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di,
-                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream) {
+                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream, int CoutT = 0) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1) return FS_ERR_SHAPE;
   if (Cout > 32) return FS_ERR_ARG;
+  if (CoutT == 0) CoutT = Cout;
   // transposed convolution: out = 2 in; input gradient of Conv3d(4,2,1): in_x = 2 out or 2 out + 1
   if ((Dout != 2 * Di && Dout != 2 * Di + 1) || (Hout != 2 * Hi && Hout != 2 * Hi + 1) ||
       (Wout != 2 * Wi && Wout != 2 * Wi + 1))
@@ -1033,7 +1037,7 @@ static int conv3d_tr_impl(const float* x, const float* w, const float* bias, con
     return FS_ERR_SHAPE;
   if ((long long)4 * Di * Hi * Wi * 4 >= (1ll << 32)) return FS_ERR_SHAPE;  // 32-bit chunk offsets
   TP p;
-  p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutT = CoutT; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
   p.Dout = Dout; p.Hout = Hout; p.Wout = Wout;
   p.Dq = (Dout + 1) / 2; p.Hq = (Hout + 1) / 2; p.Wq = (Wout + 1) / 2;
   p.slope = slope; p.Z = z; p.nslope = nslope;
@@ -1090,13 +1094,33 @@ static int conv3d_tr_impl(const float* x, const float* w, const float* bias, con
       hipLaunchKernelGGL((convtr_mfma16_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
   } else {
     hipLaunchKernelGGL(wprep_tr_kernel, dim3((cinp * 64 * 32 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
-                       cinp);
+                       cinp, p.CoutT);
     if (ws_ok)
       hipLaunchKernelGGL((convtr_mfma_ws_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(512), 0, st, x, ws, bias, y, p);
     else
       hipLaunchKernelGGL((convtr_mfma_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
   }
   FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// More than 32 output channels (block0's 128 -> 64 deconvolution): 32-channel slices of the output, one launch each
+// (the same workspace: launches on one stream run in order); the slice's pointers are offset to its first channel
+// and the kernels stride batches by the whole tensor's channel count.
+static int conv3d_tr_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
+                          const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di,
+                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream) {
+  if (Cout <= 32) return conv3d_tr_slice(x, w, bias, slope, nslope, addend, y, z, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout,
+                                         Wout, stream);
+  if (Cout % 32 != 0 || Cout > 128 || Dout < 1 || Hout < 1 || Wout < 1) return FS_ERR_ARG;
+  const size_t yvol = (size_t)Dout * Hout * Wout;
+  for (int c0 = 0; c0 < Cout; c0 += 32) {
+    const int rc = conv3d_tr_slice(x, w + (size_t)c0 * 64, bias ? bias + c0 : nullptr,
+                                   slope ? (nslope == 1 ? slope : slope + c0) : nullptr, nslope == 1 ? 1 : (nslope ? 32 : 0),
+                                   addend ? addend + c0 * yvol : nullptr, y + c0 * yvol, z ? z + c0 * yvol : nullptr, ws, B,
+                                   Cin, 32, Di, Hi, Wi, Dout, Hout, Wout, stream, Cout);
+    if (rc != FS_OK) return rc;
+  }
   return FS_OK;
 }
 

@@ -615,6 +615,8 @@ extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B,
     if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo == 16) return launch_dma<4, 2, 8, 2, 1, 2, 4, 0, 16>(g, src, dw, p, st);
     if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo >= KW) return launch_dma<4, 2, 8, 2, 1, 2, 4, 0>(g, src, dw, p, st);
     if (kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) return launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st);
+    // 1-2 source channels (the mask head: 128 columns, one 32-column tile per matrix wave): bound by the G stream
+    if (kernel == 4 && Cg <= 32 && Wo >= KW) return launch_dma<4, 2, 2, 1, 2, 2, 1, 0>(g, src, dw, p, st);
   }
   if (kernel == 3) return launch_brick<3, 1, 8, 1, 4>(g, src, dw, p, st);
   // k = 4: 64 columns per source channel.  NC = 4 gives every wave two 32-column tiles, NC = 2 one;

@@ -1465,7 +1465,8 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
 
 
 def conv3d_tr_supported(cout, k, stride, padding):
-    return (tuple(k) == (4, 4, 4) and tuple(stride) == (2, 2, 2) and tuple(padding) == (1, 1, 1) and cout <= 32)
+    return (tuple(k) == (4, 4, 4) and tuple(stride) == (2, 2, 2) and tuple(padding) == (1, 1, 1) and
+            (cout <= 32 or (cout % 32 == 0 and cout <= 128)))
 
 
 def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
@@ -1488,7 +1489,7 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
     y = x.new_empty((B, Cout, Do, Ho, Wo))
     nws = int(_lib.lib().fs_conv3d_tr_ws_floats(Cin, Cout))
     if nws < 0:
-        raise ValueError("fs_conv3d_tr supports at most 32 output channels, got %d" % Cout)
+        raise ValueError("fs_conv3d_tr supports up to 32 output channels or 64 / 96 / 128, got %d" % Cout)
     ws = x.new_empty(max(nws, 1))
     nb, fl = 4 * (x.numel() + y.numel()), 2 * x.numel() * Cout * 64
     with torch.cuda.device(x.device):

@@ -268,6 +268,9 @@ def test_corr3d_vs_oracle(ops, shape, md):
     dict(cin=30, cout=5, k=4, s=2, size=(5, 7, 132), tr=True),      # x-parity-in-rows MFMA head: two x bricks, ragged rows / channels
     dict(cin=8, cout=4, k=4, s=2, size=(6, 6, 128), tr=True),       # ... exactly one x brick + the q = Wi column
     dict(cin=20, cout=1, k=4, s=2, size=(5, 6, 72), tr=True),       # mask head: 8 parity rows of one 16-row tile
+    dict(cin=32, cout=2, k=4, s=2, size=(4, 6, 36), tr=True),       # ... its weight gradient: 2-channel chunk, one column tile per wave
+    dict(cin=16, cout=64, k=4, s=2, size=(4, 6, 36), tr=True),      # 64 output channels: two 32-channel slices (loader-wave kernel)
+    dict(cin=96, cout=8, k=4, s=2, size=(6, 10, 18), tr=False),     # input gradient with 96 channels: three slices (register-staged)
     dict(cin=12, cout=32, k=4, s=2, size=(10, 12, 136), tr=False),  # its input gradient: 12 channels x 8 parities = 6 row tiles
     dict(cin=24, cout=72, k=3, s=1, size=(5, 7, 68), tr=False),     # k3: Cg = 72 (two M groups, ragged), Cs = 24 (ragged chunk)
     dict(cin=24, cout=40, k=3, s=1, size=(5, 12, 16), tr=False),    # 16 output columns: two y rows per 32-element reduction row
@@ -404,7 +407,7 @@ def test_conv3d_fwd_mfma_vs_fp64(ops, cfg, monkeypatch):
             assert torch.equal(m(xd), y)
 
 
-@pytest.mark.parametrize("tr,nw", [(False, 7), (True, 7), (False, 1)])
+@pytest.mark.parametrize("tr,nw", [(False, 7), (True, 7), (False, 1), (True, 64)])
 def test_conv_prelu_fused_node_vs_fp64(ops, tr, nw):
     """convgrad.ConvPReLU: conv + bias + PReLU as one autograd node (bias gradient from the PReLU
     backward pass) against an fp64 CPU graph; module keys are those of Sequential(conv, PReLU)."""
@@ -412,6 +415,8 @@ def test_conv_prelu_fused_node_vs_fp64(ops, tr, nw):
     from opticalflowscivis_amd import convgrad
     g = torch.Generator().manual_seed(31 + nw + int(tr))
     cin, cout, k, s = (6, 7, 4, 2) if tr else (5, 7, 3, 1)
+    if nw == 64:  # block0's 128 -> 64 deconvolution: two 32-channel slices of the output per launch sequence
+        cin, cout = 12, 64
     x = torch.randn(2, cin, 5, 9, 13, generator=g)
     conv = (convgrad.ConvTranspose3d if tr else convgrad.Conv3d)(cin, cout, k, s, 1)
     seq = convgrad.ConvPReLU(conv, convgrad.PReLU(cout if nw > 1 else 1))
