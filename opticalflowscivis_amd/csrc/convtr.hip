@@ -900,7 +900,7 @@ __global__ __launch_bounds__(512, 2) void convtr_p8_kernel(const float* __restri
 #endif
 }
 
-template <int RT, int NT>
+template <int RT, int NT, int CINP = 32>
 void launch_p8(const float* x, const float* ws, const float* bias, float* y, const TP& p, hipStream_t st) {
   static int ncu = 0;  // one persistent workgroup per CU
   if (ncu == 0) {
@@ -913,7 +913,7 @@ void launch_p8(const float* x, const float* ws, const float* bias, float* y, con
   const long long nwg = p.tiles < ncu ? p.tiles : ncu;
   const int per = (int)((p.tiles + nwg - 1) / nwg);
   const unsigned grid = (unsigned)((p.tiles + per - 1) / per);
-  hipLaunchKernelGGL((convtr_p8_kernel<RT, NT, 32>), dim3(grid), dim3(512), 0, st, x, ws, bias, y, p, per);
+  hipLaunchKernelGGL((convtr_p8_kernel<RT, NT, CINP>), dim3(grid), dim3(512), 0, st, x, ws, bias, y, p, per);
 }
 
 // NP input-grid positions (consecutive qy) per thread: every scalar-loaded weight feeds NP FMAs.  The
@@ -1049,7 +1049,7 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   // FLOWSCI_TR_P8_ALL=1 -- but measured 2.50 vs 2.44 ms against the 16-row class kernel on the 32 -> 11 input
   // gradient at 128^3, so those layers stay there)
   static const bool p8_all = getenv("FLOWSCI_TR_P8_ALL") != nullptr;
-  if (Cout <= (p8_all ? 12 : 6) && !reg_only && z == nullptr && ws != nullptr && Cin <= 32 && Dout == 2 * Di && Hout == 2 * Hi &&
+  if (Cout <= (p8_all ? 12 : 6) && !reg_only && z == nullptr && ws != nullptr && Cin <= (Cout <= 6 ? 64 : 32) && Dout == 2 * Di && Hout == 2 * Hi &&
       Wout == 2 * Wi && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 &&
       (long long)4 * Di * Hi * Wi * 4 < (1ll << 31)) {
     // all-parities-in-rows MFMA kernel: 2x2 position rows x 128 (64) positions per brick; positions 0..Di, 0..Hi, 0..Wi
@@ -1061,7 +1061,10 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
       const int cinp = (Cin + 3) / 4 * 4;
       hipLaunchKernelGGL(wprep_p8_kernel, dim3((cinp * p8_ws_ci(rt) + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
                          cinp, rt);
-      if (rt == 1) { if (wide) launch_p8<1, 9>(x, ws, bias, y, p, st); else launch_p8<1, 5>(x, ws, bias, y, p, st); }
+      if (Cin > 32) {  // block0's heads (64 input channels): the weight table is twice as large
+        if (rt == 1) { if (wide) launch_p8<1, 9, 64>(x, ws, bias, y, p, st); else launch_p8<1, 5, 64>(x, ws, bias, y, p, st); }
+        else { if (wide) launch_p8<3, 9, 64>(x, ws, bias, y, p, st); else launch_p8<3, 5, 64>(x, ws, bias, y, p, st); }
+      } else if (rt == 1) { if (wide) launch_p8<1, 9>(x, ws, bias, y, p, st); else launch_p8<1, 5>(x, ws, bias, y, p, st); }
       else if (rt == 3) { if (wide) launch_p8<3, 9>(x, ws, bias, y, p, st); else launch_p8<3, 5>(x, ws, bias, y, p, st); }
       else launch_p8<6, 5>(x, ws, bias, y, p, st);
       FS_LAUNCH_CHECK();

@@ -269,6 +269,7 @@ def test_corr3d_vs_oracle(ops, shape, md):
     dict(cin=8, cout=4, k=4, s=2, size=(6, 6, 128), tr=True),       # ... exactly one x brick + the q = Wi column
     dict(cin=20, cout=1, k=4, s=2, size=(5, 6, 72), tr=True),       # mask head: 8 parity rows of one 16-row tile
     dict(cin=32, cout=2, k=4, s=2, size=(4, 6, 36), tr=True),       # ... its weight gradient: 2-channel chunk, one column tile per wave
+    dict(cin=64, cout=6, k=4, s=2, size=(4, 6, 36), tr=True),       # block0's flow head: 64 input channels in the LDS weight table
     dict(cin=16, cout=64, k=4, s=2, size=(4, 6, 36), tr=True),      # 64 output channels: two 32-channel slices (loader-wave kernel)
     dict(cin=96, cout=8, k=4, s=2, size=(6, 10, 18), tr=False),     # input gradient with 96 channels: three slices (register-staged)
     dict(cin=12, cout=32, k=4, s=2, size=(10, 12, 136), tr=False),  # its input gradient: 12 channels x 8 parities = 6 row tiles
