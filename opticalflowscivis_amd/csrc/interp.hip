@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void interp3d_down_adjoint_exact(const float* 
 // Same, four consecutive x per thread (Wi % 4 == 0): the row test and the index arithmetic are paid
 // once per float4 store -- the scalar version is bound by its integer divisions, not by HBM.
 __global__ __launch_bounds__(256) void interp3d_down_adjoint_exact_v4(const float* __restrict__ gout,
-                                                                     float4* __restrict__ gin, IP p) {
+                                                                     float4* __restrict__ gin, IP p, float scale) {
   const int W4 = p.Wi >> 2;
   const long long rows = p.nBC * p.Di * p.Hi;
   const long long total = rows * W4;
@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void interp3d_down_adjoint_exact_v4(const floa
     if ((ry == lo || ry == hi) && (rz == lo || rz == hi)) {
       const float* g = gout + ((bc * p.Do + z / p.s) * p.Ho + y / p.s) * p.Wo;
       if (p.s == 2) {
-        const float g0 = 0.125f * g[2 * x4], g1 = 0.125f * g[2 * x4 + 1];
+        const float g0 = 0.125f * g[2 * x4] * scale, g1 = 0.125f * g[2 * x4 + 1] * scale;
         v = make_float4(g0, g0, g1, g1);
       } else {  // s == 4: residues 1 and 2 of each group of four
-        const float g0 = 0.125f * g[x4];
+        const float g0 = 0.125f * g[x4] * scale;
         v = make_float4(0.f, g0, g0, 0.f);
       }
     }
@@ -334,7 +334,11 @@ extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, flo
                                       int Hin, int Win, int Dout, int Hout, int Wout, int factor, int upsample,
                                       float scale, fs_stream_t stream) {
   FS_ENTER();
-  if (scale != 1.0f && !(upsample && ws != nullptr)) return FS_ERR_ARG;
+  // `scale`: the separable up-sampling adjoint, or the exact float4 down-sampling adjoint (the flow's `* 1/scale` of
+  // IFBlock.forward: a power of two, so scaling the gradient inside the kernel is bitwise the separate pass)
+  const bool down_v4 = !upsample && Din == Dout * factor && Hin == Hout * factor && Win == Wout * factor &&
+                       (Win & 3) == 0 && ((uintptr_t)grad_in & 15) == 0;
+  if (scale != 1.0f && !(upsample && ws != nullptr) && !down_v4) return FS_ERR_ARG;
   FS_REQUIRE_PTR(grad_out); FS_REQUIRE_PTR(grad_in);
   if (B < 1 || C < 1 || Din < 1 || Hin < 1 || Win < 1 || Dout < 1 || Hout < 1 || Wout < 1)
     return FS_ERR_SHAPE;
@@ -359,7 +363,7 @@ extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, flo
     const bool exact = Din == Dout * factor && Hin == Hout * factor && Win == Wout * factor;
     if (exact && (Win & 3) == 0 && ((uintptr_t)grad_in & 15) == 0)
       hipLaunchKernelGGL(interp3d_down_adjoint_exact_v4, dim3(grid_for(total / 4)), dim3(256), 0, st, grad_out,
-                         (float4*)grad_in, p);
+                         (float4*)grad_in, p, scale);
     else if (exact)
       hipLaunchKernelGGL(interp3d_down_adjoint_exact, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
                          grad_in, p);

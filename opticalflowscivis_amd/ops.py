@@ -1158,9 +1158,13 @@ class _Interp3D(torch.autograd.Function):
                       Ho, Wo, factor, 1, mul, _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()),
                       record_as="fs_interp3d_bwd")
             else:
-                _call("fs_interp3d_bwd", gy.data_ptr(), gx.data_ptr(), 0, B, C, Di, Hi, Wi, Do, Ho, Wo,
-                      factor, 0, _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()))
-                if mul != 1.0:
+                # the exact float4 form takes the scale itself; the general forms need a separate pass
+                fold = (mul != 1.0 and (Di, Hi, Wi) == (Do * factor, Ho * factor, Wo * factor) and Wi % 4 == 0
+                        and gx.data_ptr() % 16 == 0)
+                _call("fs_interp3d_bwd_scaled", gy.data_ptr(), gx.data_ptr(), 0, B, C, Di, Hi, Wi, Do, Ho, Wo,
+                      factor, 0, float(mul) if fold else 1.0, _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()),
+                      record_as="fs_interp3d_bwd")
+                if mul != 1.0 and not fold:
                     gx.mul_(mul)
         return gx, None, None, None
 
