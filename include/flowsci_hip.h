@@ -28,7 +28,8 @@ enum {
   FS_ERR_NULLPTR = 1, /* a required pointer is NULL */
   FS_ERR_SHAPE = 2,   /* a size is out of the supported range */
   FS_ERR_ARG = 3,     /* an option / mode value is invalid */
-  FS_ERR_LAUNCH = 4   /* hipGetLastError() != hipSuccess after the launch */
+  FS_ERR_LAUNCH = 4,  /* hipGetLastError() != hipSuccess after the launch */
+  FS_ERR_UNSUPPORTED = 5 /* a fused entry point has no kernel for this shape / alignment: use the unfused ones */
 };
 
 /* Library version (major*10000 + minor*100 + patch). */
@@ -459,6 +460,17 @@ int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, f
 int fs_conv3d_fwd_add(const float* x, const float* w, const float* bias, const float* addend, float* y,
                       float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                       int kernel, int stride, int pad, int wmode, fs_stream_t stream);
+/* The backward counterpart for the heads (Flow-3D/model/IFNet.py:66-77: deconv -> PReLU -> deconv): the input gradient
+ * of the SECOND deconvolution (a strided convolution of its grad_out, weight read as [out][in], wmode 0) with the PReLU
+ * backward of the layer in between folded into the epilogue -- grad_act_y = conv(x) * prelu'(act_y), plus the PReLU
+ * weight gradient and the first deconvolution's bias gradient (deterministic: per-wave partials in `part`,
+ * fs_conv3d_fwd_dprelu_part_floats floats, summed in a fixed order).  FS_ERR_UNSUPPORTED: no such kernel for this
+ * shape / alignment -- use fs_conv3d_fwd followed by fs_prelu_bwd. */
+long long fs_conv3d_fwd_dprelu_part_floats(int B, int Cout, int Do, int Ho, int Wo);
+int fs_conv3d_fwd_dprelu(const float* x, const float* w, const float* act_y, const float* prelu_weight,
+                         int num_prelu_weights, float* grad_act_y, float* grad_prelu_weight, float* grad_bias,
+                         float* part, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                         int kernel, int stride, int pad, fs_stream_t stream);
 int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* bias, const float* prelu_weight,
                         const float* residual, float* y, float* z, float* ws,
                         int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,

@@ -205,6 +205,63 @@ class _ConvPReLUFn(torch.autograd.Function):
         return gx, gw, gb, ga, None, None, None
 
 
+class _HeadFn(torch.autograd.Function):
+    """out = deconv2(PReLU(deconv1(x))) [+ addend] -- an IFBlock head (Flow-3D/model/IFNet.py:66-77) -- as ONE autograd
+    node, so that the backward pass can fold the PReLU backward into the epilogue of deconv2's input-gradient
+    convolution (fs_conv3d_fwd_dprelu): the gradient w.r.t. PReLU's output is never written, and PReLU's own pass
+    over three 537 MB tensors (at 256^3) disappears.  Falls back to the two-pass form where the fused kernel does
+    not apply."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, a1, w2, b2, addend):
+        from . import ops
+        y1, z1 = ops.conv3d_tr(x, w1, b1, None, a1)
+        out = ops.conv3d_tr(z1, w2, b2, None, None, addend)
+        ctx.save_for_backward(x, w1, a1, y1, z1, w2)
+        ctx.has = (b1 is not None, b2 is not None, addend is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+        x, w1, a1, y1, z1, w2 = ctx.saved_tensors
+        s3, p3 = (2, 2, 2), (1, 1, 1)
+        gout = gout.contiguous()
+        gw2 = _conv_grad_weight(z1, w2, gout, s3, p3, True) if ctx.needs_input_grad[4] else None
+        gb2 = gout.sum(dim=(0, 2, 3, 4)) if (ctx.has[1] and ctx.needs_input_grad[5]) else None
+        fused = ops.conv3d_deconv_grad_input_dprelu(gout, w2, y1, a1)
+        if fused is not None:
+            gy1, ga1, gb1 = fused
+        else:
+            gz1 = _conv_grad_input(z1, w2, gout, s3, p3, True)
+            gy1, ga1, gb1 = ops.prelu_backward(y1, gz1, a1, want_bias_grad=ctx.has[0])
+        if not ctx.has[0]:
+            gb1 = None
+        gw1 = _conv_grad_weight(x, w1, gy1, s3, p3, True) if ctx.needs_input_grad[1] else None
+        gx = _conv_grad_input(x, w1, gy1, s3, p3, True) if ctx.needs_input_grad[0] else None
+        return gx, gw1, gb1, ga1, gw2, gb2, (gout if (ctx.has[2] and ctx.needs_input_grad[6]) else None)
+
+
+def head_fused_ok(head, x, addend):
+    """Can `head` = Sequential(ConvTranspose3d, PReLU, ConvTranspose3d) run as _HeadFn on `x`?"""
+    d1, act, d2 = head[0], head[1], head[2]
+    if not (_hip_autograd(x) and x.dim() == 5 and x.dtype == torch.float32 and isinstance(d1, ConvTranspose3d)
+            and isinstance(d2, ConvTranspose3d) and isinstance(act, nn.PReLU)):
+        return False
+    for d in (d1, d2):
+        if not (_tuple(d.kernel_size, 3) == (4, 4, 4) and _tuple(d.stride, 3) == (2, 2, 2) and _tuple(d.padding, 3) == (1, 1, 1)
+                and d.groups == 1 and _tuple(d.dilation, 3) == (1, 1, 1) and _tuple(d.output_padding, 3) == (0, 0, 0)):
+            return False
+    if act.weight.numel() not in (1, d1.out_channels):
+        return False
+    if not (_hip_tr_ok(x, d1.out_channels, (4, 4, 4), (2, 2, 2), (1, 1, 1))):
+        return False
+    mid = tuple(2 * n for n in x.shape[2:])
+    from . import ops
+    return ops.conv3d_tr_supported(d2.out_channels, (4, 4, 4), (2, 2, 2), (1, 1, 1)) and ops.conv3d_tr_fits(mid) and \
+        (addend is None or (addend.is_cuda and addend.dtype == torch.float32))
+
+
 class ConvPReLU(nn.Sequential):
     """nn.Sequential(conv, PReLU) -- the reference's `conv()` / `deconv()` helpers
     (Flow-3D/model/IFNet.py:13-29) -- with the same children (`0` = convolution, `1` = PReLU: identical

@@ -11,6 +11,7 @@ extern "C" const char* fs_error_string(int code) {
     case FS_ERR_SHAPE: return "size out of the supported range";
     case FS_ERR_ARG: return "invalid option / mode";
     case FS_ERR_LAUNCH: return "kernel launch failed";
+    case FS_ERR_UNSUPPORTED: return "no fused kernel for this shape / alignment (use the unfused entry points)";
     default: return "unknown error code";
   }
 }

@@ -46,6 +46,14 @@ struct FP {
   // written (the residual of an IFBlock unit, `convblock(x) + x`), else to Y (the residual branch of
   // that unit's input gradient)
   const float* addend;
+  // optional fused PReLU backward (loader-wave kernels, input-gradient use): the convolution's result g is the
+  // gradient w.r.t. z = prelu(act_y); the epilogue stores g * prelu'(act_y) instead and leaves per-wave partial sums
+  // of the slope gradient (sum g * act_y * [act_y <= 0]) and of the stored values (the producing layer's bias
+  // gradient) in dpart[(workgroup * 4 + wave) * CP * 2 + channel * 2 + {0, 1}]
+  const float* dy;
+  const float* dslope;
+  int dnslope;
+  float* dpart;
 };
 
 // Wt[ci][tap][co] (ci < CinP, co < CoutP; zero outside the real channels)
@@ -420,6 +428,67 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
     buf ^= 1;
   }
 
+  if (p.dy != nullptr) {
+    // ---- fused PReLU-backward epilogue
+    const float* __restrict__ dy = p.dy;
+    float* __restrict__ Yg = Y;
+    float pa[MT][16], pb[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pa[m][r] = pb[m][r] = 0.f;
+    const int oz = oz0 + wz, ox = ox0 + lx;
+    if (oz < p.Do && ox < p.Wo) {
+      const size_t yvol = (size_t)p.Do * p.Ho * p.Wo;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int oy = oy0 + (wy + n) * R + ly;
+        if (oy >= p.Ho) continue;
+        const size_t o0 = (size_t)b * p.Cout * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          float yv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {  // all loads of the tile first
+            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            yv[r] = co < p.Cout ? dy[o0 + (size_t)co * yvol] : 1.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (co < p.Cout) {
+              const float g = acc[m][n][r];
+              const float sl = p.dslope[p.dnslope == 1 ? 0 : co];
+              const float o = yv[r] > 0.f ? g : sl * g;
+              pa[m][r] += yv[r] > 0.f ? 0.f : yv[r] * g;
+              pb[m][r] += o;
+              Yg[o0 + (size_t)co * yvol] = o;
+            }
+          }
+        }
+      }
+    }
+    // the 32 lanes of a half-wave hold the same channels: butterfly over them, lane 0 / 32 writes the wave's row
+    float* __restrict__ prow = p.dpart + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * CP * 2;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = pa[m][r], bsum = pb[m][r];
+#pragma unroll
+        for (int sft = 1; sft < 32; sft <<= 1) {
+          a += __shfl_xor(a, sft);
+          bsum += __shfl_xor(bsum, sft);
+        }
+        if (col == 0) {
+          const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          prow[cl * 2] = a;
+          prow[cl * 2 + 1] = bsum;
+        }
+      }
+    return;
+  }
+
   // ---- epilogue (as above)
   const float* __restrict__ ad = p.addend;
   const float* __restrict__ slope = p.slope;
@@ -496,6 +565,30 @@ int launch(const float* X, const float* Wt, const float* bias, float* Y, FP& p, 
   return FS_OK;
 }
 
+// ga[c] = sum of the slope-gradient partials of channel c (all channels when the slope is shared), gb[c] = sum of the
+// bias-gradient partials: one block per output, fixed order, fp64 -- deterministic
+__global__ __launch_bounds__(256) void dprelu_finish_kernel(const float* __restrict__ part, int rows_per_group, int CP,
+                                                            int Cout, float* __restrict__ ga, float* __restrict__ gb,
+                                                            int nslope) {
+  const bool bias_blk = (int)blockIdx.x >= nslope;
+  const int c = bias_blk ? blockIdx.x - nslope : blockIdx.x;
+  const bool all = !bias_blk && nslope == 1 && Cout != 1;
+  __shared__ double red[256];
+  double s = 0.0;
+  const int c_lo = all ? 0 : c, c_hi = all ? Cout : c + 1;
+  for (int cc = c_lo; cc < c_hi; ++cc) {
+    const float* src = part + ((size_t)(cc / CP) * rows_per_group * CP + (cc % CP)) * 2 + (bias_blk ? 1 : 0);
+    for (int i = threadIdx.x; i < rows_per_group; i += 256) s += (double)src[(size_t)i * CP * 2];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) (bias_blk ? gb : ga)[c] = (float)red[0];
+}
+
 // channel padding of the re-laid-out weights for a layer
 void wt_dims(int Cin, int Cout, int kernel, int* CinP, int* CoutP) {
   const int ci = (kernel == 3) ? 4 : 2;
@@ -512,9 +605,19 @@ extern "C" long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel) {
   return (long long)cinp * kernel * kernel * kernel * coutp;
 }
 
+struct DPrelu {  // fused PReLU backward of the layer that produced this convolution's (gradient) output
+  const float* act_y = nullptr;
+  const float* slope = nullptr;
+  int nslope = 0;
+  float* part = nullptr;
+  float* ga = nullptr;
+  float* gb = nullptr;
+};
+
 static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
                            const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
-                           int Ho, int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream) {
+                           int Ho, int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream,
+                           const DPrelu* dp = nullptr) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y); FS_REQUIRE_PTR(ws);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1 || Do < 1 || Ho < 1 || Wo < 1)
@@ -533,6 +636,8 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Do; p.Ho = Ho; p.Wo = Wo;
   p.pad = pad;
   p.slope = slope; p.Z = z; p.nslope = nslope; p.addend = addend;
+  p.dy = dp ? dp->act_y : nullptr; p.dslope = dp ? dp->slope : nullptr; p.dnslope = dp ? dp->nslope : 0;
+  p.dpart = dp ? dp->part : nullptr;
   int cinp;
   wt_dims(Cin, Cout, kernel, &cinp, &p.CoutP);
   hipStream_t st = (hipStream_t)stream;
@@ -570,6 +675,18 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     return launch<3, 1, 4, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
   }
   const long long k4tiles = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, 8) * fs::cdiv(Wo, 32);
+  if (dp != nullptr) {
+    // fused PReLU backward: only the 32-channel loader-wave kernel has that epilogue (the input gradient of the heads'
+    // second deconvolution); everything else takes the unfused entry points
+    if (!(kernel == 4 && p.CoutP == 32 && ws_ok && k4tiles >= 512 && bias == nullptr && z == nullptr && addend == nullptr))
+      return FS_ERR_UNSUPPORTED;
+    const int rc = launch_ws<4, 2, 2, 1, 4, 2, 8, 32>(x, ws, bias, y, p, st);
+    if (rc != FS_OK) return rc;
+    hipLaunchKernelGGL(dprelu_finish_kernel, dim3(dp->nslope + Cout), dim3(256), 0, st, dp->part, (int)(k4tiles * 4), 32,
+                       Cout, dp->ga, dp->gb, dp->nslope);
+    FS_LAUNCH_CHECK();
+    return FS_OK;
+  }
   if (p.CoutP == 32) {
     if (ws_ok && k4tiles >= 512) return launch_ws<4, 2, 2, 1, 4, 2, 8, 32>(x, ws, bias, y, p, st);
     if (Wo > 16) return launch<4, 2, 2, 1, 2, 1, 8, 32>(x, ws, bias, y, p, st);
@@ -605,4 +722,29 @@ extern "C" int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* 
   FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
   return conv3d_fwd_impl(x, w, bias, prelu_weight, num_prelu_weights, residual, y, z, ws, B, Cin, Cout, Di, Hi, Wi,
                          Do, Ho, Wo, kernel, stride, pad, 0, stream);
+}
+
+// Input gradient of a convolution whose INPUT was z = prelu(act_y) (a ConvTranspose3d(4,2,1) read as the strided
+// convolution of its grad_out, wmode 0): writes grad_act_y = conv(x) * prelu'(act_y) instead of the gradient w.r.t. z,
+// and the PReLU weight gradient / the producing layer's bias gradient (per-wave partials in `part`, finished in a
+// fixed order).  FS_ERR_UNSUPPORTED when the shape / alignment has no such kernel: use fs_conv3d_fwd + fs_prelu_bwd.
+extern "C" long long fs_conv3d_fwd_dprelu_part_floats(int B, int Cout, int Do, int Ho, int Wo) {
+  if (B < 1 || Cout < 1 || Cout > 32 || Do < 1 || Ho < 1 || Wo < 1) return -1;
+  return (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, 8) * fs::cdiv(Wo, 32) * 4 * 32 * 2;
+}
+
+extern "C" int fs_conv3d_fwd_dprelu(const float* x, const float* w, const float* act_y, const float* prelu_weight,
+                                    int num_prelu_weights, float* grad_act_y, float* grad_prelu_weight,
+                                    float* grad_bias, float* part, float* ws, int B, int Cin, int Cout, int Di, int Hi,
+                                    int Wi, int Do, int Ho, int Wo, int kernel, int stride, int pad,
+                                    fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(act_y); FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(grad_act_y); FS_REQUIRE_PTR(grad_prelu_weight);
+  FS_REQUIRE_PTR(grad_bias); FS_REQUIRE_PTR(part);
+  if (num_prelu_weights != 1 && num_prelu_weights != Cout) return FS_ERR_ARG;
+  DPrelu dp;
+  dp.act_y = act_y; dp.slope = prelu_weight; dp.nslope = num_prelu_weights; dp.part = part;
+  dp.ga = grad_prelu_weight; dp.gb = grad_bias;
+  return conv3d_fwd_impl(x, w, nullptr, nullptr, 0, nullptr, grad_act_y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
+                         kernel, stride, pad, 0, stream, &dp);
 }

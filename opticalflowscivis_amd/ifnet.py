@@ -36,6 +36,11 @@ class _Head(nn.Sequential):
 
     def forward(self, x, addend=None):
         if isinstance(self[0], convgrad.ConvTranspose3d):
+            if convgrad.head_fused_ok(self, x, addend):
+                # one autograd node for the whole head: PReLU's backward runs in the epilogue of the second
+                # deconvolution's input gradient
+                return convgrad._HeadFn.apply(x, self[0].weight, self[0].bias, self[1].weight, self[2].weight,
+                                              self[2].bias, addend)
             h = convgrad.ConvPReLU.forward(self, x)
             return self[2](h) if addend is None else self[2](h, addend)
         y = super().forward(x)

@@ -1400,6 +1400,55 @@ def conv3d_wrw(g, src, k, stride, pad):
     return dw
 
 
+FS_ERR_UNSUPPORTED = 5
+
+
+def conv3d_deconv_grad_input_dprelu(gy, w, act_y, prelu_weight):
+    """Input gradient of ConvTranspose3d(4, 2, 1) with weight w [Cin, Cout, 4,4,4] whose INPUT was z = prelu(act_y):
+    (grad_act_y, grad_prelu_weight, grad_bias_of_the_layer_that_produced_act_y) in one launch
+    (fs_conv3d_fwd_dprelu: the PReLU backward is the convolution's epilogue), or None when that fused kernel does not
+    cover the shape -- the caller then runs conv3d_fwd + prelu_backward."""
+    gy = _need_cuda_f32("grad_output", gy, 5)
+    w = _need_cuda_f32("w", w, 5)
+    act_y = _need_cuda_f32("act_y", act_y, 5)
+    a = _need_cuda_f32("prelu_weight", prelu_weight, 1)
+    B, Cg = gy.shape[:2]                      # the strided convolution's input = grad_out: Cg = deconv Cout
+    Cin_t = w.shape[0]                        # its output channels = the deconvolution's input channels
+    if w.shape[1] != Cg or tuple(w.shape[2:]) != (4, 4, 4) or act_y.shape[1] != Cin_t or a.numel() not in (1, Cin_t):
+        raise ValueError("shapes do not describe a k4 s2 deconvolution: gy %s w %s act_y %s" %
+                         (tuple(gy.shape), tuple(w.shape), tuple(act_y.shape)))
+    Di, Hi, Wi = gy.shape[2:]
+    Do, Ho, Wo = act_y.shape[2:]
+    if any((n + 2 - 4) // 2 + 1 != m for n, m in zip((Di, Hi, Wi), (Do, Ho, Wo))) or Cin_t > 32:
+        return None
+    L = _lib.lib()
+    npart = int(L.fs_conv3d_fwd_dprelu_part_floats(B, Cin_t, Do, Ho, Wo))
+    if npart < 0:
+        return None
+    out = torch.empty_like(act_y)
+    ga, gb = torch.empty_like(a), act_y.new_empty(Cin_t)
+    part = act_y.new_empty(npart)
+    ws = act_y.new_empty(int(L.fs_conv3d_fwd_ws_floats(Cg, Cin_t, 4)))
+    nb = 4 * (gy.numel() + 2 * out.numel())
+    fl = 2 * out.numel() * Cg * 64
+    with torch.cuda.device(gy.device):
+        args = (gy.data_ptr(), w.data_ptr(), act_y.data_ptr(), a.data_ptr(), a.numel(), out.data_ptr(), ga.data_ptr(),
+                gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, Cg, Cin_t, Di, Hi, Wi, Do, Ho, Wo, 4, 2, 1, _stream(gy))
+        if _timing is None or (_timing_only is not None and "fs_conv3d_fwd" not in _timing_only):
+            rc = L.fs_conv3d_fwd_dprelu(*args)
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = L.fs_conv3d_fwd_dprelu(*args)
+            e1.record()
+            if rc == 0:
+                _timing.setdefault("fs_conv3d_fwd", []).append((e0, e1, nb, fl))
+    if rc == FS_ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "fs_conv3d_fwd_dprelu")
+    return out, ga, gb
+
+
 def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
     """Workgroups fs_conv3d_fwd launches for this layer (mirrors its brick choice, csrc/convfwd.hip)."""
     Do, Ho, Wo = out_dhw

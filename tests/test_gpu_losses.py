@@ -500,6 +500,49 @@ def test_upsample3d_scale_add_vs_aten(ops, shape, factor, with_prev):
         assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("nslope,with_add", [(16, True), (1, False)])
+def test_head_fused_node_vs_fp64(ops, nslope, with_add):
+    """convgrad._HeadFn: deconv -> PReLU -> deconv (+ addend) as one autograd node whose backward folds the PReLU
+    backward into the epilogue of the second deconvolution's input gradient (fs_conv3d_fwd_dprelu), against an fp64 CPU
+    graph; at a size where the fused kernel applies (>= 512 bricks), and the fallback below it."""
+    import torch.nn.functional as F
+    from opticalflowscivis_amd import convgrad
+    from opticalflowscivis_amd.ifnet import _head
+    g = torch.Generator().manual_seed(90 + nslope)
+    for size, expect_fused in (((16, 32, 64), True), ((4, 6, 8), False)):
+        head = _head(3, 16, 6)  # Sequential(deconv 16 -> 8, PReLU(8), deconv 8 -> 6)
+        head[1] = convgrad.PReLU(8 if nslope > 1 else 1)
+        with torch.no_grad():
+            head[1].weight.copy_(torch.rand(head[1].weight.shape, generator=g) - 0.3)
+        x = torch.randn((1, 16) + size, generator=g)
+        add = torch.randn((1, 6) + tuple(4 * n for n in size), generator=g) if with_add else None
+        ps = [head[0].weight, head[0].bias, head[1].weight, head[2].weight, head[2].bias]
+        ref = [t.detach().double().requires_grad_() for t in [x] + ps + ([add] if with_add else [])]
+        mid = F.prelu(F.conv_transpose3d(ref[0], ref[1], ref[2], 2, 1), ref[3])
+        outr = F.conv_transpose3d(mid, ref[4], ref[5], 2, 1)
+        if with_add:
+            outr = outr + ref[6]
+        G = torch.randn(outr.shape, generator=g)
+        gref = torch.autograd.grad((outr * G.double()).sum(), ref)
+        head = head.to(DEV)
+        xd = x.to(DEV).requires_grad_()
+        ad = add.to(DEV).requires_grad_() if with_add else None
+        out = head(xd, ad)
+        assert out.grad_fn.__class__.__name__.startswith("_HeadFn")
+        assert float((out.detach().cpu().double() - outr.detach()).abs().max()) < 3e-5 * float(outr.abs().max())
+        wrt = [xd, head[0].weight, head[0].bias, head[1].weight, head[2].weight, head[2].bias] + ([ad] if with_add else [])
+        got = torch.autograd.grad((out * G.to(DEV)).sum(), wrt)
+        for a, b in zip(got, gref):
+            assert a.shape == b.shape
+            assert float((a.detach().cpu().double() - b).abs().max()) < 5e-5 * max(1e-6, float(b.abs().max()))
+        # the fused entry point itself: taken at the large size, declined (None) at the small one
+        gy = G.to(DEV)
+        with torch.no_grad():
+            y1 = F.conv_transpose3d(xd, head[0].weight, head[0].bias, 2, 1)
+        r = ops.conv3d_deconv_grad_input_dprelu(gy, head[2].weight.detach(), y1, head[1].weight.detach())
+        assert (r is not None) == expect_fused
+
+
 def test_conv3d_tr_addend_and_block_accumulate(ops):
     """fs_conv3d_tr_add, and IFBlock(accumulate=True) == base + the reference-style deltas."""
     import torch.nn.functional as F
