@@ -99,6 +99,49 @@ __device__ __forceinline__ void store8(float* __restrict__ yc, const float (&v)[
     }
 }
 
+// store8 for the loader-wave kernels, whose epilogue is not hidden behind a second workgroup and is store-ISSUE-bound
+// (~75 cycles per store wave-instruction and CU whatever its width, csrc/convtr.hip::convtr_p8_kernel): neighbouring
+// lanes (positions q, q + 1) swap one (x = 2q, 2q + 1) pair per z parity -- DPP quad_perm [1,0,3,2] -- so that an
+// even lane holds the four consecutive outputs 2q .. 2q + 3 of the y-parity-0 row and its odd neighbour 2q - 2 ..
+// 2q + 1 of the y-parity-1 row: 16-byte stores, half as many.  EVERY lane of the wave must call it (`ok`: this
+// lane's channel and rows exist; columns are tested per element).
+__device__ __forceinline__ void store8_quad(float* __restrict__ yc, const float (&v)[8], int qz, int qy, int qx, bool ok,
+                                            const TP& p, float* __restrict__ zc = nullptr, float sl = 0.f) {
+  const float* __restrict__ ac = p.addend ? p.addend + (yc - p.Ybase) : nullptr;
+  const bool evn = (qx & 1) == 0;
+#pragma unroll
+  for (int pz = 0; pz < 2; ++pz) {
+    const float a0 = v[(pz * 2 + 0) * 2], a1 = v[(pz * 2 + 0) * 2 + 1];  // row y = 2 qy
+    const float b0 = v[(pz * 2 + 1) * 2], b1 = v[(pz * 2 + 1) * 2 + 1];  // row y = 2 qy + 1
+    const float k0 = evn ? a0 : b0, k1 = evn ? a1 : b1;
+    const float r0 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(evn ? b0 : a0), 0xB1, 0xF, 0xF, false));
+    const float r1 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(evn ? b1 : a1), 0xB1, 0xF, 0xF, false));
+    float4 o = evn ? make_float4(k0, k1, r0, r1) : make_float4(r0, r1, k0, k1);
+    const int z = 2 * qz + pz, y = 2 * qy + (evn ? 0 : 1), x0 = 2 * (evn ? qx : qx - 1);
+    if (!ok || z >= p.Dout || y >= p.Hout || x0 >= p.Wout) continue;
+    float* row = yc + ((size_t)z * p.Hout + y) * p.Wout + x0;
+    if (x0 + 3 < p.Wout) {
+      if (ac != nullptr) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ac + (row - yc));
+        o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+      }
+      *reinterpret_cast<float4*>(row) = o;
+      if (zc != nullptr)
+        *reinterpret_cast<float4*>(zc + (row - yc)) = make_float4(o.x > 0.f ? o.x : sl * o.x, o.y > 0.f ? o.y : sl * o.y,
+                                                                  o.z > 0.f ? o.z : sl * o.z, o.w > 0.f ? o.w : sl * o.w);
+    } else {
+      const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (x0 + e < p.Wout) {
+          const float w = ov[e] + (ac != nullptr ? ac[(row - yc) + e] : 0.f);
+          row[e] = w;
+          if (zc != nullptr) zc[(row - yc) + e] = w > 0.f ? w : sl * w;
+        }
+    }
+  }
+}
+
 template <int TZ, int TY>
 __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __restrict__ X,
                                                           const float* __restrict__ Wt,
@@ -202,18 +245,19 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __rest
   }
 
   const int qz = qz0 + wz, qy = qy0 + wy, qx = qx0 + col;
-  if (qz < p.Dq && qy < p.Hq && qx < p.Wq) {
+  if (qz < p.Dq && qy < p.Hq) {  // wave-uniform: every lane takes part in the lane exchange of store8_quad
     const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (co >= p.Cout) continue;
-      const float bv = bias ? bias[co] : 0.f;
+      const bool ok = co < p.Cout;
+      const int cc = ok ? co : 0;
+      const float bv = (bias && ok) ? bias[cc] : 0.f;
       float v[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = acc[c][r] + bv;
-      store8(Y + ((size_t)b * p.CoutT + co) * yvol, v, qz, qy, qx, p,
-             p.Z ? p.Z + ((size_t)b * p.CoutT + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
+      store8_quad(Y + ((size_t)b * p.CoutT + cc) * yvol, v, qz, qy, qx, ok, p,
+                  p.Z ? p.Z + ((size_t)b * p.CoutT + cc) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : cc] : 0.f);
     }
   }
 }
@@ -597,22 +641,22 @@ __global__ __launch_bounds__(512, 2) void convtr_mfma16_ws_kernel(const float* _
   }
 
   const int qz = qz0 + wz, qy = qy0 + wy;
-  if (qz < p.Dq && qy < p.Hq) {
+  if (qz < p.Dq && qy < p.Hq) {  // wave-uniform: every lane takes part in the lane exchange of store8_quad
     const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int qx = qx0 + 16 * n + col;
-      if (qx >= p.Wq) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = 4 * kq + r;
-        if (co >= p.Cout) continue;
-        const float bv = bias ? bias[co] : 0.f;
+        const bool ok = co < p.Cout;
+        const int cc = ok ? co : 0;
+        const float bv = (bias && ok) ? bias[cc] : 0.f;
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = acc[n][c][r] + bv;
-        store8(Y + ((size_t)b * p.Cout + co) * yvol, v, qz, qy, qx, p,
-               p.Z ? p.Z + ((size_t)b * p.Cout + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
+        store8_quad(Y + ((size_t)b * p.Cout + cc) * yvol, v, qz, qy, qx, ok, p,
+                    p.Z ? p.Z + ((size_t)b * p.Cout + cc) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : cc] : 0.f);
       }
     }
   }
