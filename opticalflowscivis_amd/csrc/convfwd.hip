@@ -489,53 +489,70 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
     return;
   }
 
-  // ---- epilogue (as above)
+  // ---- epilogue.  With one workgroup per CU nothing hides it, and it is store-ISSUE-bound (~75 cycles per store
+  // wave-instruction and CU whatever its width: 64 dword stores per lane were ~15 % of a conv0a brick).  A lane holds
+  // ONE x for 16 channels; the four lanes of a quad transpose 4 x 4 blocks (4 consecutive x  x  channels r & 3 ..) with
+  // two DPP swap stages, after which lane i of the quad holds 4 consecutive x of channel (r & 3) = i: one 16-byte store
+  // instead of four dword stores.  Every lane takes part in the exchange; columns past Wo are dropped at the store.
   const float* __restrict__ ad = p.addend;
   const float* __restrict__ slope = p.slope;
   float* __restrict__ Zp = p.Z;
   float* __restrict__ Yp = Y;
   const int oz = oz0 + wz;
-  const int ox = ox0 + lx;
-  if (oz < p.Do && ox < p.Wo) {
+  if (oz < p.Do) {  // wave-uniform
     const size_t yvol = (size_t)p.Do * p.Ho * p.Wo;
-    float bv[MT][16], sv[MT][16];
+    const int qi = lane & 3;                       // this lane's channel inside a block after the transpose
+    const int xq = ox0 + (lx & ~3);                // first of its four columns
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    auto swap1 = [](float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, false)); };
+    auto swap2 = [](float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, false)); };
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        bv[m][r] = (bias != nullptr && co < p.Cout) ? bias[co] : 0.f;
-        sv[m][r] = (Zp != nullptr && co < p.Cout) ? slope[p.nslope == 1 ? 0 : co] : 0.f;
-      }
+      for (int j = 0; j < 4; ++j) {
+        const int co = co0 + m * 32 + qi + 8 * j + 4 * kh;
+        const bool cok = co < p.Cout;
+        const float bv = (bias != nullptr && cok) ? bias[co] : 0.f;
+        const float sv = (Zp != nullptr && cok) ? slope[p.nslope == 1 ? 0 : co] : 0.f;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int oy = oy0 + (wy + n) * R + ly;
-      if (oy >= p.Ho) continue;
-      const size_t o0 = (size_t)b * p.Cout * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + ox;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        float av[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          av[r] = (ad != nullptr && co < p.Cout) ? ad[o0 + (size_t)co * yvol] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (co < p.Cout) {
-            const float v = acc[m][n][r] + bv[m][r];
-            const size_t o = o0 + (size_t)co * yvol;
+        for (int n = 0; n < NT; ++n) {
+          float a0 = acc[m][n][4 * j], a1 = acc[m][n][4 * j + 1], a2 = acc[m][n][4 * j + 2], a3 = acc[m][n][4 * j + 3];
+          {  // lanes x registers 4 x 4 transpose
+            const float rA = swap1(b0 ? a0 : a1), rB = swap1(b0 ? a2 : a3);
+            if (b0) { a0 = rA; a2 = rB; } else { a1 = rA; a3 = rB; }
+            const float rC = swap2(b1 ? a0 : a2), rD = swap2(b1 ? a1 : a3);
+            if (b1) { a0 = rC; a1 = rD; } else { a2 = rC; a3 = rD; }
+          }
+          const int oy = oy0 + (wy + n) * R + ly;
+          if (!cok || oy >= p.Ho || xq >= p.Wo) continue;
+          const size_t o = ((size_t)b * p.Cout + co) * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + xq;
+          float4 v = make_float4(a0 + bv, a1 + bv, a2 + bv, a3 + bv);
+          if (xq + 3 < p.Wo) {
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ad != nullptr) av = *reinterpret_cast<const float4*>(ad + o);
             if (Zp != nullptr) {
-              Yp[o] = v;
-              Zp[o] = (v > 0.f ? v : sv[m][r] * v) + av[r];
+              *reinterpret_cast<float4*>(Yp + o) = v;
+              *reinterpret_cast<float4*>(Zp + o) = make_float4((v.x > 0.f ? v.x : sv * v.x) + av.x, (v.y > 0.f ? v.y : sv * v.y) + av.y,
+                                                               (v.z > 0.f ? v.z : sv * v.z) + av.z, (v.w > 0.f ? v.w : sv * v.w) + av.w);
             } else {
-              Yp[o] = v + av[r];
+              *reinterpret_cast<float4*>(Yp + o) = make_float4(v.x + av.x, v.y + av.y, v.z + av.z, v.w + av.w);
             }
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (xq + e < p.Wo) {
+                const float ae = ad != nullptr ? ad[o + e] : 0.f;
+                if (Zp != nullptr) {
+                  Yp[o + e] = vv[e];
+                  Zp[o + e] = (vv[e] > 0.f ? vv[e] : sv * vv[e]) + ae;
+                } else {
+                  Yp[o + e] = vv[e] + ae;
+                }
+              }
           }
         }
       }
-    }
   }
 }
 
