@@ -34,6 +34,10 @@
 namespace {
 
 constexpr int TY = 8, TX = 32, CC = 8;
+// displacement rows per wave of the tiled kernels (forward: 1 -> 2md+1 waves, 36 accumulators per lane at md = 4:
+// 1 / 2 / 3 rows per wave measured 24 / 27 / 37 us at the (64, 19, 57) level, equal at (32, 38, 113))
+#define FS_C2_FWD_DPW 1
+#define FS_C2_BWD_DPW 3
 
 // Two problems of one shape per launch (UPFlow correlates both directions at every level,
 // upflow.py:649,652); pointers of the second problem may equal the first's.
@@ -50,164 +54,381 @@ struct C2Set {
 };
 
 
-template <int MD>
-__global__ __launch_bounds__(64 * (2 * MD + 1)) void corr2d_fwd_kernel(C2Set a, int B, int C, int H, int W) {
-  constexpr int ND = 2 * MD + 1;
-  constexpr int SR = TY + 2 * MD;        // staged rows
-  constexpr int SCOLS = TX + 2 * MD;     // staged cols (multiple of 4 for MD in {2,4}; padded below)
-  constexpr int SW = (SCOLS + 3) / 4 * 4;  // row stride, 16-B aligned for ds_read_b128
-  constexpr int NT = 64 * ND;
-  __shared__ __attribute__((aligned(16))) float s2[CC][SR][SW];
-  __shared__ __attribute__((aligned(16))) float s1[CC][TY][TX];
+// 4 consecutive floats at any dword alignment: gfx950 global memory takes multi-dword accesses at 4-byte
+// alignment (feature rows are W = 57, 113, ... floats long, so row starts are not 16-byte aligned)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
-  const int set = blockIdx.z / B, b = blockIdx.z - set * B;
-  const float* __restrict__ f1 = a.f1[set];
-  const float* __restrict__ f2 = a.f2[set];
-  const float* __restrict__ st1 = a.st1[set];
-  const float* __restrict__ st2 = a.st2[set];
-  float* __restrict__ out = a.out[set];
-  const int y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
-  const int t = threadIdx.x;
-  const int lane = t & 63, dy = t >> 6;  // wave index = displacement row
-  const int qy = lane >> 3, qx = (lane & 7) * 4;
-  const size_t HW = (size_t)H * W;
-  const float* f1b = f1 + (size_t)b * C * HW;
-  const float* f2b = f2 + (size_t)b * C * HW;
-
-  float acc[4][ND];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < ND; ++j) acc[i][j] = 0.f;
-
-  for (int c0 = 0; c0 < C; c0 += CC) {
-    // stage the f2 window and the f1 tile of CC channels (zeros outside image / channel range)
-    for (int i = t; i < CC * SR * SCOLS; i += NT) {
-      const int c = i / (SR * SCOLS), rem = i - c * (SR * SCOLS);
-      const int r = rem / SCOLS, col = rem - r * SCOLS;
-      const int gy = y0 + r - MD, gx = x0 + col - MD;
-      float v = 0.f;
-      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        v = f2b[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
-        // normalize_features folded into the load (§8f.4): the zero padding applies AFTER it
-        if (st2) { const float* q = st2 + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
-      }
-      s2[c][r][col] = v;
-    }
-    for (int i = t; i < CC * TY * TX; i += NT) {
-      const int c = i / (TY * TX), rem = i - c * (TY * TX);
-      const int r = rem / TX, col = rem - r * TX;
-      const int gy = y0 + r, gx = x0 + col;
-      float v = 0.f;
-      if (c0 + c < C && gy < H && gx < W) {
-        v = f1b[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
-        if (st1) { const float* q = st1 + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
-      }
-      s1[c][r][col] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(&s1[c][qy][qx]);
-      float row[4 + 2 * MD + 3];
-      const float* rp = &s2[c][qy + dy][qx];
-#pragma unroll
-      for (int k = 0; k < (4 + 2 * MD + 3) / 4; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
-        row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
-      }
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < ND; ++j) acc[i][j] = fmaf(av[i], row[i + j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-
-  const int y = y0 + qy;
-  if (y >= H) return;
-  const float fC = (float)C;
-  float* ob = out + ((size_t)b * ND * ND + (size_t)dy * ND) * HW + (size_t)y * W;
-#pragma unroll
-  for (int j = 0; j < ND; ++j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = x0 + qx + i;
-      if (x < W) ob[(size_t)j * HW + x] = acc[i][j] / fC;  // torch.mean = sum / C
-    }
+__device__ __forceinline__ void store4_masked(float* __restrict__ p, float4 v, int mask) {
+  if (mask == 0xF) {
+    f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *reinterpret_cast<f4u*>(p) = t;
+  } else {
+    if (mask & 1) p[0] = v.x;
+    if (mask & 2) p[1] = v.y;
+    if (mask & 4) p[2] = v.z;
+    if (mask & 8) p[3] = v.w;
   }
 }
 
-// grad[c,p] = (1/C) sum_d g(d,p) * other[c, p+d];  z < B: (g = gout, other = f2) -> grad_f1;
-// z >= B: (g = gout transposed on the fly, other = f1) -> grad_f2.
-template <int MD>
-__global__ __launch_bounds__(256) void corr2d_bwd_kernel(C2Set a, int B, int C, int H, int W) {
-  constexpr int ND = 2 * MD + 1;
-  constexpr int SR = TY + 2 * MD, SW = TX + 2 * MD;
-  __shared__ float s[CC][SR][SW];
+// bit e: column gx + e of a valid row is inside the image
+__device__ __forceinline__ int row_mask(bool rowok, int gx, int W) {
+  if (!rowok) return 0;
+  return ((unsigned)gx < (unsigned)W ? 1 : 0) | ((unsigned)(gx + 1) < (unsigned)W ? 2 : 0) |
+         ((unsigned)(gx + 2) < (unsigned)W ? 4 : 0) | ((unsigned)(gx + 3) < (unsigned)W ? 8 : 0);
+}
 
-  const int set = blockIdx.z / (2 * B), zr = blockIdx.z - set * 2 * B;
-  const bool second = zr >= B;
-  const int b = second ? zr - B : zr;
+__device__ __forceinline__ float4 keep4(float4 v, int mask) {
+  return make_float4((mask & 1) ? v.x : 0.f, (mask & 2) ? v.y : 0.f, (mask & 4) ? v.z : 0.f, (mask & 8) ? v.w : 0.f);
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear id; each XCD has its own L2.  A 1-D grid is re-mapped so
+// that every XCD works on one contiguous range of logical tiles: x / y neighbours (which share halo rows of the
+// inputs and, with W % 32 != 0, cache lines of the outputs) then meet in the same L2.
+__device__ __forceinline__ long long xcd_tile(long long id, long long total) {
+  const long long per = total / 8;
+  return id < per * 8 ? (id & 7) * per + (id >> 3) : id;
+}
+
+// lane -> (row, quad) of the 8 x 8 quads of a tile, chosen for ds_read_b128: the LDS serves a wave's 16-byte reads in
+// four fixed groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32), 64 banks of 4 bytes.  A
+// group is mapped to the 8 quads of row r and of row r + 4: with the staged row pitch of 40 floats the two rows
+// start 160 floats = 32 banks apart, so the 16 reads cover all 64 banks once -- conflict-free -- where the plain
+// (lane / 8, lane % 8) order gives 2- to 3-way conflicts.
+__device__ __forceinline__ void lane_quad(int lane, int& qy, int& qx) {
+  const int code = (0x73261540u >> (4 * ((lane & 31) >> 2))) & 7;  // (group-in-half << 2) | rank of this lane quartet
+  const int g = (code & 3) * 4 + (lane & 3);                        // 0 .. 15 inside the group
+  qy = 2 * (lane >> 5) + (code >> 2) + 4 * (g >> 3);
+  qx = (g & 7) * 4;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor its builtins)
+// Loads go through a buffer descriptor over the rest of the tensor: every staged vector is ONE unconditional
+// buffer_load_dwordx4 -- no per-lane branch, so the loads of a chunk are all in flight together (with a masked
+// global load the compiler waits after every vector) -- and the elements outside the image are cleared by mask
+// afterwards.  A vector that leaves the tensor (before its first or past its last float) reads 0 there: the
+// range check is per dword.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* base, long long floats) {
+  const long long bytes = floats * 4;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes,
+                                           0x00020000);
+}
+__device__ __forceinline__ float4 bload4(rsrc_t r, int off_floats) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, off_floats * 4, 0, 0);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
+// The staged window of one tile: CH channels x (TY + 2 md) rows x SV float4, as per-thread items whose geometry
+// (offset inside a channel group, LDS offset, element mask) is fixed for the whole workgroup.
+template <int MD, int CH, int NT>
+struct Window {
+  static constexpr int SR = TY + 2 * MD, SV = (TX + 2 * MD + 3) / 4;
+  static constexpr int SW = 40;  // row pitch: see lane_quad
+  static_assert(4 * SV <= SW, "staged row fits the pitch");
+  static constexpr int N = CH * SR * SV, K = (N + NT - 1) / NT;
+  static constexpr int FLOATS = CH * SR * SW;
+  int off[K], lo[K], cm[K];  // offset (floats), LDS offset, (channel << 4) | mask
+
+  __device__ __forceinline__ void init(int t, int y0, int x0, int H, int W) {
+    const int HW = H * W;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = t + NT * k;
+      const int c = i / (SR * SV), rem = i - c * (SR * SV);
+      const int r = rem / SV, v = rem - r * SV;
+      const int gy = y0 + r - MD, gx = x0 + 4 * v - MD;
+      off[k] = c * HW + gy * W + gx;
+      lo[k] = (c * SR + r) * SW + 4 * v;
+      cm[k] = (c << 4) | (i < N ? row_mask(gy >= 0 && gy < H, gx, W) : 0);
+    }
+  }
+  __device__ __forceinline__ void load(float4 (&pf)[K], rsrc_t r, int coff) const {
+#pragma unroll
+    for (int k = 0; k < K; ++k) pf[k] = bload4(r, coff + off[k]);
+  }
+  // st (nullable) = (mean, rstd) of the group's first channel: normalize_features folded in (§8f.4) -- the zero
+  // padding applies AFTER it
+  __device__ __forceinline__ void put(const float4 (&pf)[K], float* __restrict__ s, int t,
+                                      const float* __restrict__ st, int nch) const {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (t + NT * k >= N) continue;
+      const int c = cm[k] >> 4;
+      float4 v = pf[k];
+      if (st != nullptr) {
+        const float2 q = *reinterpret_cast<const float2*>(st + 2 * (c < nch ? c : 0));
+        v = make_float4((v.x - q.x) * q.y, (v.y - q.x) * q.y, (v.z - q.x) * q.y, (v.w - q.x) * q.y);
+      }
+      *reinterpret_cast<float4*>(s + lo[k]) = keep4(v, c < nch ? (cm[k] & 0xF) : 0);
+    }
+  }
+};
+#endif
+
+// Forward.  One workgroup = one 8 x 32-pixel tile of one sample; lane = a quad of 4 consecutive pixels, wave w owns
+// the displacement rows 3 w .. 3 w + 2, so a lane keeps 4 x (2md+1) x 3 accumulators and does 36 FMAs (md = 4) per
+// 3 ds_read_b128 of an f2 row.  Channels stream through two LDS buffers in chunks of 8: the loads of chunk k + 1
+// (16-byte, dword-aligned; geometry precomputed, no div/mod, no branches) are in flight while chunk k is
+// computed; one barrier per chunk.  The epilogue writes 16-byte vectors.
+template <int MD, int DPW>
+__global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_fwd_q_kernel(C2Set a, int B, int C, int H, int W) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int ND = 2 * MD + 1;
+  constexpr int NWV = (ND + DPW - 1) / DPW, NT = 64 * NWV;
+  using W2 = Window<MD, CC, NT>;
+  constexpr int SR = W2::SR, SW = W2::SW;
+  constexpr int N1 = CC * TY * (TX / 4), K1 = (N1 + NT - 1) / NT;
+  constexpr int P1 = 40;  // f1 row pitch, as the window's (lane_quad)
+  constexpr int BUF = W2::FLOATS + CC * TY * P1;
+  constexpr int RV = (4 + 2 * MD + 3) / 4;  // float4 reads per f2 row segment
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+  const int ntx = (W + TX - 1) / TX, nty = (H + TY - 1) / TY;
+  long long tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int x0 = (int)(tile % ntx) * TX; tile /= ntx;
+  const int y0 = (int)(tile % nty) * TY; tile /= nty;
+  const int b = (int)(tile % B), set = (int)(tile / B);
+  const float* __restrict__ st1 = a.st1[set];
+  const float* __restrict__ st2 = a.st2[set];
+  float* __restrict__ out = a.out[set];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6;
+  int qy, qx;
+  lane_quad(lane, qy, qx);
+  const int HW = H * W;
+  const long long rest = (long long)(B - b) * C * HW;
+  const rsrc_t r1 = make_rsrc(a.f1[set] + (size_t)b * C * HW, rest);
+  const rsrc_t r2 = make_rsrc(a.f2[set] + (size_t)b * C * HW, rest);
+  if (st1 != nullptr) { st1 += 2 * (size_t)b * C; st2 += 2 * (size_t)b * C; }
+
+  W2 w2;
+  w2.init(t, y0, x0, H, W);
+  int off1[K1], lo1[K1], cm1[K1];
+#pragma unroll
+  for (int k = 0; k < K1; ++k) {
+    const int i = t + NT * k;
+    const int c = i / (TY * (TX / 4)), rem = i - c * (TY * (TX / 4));
+    const int r = rem / (TX / 4), v = rem - r * (TX / 4);
+    const int gy = y0 + r, gx = x0 + 4 * v;
+    off1[k] = c * HW + gy * W + gx;
+    lo1[k] = W2::FLOATS + (c * TY + r) * P1 + 4 * v;
+    cm1[k] = (c << 4) | (i < N1 ? row_mask(gy < H, gx, W) : 0);
+  }
+  float4 pf2[W2::K], pf1[K1];
+  auto fetch = [&](int c0) {
+    w2.load(pf2, r2, c0 * HW);
+#pragma unroll
+    for (int k = 0; k < K1; ++k) pf1[k] = bload4(r1, c0 * HW + off1[k]);
+  };
+  auto put = [&](float* s, int c0) {
+    const int nch = C - c0;
+    w2.put(pf2, s, t, st2 != nullptr ? st2 + 2 * c0 : nullptr, nch);
+#pragma unroll
+    for (int k = 0; k < K1; ++k) {
+      if (t + NT * k >= N1) continue;
+      const int c = cm1[k] >> 4;
+      float4 v = pf1[k];
+      if (st1 != nullptr) {
+        const float2 q = *reinterpret_cast<const float2*>(st1 + 2 * (c0 + (c < nch ? c : 0)));
+        v = make_float4((v.x - q.x) * q.y, (v.y - q.x) * q.y, (v.z - q.x) * q.y, (v.w - q.x) * q.y);
+      }
+      *reinterpret_cast<float4*>(s + lo1[k]) = keep4(v, c < nch ? (cm1[k] & 0xF) : 0);
+    }
+  };
+
+  float acc[DPW][4][ND];
+#pragma unroll
+  for (int d = 0; d < DPW; ++d)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < ND; ++j) acc[d][i][j] = 0.f;
+
+  fetch(0);
+  put(lds, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    const bool more = c0 + CC < C;
+    fetch(more ? c0 + CC : c0);  // unconditional (a conditional load becomes a copy behind a wait); unused at the end
+    const float* s2 = lds + buf * BUF;
+    const float* s1 = s2 + W2::FLOATS;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      const float4 av4 = *reinterpret_cast<const float4*>(s1 + (c * TY + qy) * P1 + qx);
+      const float av[4] = {av4.x, av4.y, av4.z, av4.w};
+#pragma unroll
+      for (int d = 0; d < DPW; ++d) {
+        const int dy = DPW * wv + d;
+        if (dy >= ND) continue;  // wave-uniform
+        float row[4 * RV];
+        const float* rp = s2 + (c * SR + qy + dy) * SW + qx;
+#pragma unroll
+        for (int k = 0; k < RV; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
+          row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) acc[d][i][j] = fmaf(av[i], row[i + j], acc[d][i][j]);
+      }
+    }
+    if (more) put(lds + (buf ^ 1) * BUF, c0 + CC);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  const int y = y0 + qy, x = x0 + qx;
+  const int smask = row_mask(y < H, x, W);
+  if (smask == 0) return;
+  const float fC = (float)C;
+#pragma unroll
+  for (int d = 0; d < DPW; ++d) {
+    const int dy = DPW * wv + d;
+    if (dy >= ND) continue;
+    float* ob = out + ((size_t)b * ND * ND + (size_t)dy * ND) * HW + (size_t)y * W + x;
+#pragma unroll
+    for (int j = 0; j < ND; ++j)  // torch.mean = sum / C
+      store4_masked(ob + (size_t)j * HW,
+                    make_float4(acc[d][0][j] / fC, acc[d][1][j] / fC, acc[d][2][j] / fC, acc[d][3][j] / fC), smask);
+  }
+#endif
+}
+
+// Backward.  grad[c,p] = (1/C) sum_d g(d,p) * other[c, p+d];  first: (g = gout, other = f2) -> grad_f1;  second:
+// (g = gout transposed on the fly, gT[d,q] = g[-d, q+d], other = f1) -> grad_f2.  One workgroup = one 8 x 32 tile,
+// 16 channels of one sample; their `other` window is staged once (41 KB).  lane = a quad of 4 consecutive pixels,
+// wave w owns the displacement rows 3 w .. 3 w + 2: it loads the 4 x (2md+1) upstream gradients of a row as
+// 16-byte vectors (each gradient value is read once per workgroup) and runs them against all 16 channels --
+// 36 FMAs (md = 4) per 3 ds_read_b128.  The three partial sums meet in LDS; wave 0 writes 16-byte vectors.
+// No atomics, bitwise reproducible.
+constexpr int CBW = 16;
+template <int MD, int DPW>
+__global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_bwd_q_kernel(C2Set a, int B, int C, int H, int W) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int ND = 2 * MD + 1;
+  constexpr int NWV = (ND + DPW - 1) / DPW, NT = 64 * NWV;
+  using WO = Window<MD, CBW, NT>;
+  constexpr int SR = WO::SR, SW = WO::SW;
+  constexpr int RV = (4 + 2 * MD + 3) / 4;
+  constexpr int RED = (NWV - 1) * CBW * 4 * 64;  // the partial sums of waves 1.. (float4-interleaved by lane)
+  constexpr int LDSF = WO::FLOATS > RED ? WO::FLOATS : RED;
+  __shared__ __attribute__((aligned(16))) float s[LDSF];
+
+  const int CG = (C + CBW - 1) / CBW;
+  const int ntx = (W + TX - 1) / TX, nty = (H + TY - 1) / TY;
+  long long tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int x0 = (int)(tile % ntx) * TX; tile /= ntx;
+  const int y0 = (int)(tile % nty) * TY; tile /= nty;
+  const int cg = (int)(tile % CG); tile /= CG;
+  const int b = (int)(tile % B); tile /= B;
+  const bool second = (tile & 1) != 0;
+  const int set = (int)(tile >> 1);
   float* __restrict__ grad = second ? a.g2[set] : a.g1[set];
   if (grad == nullptr) return;  // uniform per block
   const float* __restrict__ other = second ? a.f1[set] : a.f2[set];
   const float* __restrict__ ost = second ? a.st1[set] : a.st2[set];  // moments of `other` (NULL: plain)
-  const float* __restrict__ gout = a.gout[set];
-  const int y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
   const int t = threadIdx.x;
-  const int py = t / TX, px = t % TX;
-  const int y = y0 + py, x = x0 + px;
-  const bool live = (y < H && x < W);
-  const size_t HW = (size_t)H * W;
-  const float* gb = gout + (size_t)b * ND * ND * HW;
-  const float* ob = other + (size_t)b * C * HW;
+  const int lane = t & 63, wv = t >> 6;
+  int qy, qx;
+  lane_quad(lane, qy, qx);
+  const int HW = H * W;
+  const int c0 = cg * CBW;
+  const int y = y0 + qy, x = x0 + qx;
+  const int pmask = row_mask(y < H, x, W);  // this quad's pixels inside the image
 
-  // this pixel's (2md+1)^2 upstream gradients
-  float g[ND][ND];
+  // this wave's upstream gradients: rows j = 3 wv .. 3 wv + 2 of the displacement window, all in flight at once
+  const rsrc_t rg = make_rsrc(a.gout[set] + (size_t)b * ND * ND * HW, (long long)(B - b) * ND * ND * HW);
+  float4 g[DPW][ND];
 #pragma unroll
-  for (int j = 0; j < ND; ++j)
+  for (int d = 0; d < DPW; ++d) {
+    const int j = DPW * wv + d;
+    if (j >= ND) continue;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-      float v = 0.f;
-      if (live) {
-        if (!second) {
-          v = gb[(size_t)(j * ND + i) * HW + (size_t)y * W + x];
-        } else {
-          // gT[d, q] = g[-d, q + d]
-          const int yy = y + (j - MD), xx = x + (i - MD);
-          if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-            v = gb[(size_t)((ND - 1 - j) * ND + (ND - 1 - i)) * HW + (size_t)yy * W + xx];
-        }
-      }
-      g[j][i] = v;
+      // first: g[(j,i), p];  second: gT[(j,i), q] = g[(ND-1-j, ND-1-i), q + d]
+      const int plane = second ? (ND - 1 - j) * ND + (ND - 1 - i) : j * ND + i;
+      const int yy = second ? y + (j - MD) : y, xx = second ? x + (i - MD) : x;
+      g[d][i] = bload4(rg, plane * HW + yy * W + xx);
     }
-
-  const float fC = (float)C;
-  for (int c0 = 0; c0 < C; c0 += CC) {
-    for (int i = t; i < CC * SR * SW; i += 256) {
-      const int c = i / (SR * SW), rem = i - c * (SR * SW);
-      const int r = rem / SW, col = rem - r * SW;
-      const int gy = y0 + r - MD, gx = x0 + col - MD;
-      float v = 0.f;
-      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        v = ob[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
-        if (ost) { const float* q = ost + 2 * ((size_t)b * C + c0 + c); v = (v - q[0]) * q[1]; }
-      }
-      s[c][r][col] = v;
-    }
-    __syncthreads();
-    for (int c = 0; c < CC && c0 + c < C; ++c) {
-      float a = 0.f;
-#pragma unroll
-      for (int j = 0; j < ND; ++j)
-#pragma unroll
-        for (int i = 0; i < ND; ++i) a = fmaf(g[j][i], s[c][py + j][px + i], a);
-      if (live) grad[((size_t)b * C + c0 + c) * HW + (size_t)y * W + x] = a / fC;
-    }
-    __syncthreads();
   }
+  {
+    WO wo;
+    wo.init(t, y0, x0, H, W);
+    float4 pf[WO::K];
+    wo.load(pf, make_rsrc(other + ((size_t)b * C + c0) * HW, ((long long)(B - b) * C - c0) * HW), 0);
+    wo.put(pf, s, t, ost != nullptr ? ost + 2 * ((size_t)b * C + c0) : nullptr, C - c0);
+  }
+#pragma unroll
+  for (int d = 0; d < DPW; ++d) {
+    const int j = DPW * wv + d;
+    if (j >= ND) continue;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int yy = second ? y + (j - MD) : y, xx = second ? x + (i - MD) : x;
+      g[d][i] = keep4(g[d][i], row_mask(yy >= 0 && yy < H, xx, W) & pmask);
+    }
+  }
+  __syncthreads();
+
+  float acc[CBW][4];
+#pragma unroll
+  for (int c = 0; c < CBW; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = 0.f;
+
+#pragma unroll
+  for (int d = 0; d < DPW; ++d) {
+    const int j = DPW * wv + d;
+    if (j >= ND) continue;  // wave-uniform
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+      float row[4 * RV];
+      const float* rp = s + (c * SR + qy + j) * SW + qx;
+#pragma unroll
+      for (int k = 0; k < RV; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
+        row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        acc[c][0] = fmaf(g[d][i].x, row[i], acc[c][0]);
+        acc[c][1] = fmaf(g[d][i].y, row[i + 1], acc[c][1]);
+        acc[c][2] = fmaf(g[d][i].z, row[i + 2], acc[c][2]);
+        acc[c][3] = fmaf(g[d][i].w, row[i + 3], acc[c][3]);
+      }
+    }
+  }
+
+  if (NWV > 1) {
+    __syncthreads();  // everyone is done with the window
+    if (wv > 0) {
+      float* rp = s + (size_t)(wv - 1) * CBW * 256 + lane * 4;
+#pragma unroll
+      for (int c = 0; c < CBW; ++c)
+        *reinterpret_cast<float4*>(rp + c * 256) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) {
+      const float* rp = s + (size_t)(w - 1) * CBW * 256 + lane * 4;
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(rp + c * 256);
+        acc[c][0] += v.x; acc[c][1] += v.y; acc[c][2] += v.z; acc[c][3] += v.w;
+      }
+    }
+  }
+  if (pmask == 0) return;
+  const float fC = (float)C;
+  float* op = grad + ((size_t)b * C + c0) * HW + (size_t)y * W + x;
+#pragma unroll
+  for (int c = 0; c < CBW; ++c)
+    if (c0 + c < C)
+      store4_masked(op + (size_t)c * HW, make_float4(acc[c][0] / fC, acc[c][1] / fC, acc[c][2] / fC, acc[c][3] / fC), pmask);
+#endif
 }
 
 // ---- coarse pyramid levels: direct kernels (h*w <= 512) -----------------------------------------------
@@ -338,8 +559,9 @@ int launch_small_bwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st)
 template <int MD>
 int launch_fwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st) {
   if (H * W <= kSmallHW) return launch_small_fwd<MD>(a, B, C, H, W, st);
-  dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), B * a.nsets);
-  hipLaunchKernelGGL(corr2d_fwd_kernel<MD>, grid, dim3(64 * (2 * MD + 1)), 0, st, a, B, C, H, W);
+  const dim3 grid((unsigned)((long long)fs::cdiv(W, TX) * fs::cdiv(H, TY) * B * a.nsets));
+  constexpr int DPW = FS_C2_FWD_DPW;
+  hipLaunchKernelGGL((corr2d_fwd_q_kernel<MD, DPW>), grid, dim3(64 * ((2 * MD + DPW) / DPW)), 0, st, a, B, C, H, W);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -347,15 +569,17 @@ int launch_fwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st) {
 template <int MD>
 int launch_bwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st) {
   if (H * W <= kSmallHW) return launch_small_bwd<MD>(a, B, C, H, W, st);
-  dim3 grid(fs::cdiv(W, TX), fs::cdiv(H, TY), 2 * B * a.nsets);
-  hipLaunchKernelGGL(corr2d_bwd_kernel<MD>, grid, dim3(256), 0, st, a, B, C, H, W);
+  const dim3 grid((unsigned)((long long)fs::cdiv(W, TX) * fs::cdiv(H, TY) * 2 * B * a.nsets * fs::cdiv(C, CBW)));
+  constexpr int DPW = FS_C2_BWD_DPW;
+  hipLaunchKernelGGL((corr2d_bwd_q_kernel<MD, DPW>), grid, dim3(64 * ((2 * MD + DPW) / DPW)), 0, st, a, B, C, H, W);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
 int check_shape(int B, int C, int H, int W, int md) {
   if (B < 1 || C < 1 || H < 1 || W < 1) return FS_ERR_SHAPE;
-  if (4 * (long long)B > 65535 || fs::cdiv(H, TY) > 65535) return FS_ERR_SHAPE;
+  if ((long long)fs::cdiv(W, TX) * fs::cdiv(H, TY) * 4 * B * fs::cdiv(C, CBW) >= (1ll << 31)) return FS_ERR_SHAPE;  // 1-D grids
+  if ((long long)C * H * W >= (1ll << 29) || 81ll * H * W >= (1ll << 29)) return FS_ERR_SHAPE;  // 32-bit byte offsets inside a sample
   if (md < 1 || md > 4) return FS_ERR_ARG;
   return FS_OK;
 }

@@ -28,3 +28,7 @@ print("==== all aten ops by device time ====")
 for e in sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)[:40]:
     if e.self_device_time_total > 50:
         print("%-60s n=%4d  self %8.3f ms" % (e.key[:60], e.count, e.self_device_time_total / 1e3))
+print("==== aten ops by input shape ====")
+for e in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total):
+    if e.key.startswith("aten::") and e.self_device_time_total > 20:
+        print("%-28s n=%4d  self %8.3f ms  %s" % (e.key, e.count, e.self_device_time_total / 1e3, str(e.input_shapes)[:150]))
