@@ -9,35 +9,29 @@
 // f2 reads as 0 outside the image; dy-major channel order (pinned by Corr_pyTorch,
 // UPFlow/utils/pytorch_correlation.py:27-50).
 //
-// Forward.  One workgroup = one 8x32-pixel tile of one sample, 2md+1 waves: wave `dy` owns one
-// displacement row, lane = a quad of 4 consecutive pixels, so each lane keeps 4 x (2md+1)
-// accumulators.  Channels are streamed through LDS in chunks of 8: the f2 search window
-// (tile + md halo) and the f1 tile are loaded once per chunk with coalesced rows, then every
-// lane reads its f2 row segment (4 + 2md floats) as ds_read_b128 and does 4*(2md+1) FMAs per
-// 3 LDS instructions -- VALU-bound, not LDS-bound.  HBM traffic is the algorithmic
-// 4*(2C + (2md+1)^2) B/pixel; the halo re-reads of f2 are served by L2.
-// The channel reduction of the tiled kernel runs in registers (lanes = pixels).  That form needs pixels:
-// the three coarsest UPFlow levels at C3 are (C, h, w) = (196, 3, 8), (128, 5, 15), (96, 10, 29) -- 24 .. 290
-// pixels per sample, C >> pixels -- where an 8x32 tile is mostly empty and the kernel is a serial chain of
-// C/8 stage-barrier-compute rounds (86 us for 150 K output floats).  Those levels (h*w <= 512) run the
-// direct kernels below instead: no LDS, no barrier, one thread per (sample, displacement, pixel) output and
-// channel slice -- the C range is split over 1..8 lane groups of a wave and reduced with wave shuffles
-// (2 * log2(slices) DPP steps per output) -- so that even a B = 2 launch fills the chip.
+// Tiled kernels (corr2d_fwd_q_kernel / corr2d_bwd_q_kernel, described at their definitions): one workgroup = one
+// 8 x 32-pixel tile, lane = a quad of 4 consecutive pixels, the search window (tile + md halo) staged through LDS
+// by unconditional 16-byte buffer loads at dword alignment, packed-FP32 FMAs on aligned register pairs, 16-byte
+// stores, tiles dealt to the XCDs in contiguous ranges.  Both are bound by VALU instruction issue; HBM traffic is
+// the algorithmic 4*(2C + (2md+1)^2) B/pixel forward, 4*(4C + (2md+1)^2) backward; halo re-reads hit L2.
+// They need pixels: the coarsest UPFlow levels at C3 are (C, h, w) = (196, 3, 8) and (128, 5, 15), 24 / 75 pixels
+// per sample, C >> pixels, where an 8 x 32 tile is mostly empty and the forward kernel is a serial chain of C/8
+// stage-barrier-compute rounds.  Those run the direct kernels instead (thresholds: kSmall* below): no LDS, no
+// barrier, one thread per (sample, displacement, pixel) output and channel slice -- the C range is split over
+// 1..8 lane groups of a wave and reduced with wave shuffles -- so that even a B = 2 launch fills the chip.
 //
 // Backward.  grad_f1[c,p] = (1/C) sum_d g[d,p] f2[c,p+d] is a gather;  grad_f2 is the same gather
 // with the roles swapped and the displacement negated:  grad_f2[c,q] = (1/C) sum_d gT[d,q] f1[c,q+d]
-// with gT[d,q] = g[-d, q+d] (0 when q+d is outside).  One launch computes both (blockIdx.z picks),
-// no atomics, bitwise reproducible: thread = pixel, its (2md+1)^2 upstream gradients live in
-// registers, channel chunks of the other feature map are staged in LDS.
+// with gT[d,q] = g[-d, q+d] (0 when q+d is outside).  One launch computes both, no atomics, bitwise reproducible.
 #include "common.hpp"
 
 namespace {
 
-constexpr int TY = 8, TX = 32, CC = 8;
+constexpr int TY = 8, TX = 32;
+[[maybe_unused]] constexpr int CC = 8;  // channels per staged chunk of the forward kernel
 // displacement rows per wave of the tiled kernels (forward: 1 -> 2md+1 waves, 36 accumulators per lane at md = 4:
 // 1 / 2 / 3 rows per wave measured 24 / 27 / 37 us at the (64, 19, 57) level, equal at (32, 38, 113))
 #define FS_C2_FWD_DPW 1
-#define FS_C2_BWD_DPW 3
 
 // Two problems of one shape per launch (UPFlow correlates both directions at every level,
 // upflow.py:649,652); pointers of the second problem may equal the first's.
@@ -57,6 +51,7 @@ struct C2Set {
 // 4 consecutive floats at any dword alignment: gfx950 global memory takes multi-dword accesses at 4-byte
 // alignment (feature rows are W = 57, 113, ... floats long, so row starts are not 16-byte aligned)
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void store4_masked(float* __restrict__ p, float4 v, int mask) {
   if (mask == 0xF) {
@@ -84,9 +79,16 @@ __device__ __forceinline__ float4 keep4(float4 v, int mask) {
 // Workgroups are dealt to the 8 XCDs round-robin by linear id; each XCD has its own L2.  A 1-D grid is re-mapped so
 // that every XCD works on one contiguous range of logical tiles: x / y neighbours (which share halo rows of the
 // inputs and, with W % 32 != 0, cache lines of the outputs) then meet in the same L2.
-__device__ __forceinline__ long long xcd_tile(long long id, long long total) {
-  const long long per = total / 8;
+__device__ __forceinline__ unsigned xcd_tile(unsigned id, unsigned total) {
+  const unsigned per = total >> 3;
   return id < per * 8 ? (id & 7) * per + (id >> 3) : id;
+}
+
+// sum / C as torch.mean computes it: a multiplication by 1/C is the same float whenever C is a power of two
+// (every tiled UPFlow level), and ~10 instructions cheaper per value
+__device__ __forceinline__ float4 mean4(float4 v, float fC, float rC, bool pow2) {
+  return pow2 ? make_float4(v.x * rC, v.y * rC, v.z * rC, v.w * rC)
+              : make_float4(v.x / fC, v.y / fC, v.z / fC, v.w / fC);
 }
 
 // lane -> (row, quad) of the 8 x 8 quads of a tile, chosen for ds_read_b128: the LDS serves a wave's 16-byte reads in
@@ -105,17 +107,25 @@ __device__ __forceinline__ void lane_quad(int lane, int& qy, int& qx) {
 // Loads go through a buffer descriptor over the rest of the tensor: every staged vector is ONE unconditional
 // buffer_load_dwordx4 -- no per-lane branch, so the loads of a chunk are all in flight together (with a masked
 // global load the compiler waits after every vector) -- and the elements outside the image are cleared by mask
-// afterwards.  A vector that leaves the tensor (before its first or past its last float) reads 0 there: the
-// range check is per dword.
+// afterwards.  A vector that runs past the tensor's last float reads 0 there (the range check is per dword).
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const float* base, long long floats) {
   const long long bytes = floats * 4;
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes,
                                            0x00020000);
 }
+// (the descriptor starts at the tensor's first float, so only the one vector that straddles it has a negative
+// offset with live elements: it is loaded from offset 0 and shifted into place by fix_head -- a negative offset is
+// out of range as a whole, not per dword)
 __device__ __forceinline__ float4 bload4(rsrc_t r, int off_floats) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, off_floats * 4, 0, 0);
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (off_floats < 0 ? 0 : off_floats) * 4, 0, 0);
   return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ float4 fix_head(float4 v, int off_floats) {
+  if (off_floats >= 0 || off_floats <= -4) return v;
+  if (off_floats == -1) return make_float4(0.f, v.x, v.y, v.z);
+  if (off_floats == -2) return make_float4(0.f, 0.f, v.x, v.y);
+  return make_float4(0.f, 0.f, 0.f, v.x);
 }
 
 // The staged window of one tile: CH channels x (TY + 2 md) rows x SV float4, as per-thread items whose geometry
@@ -149,12 +159,12 @@ struct Window {
   // st (nullable) = (mean, rstd) of the group's first channel: normalize_features folded in (§8f.4) -- the zero
   // padding applies AFTER it
   __device__ __forceinline__ void put(const float4 (&pf)[K], float* __restrict__ s, int t,
-                                      const float* __restrict__ st, int nch) const {
+                                      const float* __restrict__ st, int nch, int coff) const {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (t + NT * k >= N) continue;
       const int c = cm[k] >> 4;
-      float4 v = pf[k];
+      float4 v = fix_head(pf[k], coff + off[k]);
       if (st != nullptr) {
         const float2 q = *reinterpret_cast<const float2*>(st + 2 * (c < nch ? c : 0));
         v = make_float4((v.x - q.x) * q.y, (v.y - q.x) * q.y, (v.z - q.x) * q.y, (v.w - q.x) * q.y);
@@ -184,10 +194,10 @@ __global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_fwd_q_kern
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
   const int ntx = (W + TX - 1) / TX, nty = (H + TY - 1) / TY;
-  long long tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int x0 = (int)(tile % ntx) * TX; tile /= ntx;
-  const int y0 = (int)(tile % nty) * TY; tile /= nty;
-  const int b = (int)(tile % B), set = (int)(tile / B);
+  unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int x0 = (int)(tile % (unsigned)ntx) * TX; tile /= (unsigned)ntx;
+  const int y0 = (int)(tile % (unsigned)nty) * TY; tile /= (unsigned)nty;
+  const int b = (int)(tile % (unsigned)B), set = (int)(tile / (unsigned)B);
   const float* __restrict__ st1 = a.st1[set];
   const float* __restrict__ st2 = a.st2[set];
   float* __restrict__ out = a.out[set];
@@ -196,9 +206,9 @@ __global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_fwd_q_kern
   int qy, qx;
   lane_quad(lane, qy, qx);
   const int HW = H * W;
-  const long long rest = (long long)(B - b) * C * HW;
-  const rsrc_t r1 = make_rsrc(a.f1[set] + (size_t)b * C * HW, rest);
-  const rsrc_t r2 = make_rsrc(a.f2[set] + (size_t)b * C * HW, rest);
+  const rsrc_t r1 = make_rsrc(a.f1[set], (long long)B * C * HW);
+  const rsrc_t r2 = make_rsrc(a.f2[set], (long long)B * C * HW);
+  const int boff = b * C * HW;
   if (st1 != nullptr) { st1 += 2 * (size_t)b * C; st2 += 2 * (size_t)b * C; }
 
   W2 w2;
@@ -216,13 +226,13 @@ __global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_fwd_q_kern
   }
   float4 pf2[W2::K], pf1[K1];
   auto fetch = [&](int c0) {
-    w2.load(pf2, r2, c0 * HW);
+    w2.load(pf2, r2, boff + c0 * HW);
 #pragma unroll
-    for (int k = 0; k < K1; ++k) pf1[k] = bload4(r1, c0 * HW + off1[k]);
+    for (int k = 0; k < K1; ++k) pf1[k] = bload4(r1, boff + c0 * HW + off1[k]);  // (never negative)
   };
   auto put = [&](float* s, int c0) {
     const int nch = C - c0;
-    w2.put(pf2, s, t, st2 != nullptr ? st2 + 2 * c0 : nullptr, nch);
+    w2.put(pf2, s, t, st2 != nullptr ? st2 + 2 * c0 : nullptr, nch, boff + c0 * HW);
 #pragma unroll
     for (int k = 0; k < K1; ++k) {
       if (t + NT * k >= N1) continue;
@@ -236,13 +246,20 @@ __global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_fwd_q_kern
     }
   };
 
-  float acc[DPW][4][ND];
+  // accumulators as aligned register pairs for v_pk_fma_f32: out(px i, dx j) += f1[i] * row[i + j], paired over j so
+  // that the row operand (row[i + j], row[i + j + 1]) starts at an even register: i even -> pairs j = (0,1), (2,3),
+  // .. and a single j = ND - 1;  i odd -> a single j = 0 and pairs j = (1,2), (3,4), ..
+  constexpr int NP = (ND - 1) / 2;
+  v2f accp[DPW][4][NP];
+  float accs[DPW][4];
 #pragma unroll
   for (int d = 0; d < DPW; ++d)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      accs[d][i] = 0.f;
 #pragma unroll
-      for (int j = 0; j < ND; ++j) acc[d][i][j] = 0.f;
+      for (int q = 0; q < NP; ++q) accp[d][i][q] = v2f{0.f, 0.f};
+    }
 
   fetch(0);
   put(lds, 0);
@@ -261,17 +278,22 @@ __global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_fwd_q_kern
       for (int d = 0; d < DPW; ++d) {
         const int dy = DPW * wv + d;
         if (dy >= ND) continue;  // wave-uniform
-        float row[4 * RV];
+        v2f r2[2 * RV];
         const float* rp = s2 + (c * SR + qy + dy) * SW + qx;
 #pragma unroll
         for (int k = 0; k < RV; ++k) {
           const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
-          row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+          r2[2 * k] = v2f{v.x, v.y}; r2[2 * k + 1] = v2f{v.z, v.w};
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          const v2f a2 = v2f{av[i], av[i]};
 #pragma unroll
-          for (int j = 0; j < ND; ++j) acc[d][i][j] = fmaf(av[i], row[i + j], acc[d][i][j]);
+          for (int q = 0; q < NP; ++q)
+            accp[d][i][q] = __builtin_elementwise_fma(a2, r2[(i + (i & 1)) / 2 + q], accp[d][i][q]);
+          const float rs = (i & 1) ? r2[(i - 1) / 2].y : r2[(i + ND - 1) / 2].x;
+          accs[d][i] = fmaf(av[i], rs, accs[d][i]);
+        }
       }
     }
     if (more) put(lds + (buf ^ 1) * BUF, c0 + CC);
@@ -282,47 +304,63 @@ __global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_fwd_q_kern
   const int y = y0 + qy, x = x0 + qx;
   const int smask = row_mask(y < H, x, W);
   if (smask == 0) return;
-  const float fC = (float)C;
+  const float fC = (float)C, rC = 1.0f / fC;
+  const bool pow2 = (C & (C - 1)) == 0;
 #pragma unroll
   for (int d = 0; d < DPW; ++d) {
     const int dy = DPW * wv + d;
     if (dy >= ND) continue;
     float* ob = out + ((size_t)b * ND * ND + (size_t)dy * ND) * HW + (size_t)y * W + x;
 #pragma unroll
-    for (int j = 0; j < ND; ++j)  // torch.mean = sum / C
-      store4_masked(ob + (size_t)j * HW,
-                    make_float4(acc[d][0][j] / fC, acc[d][1][j] / fC, acc[d][2][j] / fC, acc[d][3][j] / fC), smask);
+    for (int j = 0; j < ND; ++j) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // (i, j) lives in a pair or in the single of its parity class
+        const int jj = j - (i & 1);
+        v[i] = (i & 1) ? (j == 0 ? accs[d][i] : ((jj & 1) ? accp[d][i][jj / 2].y : accp[d][i][jj / 2].x))
+                       : (j == ND - 1 ? accs[d][i] : ((j & 1) ? accp[d][i][j / 2].y : accp[d][i][j / 2].x));
+      }
+      store4_masked(ob + (size_t)j * HW, mean4(make_float4(v[0], v[1], v[2], v[3]), fC, rC, pow2), smask);
+    }
   }
 #endif
 }
 
 // Backward.  grad[c,p] = (1/C) sum_d g(d,p) * other[c, p+d];  first: (g = gout, other = f2) -> grad_f1;  second:
-// (g = gout transposed on the fly, gT[d,q] = g[-d, q+d], other = f1) -> grad_f2.  One workgroup = one 8 x 32 tile,
-// 16 channels of one sample; their `other` window is staged once (41 KB).  lane = a quad of 4 consecutive pixels,
-// wave w owns the displacement rows 3 w .. 3 w + 2: it loads the 4 x (2md+1) upstream gradients of a row as
-// 16-byte vectors (each gradient value is read once per workgroup) and runs them against all 16 channels --
-// 36 FMAs (md = 4) per 3 ds_read_b128.  The three partial sums meet in LDS; wave 0 writes 16-byte vectors.
-// No atomics, bitwise reproducible.
-constexpr int CBW = 16;
-template <int MD, int DPW>
-__global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_bwd_q_kernel(C2Set a, int B, int C, int H, int W) {
+// (g = gout transposed on the fly, gT[d,q] = g[-d, q+d], other = f1) -> grad_f2.  The forward kernel with the roles
+// of channel and displacement exchanged: the reduction runs over d, the outputs are indexed by c.  One workgroup =
+// one 8 x 32 tile x 32 channels of one sample (all channels of the finest UPFlow level: the gradient tile is read
+// once per gradient), 8 waves x 2 channel PAIRS.  These kernels are bound by VALU instruction issue, not by LDS or
+// HBM (measured: 3500 instructions per wave around 648 useful v_pk_fma_f32), so the layout serves the packed FMA:
+// the `other` window sits in LDS with the two channels of a pair interleaved per pixel, [pair][row][x][2]; a
+// ds_read_b128 then returns aligned register pairs (c0, c1) and one v_pk_fma_f32 updates both channels of a pixel
+// with the gradient value broadcast by op_sel -- no register moves.  The upstream gradient passes through two
+// small LDS buffers one displacement row (2md+1 planes of the tile) at a time; every global load of the workgroup
+// is issued up front and consumed in issue order.  Thread -> staging item maps are shifts and masks only.
+// lane = a quad of 4 consecutive pixels.  No cross-wave reduction, no atomics, bitwise reproducible; 16-byte stores.
+constexpr int CBW = 32;
+template <int MD>
+__global__ __launch_bounds__(512) void corr2d_bwd_q_kernel(C2Set a, int B, int C, int H, int W) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int ND = 2 * MD + 1;
-  constexpr int NWV = (ND + DPW - 1) / DPW, NT = 64 * NWV;
-  using WO = Window<MD, CBW, NT>;
-  constexpr int SR = WO::SR, SW = WO::SW;
-  constexpr int RV = (4 + 2 * MD + 3) / 4;
-  constexpr int RED = (NWV - 1) * CBW * 4 * 64;  // the partial sums of waves 1.. (float4-interleaved by lane)
-  constexpr int LDSF = WO::FLOATS > RED ? WO::FLOATS : RED;
-  __shared__ __attribute__((aligned(16))) float s[LDSF];
+  constexpr int SR = TY + 2 * MD, SV = (TX + 2 * MD + 3) / 4;
+  constexpr int RV = (4 + 2 * MD + 3) / 4;    // float4 per channel of a row segment
+  constexpr int WP = 88;                       // window row pitch (2 channels x 40 px, + 8: rows r and r + 4 half a bank cycle apart)
+  constexpr int WPAIR = SR * WP;
+  constexpr int WFLOATS = (CBW / 2) * WPAIR;
+  constexpr int GP = 40;                       // row pitch of a staged gradient plane (lane_quad)
+  constexpr int GBUF = ND * TY * GP;           // one displacement row: ND planes x 8 rows
+  constexpr int KW = CBW / 4, KG = (ND + 7) / 8;
+  static_assert(SR <= 16 && SV <= 16 && 8 * SV <= WP, "staging maps");
+  __shared__ __attribute__((aligned(16))) float s[WFLOATS + 2 * GBUF];
 
   const int CG = (C + CBW - 1) / CBW;
   const int ntx = (W + TX - 1) / TX, nty = (H + TY - 1) / TY;
-  long long tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int x0 = (int)(tile % ntx) * TX; tile /= ntx;
-  const int y0 = (int)(tile % nty) * TY; tile /= nty;
-  const int cg = (int)(tile % CG); tile /= CG;
-  const int b = (int)(tile % B); tile /= B;
+  unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int x0 = (int)(tile % (unsigned)ntx) * TX; tile /= (unsigned)ntx;
+  const int y0 = (int)(tile % (unsigned)nty) * TY; tile /= (unsigned)nty;
+  const int cg = (int)(tile % (unsigned)CG); tile /= (unsigned)CG;
+  const int b = (int)(tile % (unsigned)B); tile /= (unsigned)B;
   const bool second = (tile & 1) != 0;
   const int set = (int)(tile >> 1);
   float* __restrict__ grad = second ? a.g2[set] : a.g1[set];
@@ -334,100 +372,138 @@ __global__ __launch_bounds__(64 * ((2 * MD + DPW) / DPW)) void corr2d_bwd_q_kern
   int qy, qx;
   lane_quad(lane, qy, qx);
   const int HW = H * W;
-  const int c0 = cg * CBW;
-  const int y = y0 + qy, x = x0 + qx;
-  const int pmask = row_mask(y < H, x, W);  // this quad's pixels inside the image
+  const int c0 = cg * CBW, nch = C - c0;
 
-  // this wave's upstream gradients: rows j = 3 wv .. 3 wv + 2 of the displacement window, all in flight at once
+  // window items: thread = (pair parity t >> 8, row (t >> 4) & 15, float4 column t & 15), item k = pair (t >> 8) + 2 k
+  const int wvx = t & 15, wr = (t >> 4) & 15, wp0 = t >> 8;
+  const int wgy = y0 + wr - MD, wgx = x0 + 4 * wvx - MD;
+  const bool wlive = wr < SR && wvx < SV;
+  const int wmask = wlive ? row_mask(wgy >= 0 && wgy < H, wgx, W) : 0;
+  const int woff = (b * C + c0) * HW + wgy * W + wgx;
+  const rsrc_t rw = make_rsrc(other, (long long)B * C * HW);
+  float4 pa[KW], pb[KW];
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    const int cp = wp0 + 2 * k;
+    pa[k] = bload4(rw, (2 * cp) * HW + woff);
+    pb[k] = bload4(rw, (2 * cp + 1) * HW + woff);
+  }
+
+  // gradient items of displacement row j: thread = (dx index i = (t >> 6) + 8 k, tile row (t >> 3) & 7, float4 t & 7)
+  //   first : g[(j, i)] at (y0 + r, x0 + 4 v)
+  //   second: gT[(j, i)] = g[(ND-1-j, ND-1-i)] at (y0 + r + j - MD, x0 + 4 v + i - MD)
+  const int gv = t & 7, gr = (t >> 3) & 7, gi0 = t >> 6;
+  const int ggy = y0 + gr, ggx = x0 + 4 * gv;
+  const int own = row_mask(ggy < H, ggx, W);
+  // (a gradient vector with live elements never starts before its plane: no negative offsets here)
   const rsrc_t rg = make_rsrc(a.gout[set] + (size_t)b * ND * ND * HW, (long long)(B - b) * ND * ND * HW);
-  float4 g[DPW][ND];
+  float4 pg[ND][KG];
+  auto gfetch = [&](int j) {
+    const int step = second ? (ND - 1 - j) * ND * HW + (j - MD) * W : j * ND * HW;
 #pragma unroll
-  for (int d = 0; d < DPW; ++d) {
-    const int j = DPW * wv + d;
-    if (j >= ND) continue;  // wave-uniform
+    for (int k = 0; k < KG; ++k) {
+      const int i = gi0 + 8 * k;
+      const int off = second ? (ND - 1 - i) * HW + ggy * W + ggx + (i - MD) : i * HW + ggy * W + ggx;
+      pg[j][k] = bload4(rg, off + step);
+    }
+  };
+  gfetch(0);
+  auto gput = [&](float* gs, int j) {
+    const int yy = ggy + (j - MD);
+    const bool rok = !second || (yy >= 0 && yy < H);
 #pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      // first: g[(j,i), p];  second: gT[(j,i), q] = g[(ND-1-j, ND-1-i), q + d]
-      const int plane = second ? (ND - 1 - j) * ND + (ND - 1 - i) : j * ND + i;
-      const int yy = second ? y + (j - MD) : y, xx = second ? x + (i - MD) : x;
-      g[d][i] = bload4(rg, plane * HW + yy * W + xx);
+    for (int k = 0; k < KG; ++k) {
+      const int i = gi0 + 8 * k;
+      if (i >= ND) continue;
+      const int m = !rok ? 0 : (second ? own & row_mask(true, ggx + i - MD, W) : own);
+      *reinterpret_cast<float4*>(gs + (i * TY + gr) * GP + 4 * gv) = keep4(pg[j][k], m);
+    }
+  };
+
+  // window: normalise, clear what lies outside the image / past the last channel, interleave the pair, store
+  if (wlive) {
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const int cp = wp0 + 2 * k;
+      float4 va = fix_head(pa[k], (2 * cp) * HW + woff), vb = fix_head(pb[k], (2 * cp + 1) * HW + woff);
+      if (ost != nullptr) {
+        const float* q = ost + 2 * ((size_t)b * C + c0);
+        const float2 qa = *reinterpret_cast<const float2*>(q + 2 * (2 * cp < nch ? 2 * cp : 0));
+        const float2 qb = *reinterpret_cast<const float2*>(q + 2 * (2 * cp + 1 < nch ? 2 * cp + 1 : 0));
+        va = make_float4((va.x - qa.x) * qa.y, (va.y - qa.x) * qa.y, (va.z - qa.x) * qa.y, (va.w - qa.x) * qa.y);
+        vb = make_float4((vb.x - qb.x) * qb.y, (vb.y - qb.x) * qb.y, (vb.z - qb.x) * qb.y, (vb.w - qb.x) * qb.y);
+      }
+      va = keep4(va, 2 * cp < nch ? wmask : 0);
+      vb = keep4(vb, 2 * cp + 1 < nch ? wmask : 0);
+      float* wp = s + cp * WPAIR + wr * WP + 8 * wvx;
+      *reinterpret_cast<float4*>(wp) = make_float4(va.x, vb.x, va.y, vb.y);
+      *reinterpret_cast<float4*>(wp + 4) = make_float4(va.z, vb.z, va.w, vb.w);
     }
   }
-  {
-    WO wo;
-    wo.init(t, y0, x0, H, W);
-    float4 pf[WO::K];
-    wo.load(pf, make_rsrc(other + ((size_t)b * C + c0) * HW, ((long long)(B - b) * C - c0) * HW), 0);
-    wo.put(pf, s, t, ost != nullptr ? ost + 2 * ((size_t)b * C + c0) : nullptr, C - c0);
-  }
+  gput(s + WFLOATS, 0);
+  // the remaining displacement rows: all in flight from here on, consumed in issue order (the window's registers
+  // are free now)
 #pragma unroll
-  for (int d = 0; d < DPW; ++d) {
-    const int j = DPW * wv + d;
-    if (j >= ND) continue;
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      const int yy = second ? y + (j - MD) : y, xx = second ? x + (i - MD) : x;
-      g[d][i] = keep4(g[d][i], row_mask(yy >= 0 && yy < H, xx, W) & pmask);
-    }
-  }
+  for (int j = 1; j < ND; ++j) gfetch(j);
   __syncthreads();
 
-  float acc[CBW][4];
+  v2f acc[2][4];  // [pair of this wave][pixel] = (channel 4 wv + 2 pair, + 1)
 #pragma unroll
-  for (int c = 0; c < CBW; ++c)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[c][i] = 0.f;
+    for (int i = 0; i < 4; ++i) acc[c][i] = v2f{0.f, 0.f};
 
 #pragma unroll
-  for (int d = 0; d < DPW; ++d) {
-    const int j = DPW * wv + d;
-    if (j >= ND) continue;  // wave-uniform
+  for (int j = 0; j < ND; ++j) {
+    const float* gs = s + WFLOATS + (j & 1) * GBUF + qy * GP + qx;
+    float4 g[ND];
 #pragma unroll
-    for (int c = 0; c < CBW; ++c) {
-      float row[4 * RV];
-      const float* rp = s + (c * SR + qy + j) * SW + qx;
+    for (int i = 0; i < ND; ++i) g[i] = *reinterpret_cast<const float4*>(gs + i * TY * GP);
 #pragma unroll
-      for (int k = 0; k < RV; ++k) {
+    for (int c = 0; c < 2; ++c) {
+      v2f r2[4 * RV];  // r2[m] = (c0, c1) at pixel qx + m of window row qy + j
+      const float* rp = s + (wv * 2 + c) * WPAIR + (qy + j) * WP + 2 * qx;
+#pragma unroll
+      for (int k = 0; k < 2 * RV; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
-        row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+        r2[2 * k] = v2f{v.x, v.y}; r2[2 * k + 1] = v2f{v.z, v.w};
       }
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
-        acc[c][0] = fmaf(g[d][i].x, row[i], acc[c][0]);
-        acc[c][1] = fmaf(g[d][i].y, row[i + 1], acc[c][1]);
-        acc[c][2] = fmaf(g[d][i].z, row[i + 2], acc[c][2]);
-        acc[c][3] = fmaf(g[d][i].w, row[i + 3], acc[c][3]);
+        acc[c][0] = __builtin_elementwise_fma(v2f{g[i].x, g[i].x}, r2[i], acc[c][0]);
+        acc[c][1] = __builtin_elementwise_fma(v2f{g[i].y, g[i].y}, r2[i + 1], acc[c][1]);
+        acc[c][2] = __builtin_elementwise_fma(v2f{g[i].z, g[i].z}, r2[i + 2], acc[c][2]);
+        acc[c][3] = __builtin_elementwise_fma(v2f{g[i].w, g[i].w}, r2[i + 3], acc[c][3]);
       }
+    }
+    // pin this row's FMAs here: left alone, the compiler sinks the FMAs of all rows behind the last barrier and
+    // parks every LDS read of the kernel in scratch on the way (2 KB per lane)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[c][i]));
+    if (j + 1 < ND) {
+      gput(s + WFLOATS + ((j + 1) & 1) * GBUF, j + 1);
+      __syncthreads();
     }
   }
 
-  if (NWV > 1) {
-    __syncthreads();  // everyone is done with the window
-    if (wv > 0) {
-      float* rp = s + (size_t)(wv - 1) * CBW * 256 + lane * 4;
-#pragma unroll
-      for (int c = 0; c < CBW; ++c)
-        *reinterpret_cast<float4*>(rp + c * 256) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
-    }
-    __syncthreads();
-    if (wv > 0) return;
-#pragma unroll
-    for (int w = 1; w < NWV; ++w) {
-      const float* rp = s + (size_t)(w - 1) * CBW * 256 + lane * 4;
-#pragma unroll
-      for (int c = 0; c < CBW; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(rp + c * 256);
-        acc[c][0] += v.x; acc[c][1] += v.y; acc[c][2] += v.z; acc[c][3] += v.w;
-      }
-    }
-  }
+  const int y = y0 + qy, x = x0 + qx;
+  const int pmask = row_mask(y < H, x, W);
   if (pmask == 0) return;
-  const float fC = (float)C;
-  float* op = grad + ((size_t)b * C + c0) * HW + (size_t)y * W + x;
+  const float fC = (float)C, rC = 1.0f / fC;
+  const bool pow2 = (C & (C - 1)) == 0;
+  const int cw = c0 + wv * 4;
+  float* op = grad + ((size_t)b * C + cw) * HW + (size_t)y * W + x;
 #pragma unroll
-  for (int c = 0; c < CBW; ++c)
-    if (c0 + c < C)
-      store4_masked(op + (size_t)c * HW, make_float4(acc[c][0] / fC, acc[c][1] / fC, acc[c][2] / fC, acc[c][3] / fC), pmask);
+  for (int c = 0; c < 2; ++c) {
+    if (cw + 2 * c < C)
+      store4_masked(op + (size_t)(2 * c) * HW,
+                    mean4(make_float4(acc[c][0].x, acc[c][1].x, acc[c][2].x, acc[c][3].x), fC, rC, pow2), pmask);
+    if (cw + 2 * c + 1 < C)
+      store4_masked(op + (size_t)(2 * c + 1) * HW,
+                    mean4(make_float4(acc[c][0].y, acc[c][1].y, acc[c][2].y, acc[c][3].y), fC, rC, pow2), pmask);
+  }
 #endif
 }
 
@@ -526,7 +602,10 @@ __global__ __launch_bounds__(256) void corr2d_small_bwd_kernel(C2Set a, int B, i
   grad[e] = acc / (float)C;
 }
 
-constexpr int kSmallHW = 512;  // direct kernels up to this many pixels per sample
+// direct kernels up to this many pixels per sample (C3 levels (196, 3, 8) / (128, 5, 15) / (96, 10, 29), both
+// directions per launch, direct vs tiled: forward 6.7 vs - / 16 vs 31 / 50 vs 26 us, with the normalisation folded
+// in 15 vs - / 68 vs 34 / 152 vs 28 us; backward 17 vs - / 42 vs 26 / 186 vs 38 us)
+constexpr int kSmallFwd = 128, kSmallFwdNorm = 32, kSmallBwd = 32;
 
 template <int MD>
 int launch_small_fwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st) {
@@ -558,7 +637,7 @@ int launch_small_bwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st)
 
 template <int MD>
 int launch_fwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st) {
-  if (H * W <= kSmallHW) return launch_small_fwd<MD>(a, B, C, H, W, st);
+  if (H * W <= (a.st1[0] != nullptr ? kSmallFwdNorm : kSmallFwd)) return launch_small_fwd<MD>(a, B, C, H, W, st);
   const dim3 grid((unsigned)((long long)fs::cdiv(W, TX) * fs::cdiv(H, TY) * B * a.nsets));
   constexpr int DPW = FS_C2_FWD_DPW;
   hipLaunchKernelGGL((corr2d_fwd_q_kernel<MD, DPW>), grid, dim3(64 * ((2 * MD + DPW) / DPW)), 0, st, a, B, C, H, W);
@@ -568,10 +647,9 @@ int launch_fwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st) {
 
 template <int MD>
 int launch_bwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st) {
-  if (H * W <= kSmallHW) return launch_small_bwd<MD>(a, B, C, H, W, st);
+  if (H * W <= kSmallBwd) return launch_small_bwd<MD>(a, B, C, H, W, st);
   const dim3 grid((unsigned)((long long)fs::cdiv(W, TX) * fs::cdiv(H, TY) * 2 * B * a.nsets * fs::cdiv(C, CBW)));
-  constexpr int DPW = FS_C2_BWD_DPW;
-  hipLaunchKernelGGL((corr2d_bwd_q_kernel<MD, DPW>), grid, dim3(64 * ((2 * MD + DPW) / DPW)), 0, st, a, B, C, H, W);
+  hipLaunchKernelGGL(corr2d_bwd_q_kernel<MD>, grid, dim3(512), 0, st, a, B, C, H, W);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -579,7 +657,7 @@ int launch_bwd(const C2Set& a, int B, int C, int H, int W, hipStream_t st) {
 int check_shape(int B, int C, int H, int W, int md) {
   if (B < 1 || C < 1 || H < 1 || W < 1) return FS_ERR_SHAPE;
   if ((long long)fs::cdiv(W, TX) * fs::cdiv(H, TY) * 4 * B * fs::cdiv(C, CBW) >= (1ll << 31)) return FS_ERR_SHAPE;  // 1-D grids
-  if ((long long)C * H * W >= (1ll << 29) || 81ll * H * W >= (1ll << 29)) return FS_ERR_SHAPE;  // 32-bit byte offsets inside a sample
+  if ((long long)B * C * H * W >= (1ll << 29) || 81ll * H * W >= (1ll << 29)) return FS_ERR_SHAPE;  // 32-bit byte offsets inside a tensor
   if (md < 1 || md > 4) return FS_ERR_ARG;
   return FS_OK;
 }

@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The stock 2-D convolutions of the UPFlow / Flow-2D callers run on MIOpen.  Its find step picks a solver per shape
+# by timing, so one run gets its fp32 Winograd backward solvers and the next does not; they move single bias-gradient
+# entries by ~1e-3, which made the per-level gradient comparison with the reference's values
+# (test_gpu_e2e.py::test_upflow_levels_teacher_forced) pass or fail by the draw.  The tests compare numerics, not
+# speed: keep MIOpen on its direct / implicit-GEMM solvers, the same in every run.  (Read by MIOpen at its first
+# convolution, long after this import; the HIP kernels under test are not affected.)
+os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

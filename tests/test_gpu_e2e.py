@@ -134,11 +134,10 @@ def test_upflow_levels_teacher_forced(golden):
     difference is amplified down the pyramid) -- so every pyramid level is ALSO checked on its own, fed the
     reference's inputs of that level (tests/golden/upflow_levels.npz, captured by running the reference):
     `decode_level_res` outputs at 1e-4, the gradients w.r.t. every level input and every parameter of the
-    estimator / context networks at 5e-3 (projections: dot with a seeded Gaussian tensor + absolute sum; the absolute
-    sums agree to ~3e-5, and so do the projections whenever MIOpen's find step picks its direct / implicit-GEMM
-    backward solvers for the estimator's 2-D convolutions -- its fp32 Winograd solvers, picked or not from one run
-    to the next by the find step's timings, move single bias-gradient entries by ~1e-3, measured 2e-3 on the
-    projection scale).
+    estimator / context networks at 5e-3 (projections: dot with a seeded Gaussian tensor + absolute sum; both agree
+    to ~3e-5 with MIOpen on its direct / implicit-GEMM backward solvers for the estimator's 2-D convolutions, which
+    tests/conftest.py pins -- its fp32 Winograd solvers, picked or not from one run to the next by the find step's
+    timings, move single bias-gradient entries by ~1e-3, measured up to 5e-3 on the projection scale).
     The forward value of the two feature warps is forced to the reference's (their mask decisions included); the
     HIP warp itself is compared with it away from pixels where the two masks disagree, and its own gradient is
     what flows back."""

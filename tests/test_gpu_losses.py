@@ -40,13 +40,15 @@ def test_corr2d_golden(ops, golden):
         assert float((g2.cpu() - torch.from_numpy(g[pre + "g2"])).abs().max()) < 2e-5
 
 
-# (the tiled LDS kernels above 512 pixels per sample, the direct kernels with 1 / 2 / 4 / 8 channel slices
-# per output below: the C3 pyramid shapes at a small and at the full batch, odd channel counts, md 1..4)
+# (the tiled LDS kernels -- forward above 128 pixels per sample, backward above 32 -- and the direct kernels with
+# 1 / 2 / 4 / 8 channel slices per output below that: the C3 pyramid shapes at a small and at the full batch, odd
+# channel counts, more than one 32-channel group, md 1..4 on both kinds, rows that are not multiples of 4 floats)
 @pytest.mark.parametrize("shape,md", [((2, 32, 38, 113), 4), ((3, 196, 3, 8), 4), ((1, 7, 19, 57), 4),
                                       ((2, 5, 9, 40), 2), ((1, 3, 11, 33), 3), ((1, 4, 6, 6), 1),
                                       ((32, 196, 3, 8), 4), ((32, 128, 5, 15), 4), ((2, 96, 10, 29), 4),
                                       ((1, 50, 5, 15), 4), ((1, 27, 3, 8), 2), ((2, 64, 19, 57), 4),
-                                      ((1, 9, 40, 33), 4)])
+                                      ((1, 9, 40, 33), 4), ((2, 40, 16, 64), 2), ((2, 8, 12, 44), 1),
+                                      ((2, 33, 20, 41), 3)])
 def test_corr2d_vs_oracle(ops, shape, md):
     g = torch.Generator().manual_seed(shape[1] * 31 + md)
     f1, f2 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
