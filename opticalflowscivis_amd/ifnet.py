@@ -152,9 +152,13 @@ class IFNet(nn.Module):
 
     def forward(self, x, scale=(4, 2, 1), timestep=0.5):
         # channel slices of [B,3,...] are strided: split once into contiguous frames (every warp and
-        # epilogue launch would otherwise copy them again)
+        # epilogue launch would otherwise copy them again).  `x` may also be the pair (imgs, gt) the training step
+        # holds anyway: the reference concatenates the two only for this method to split them again.
+        if isinstance(x, (tuple, list)):
+            x, gt = x
+        else:
+            gt = x[:, 2:3] if self.nd == 2 else x[:, 2:]  # empty at inference time
         img0, img1 = x[:, :1].contiguous(), x[:, 1:2].contiguous()
-        gt = x[:, 2:3] if self.nd == 2 else x[:, 2:]  # empty at inference time
         gt = gt.contiguous()
         flow_list, merged, mask_list, mask_logits = [], [], [], []
         warped_img0, warped_img1 = img0, img1

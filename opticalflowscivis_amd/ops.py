@@ -904,16 +904,19 @@ class _Merge(torch.autograd.Function):
             _call("fs_merge_fwd", w0.data_ptr(), w1.data_ptr(), m.data_ptr(), merged.data_ptr(),
                   sig.data_ptr(), B, C, S, _stream(w0), algo_bytes=4 * (3 * w0.numel() + 2 * m.numel()))
         ctx.save_for_backward(w0, w1, m)
+        # the sigmoid output usually has no consumer with a gradient (Flow-3D returns it, no loss reads it): an
+        # undefined gradient stays None instead of a zero-filled tensor the kernel would then read
+        ctx.set_materialize_grads(False)
         return merged, sig
 
     @staticmethod
     def backward(ctx, gmerged, gsig):
         w0, w1, m = ctx.saved_tensors
         n0, n1, nm = ctx.needs_input_grad
-        if not (n0 or n1 or nm):
+        if not (n0 or n1 or nm) or (gmerged is None and gsig is None):
             return None, None, None
         B, C, S = _flat3(w0)
-        gmerged = gmerged.contiguous()
+        gmerged = torch.zeros_like(w0) if gmerged is None else gmerged.contiguous()
         gsig = gsig.contiguous() if gsig is not None else None
         g0 = torch.empty_like(w0) if n0 else None
         g1 = torch.empty_like(w1) if n1 else None

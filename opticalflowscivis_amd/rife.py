@@ -182,7 +182,7 @@ class Model3D(ModelBase):
         else:
             self.eval()
         flow, mask, merged, flow_teacher, merged_teacher, loss_distill = self.flownet(
-            torch.cat((imgs, gt), 1), scale=[4, 2, 1])
+            (imgs, gt), scale=[4, 2, 1])
         sp = tuple(min(a, b) for a, b in zip(imgs.shape[2:], mask.shape[2:]))
         gt = gt[(slice(None), slice(None)) + tuple(slice(0, s) for s in sp)]
         pair_loss = self.lap if lap_loss else ops.l1_loss
@@ -257,7 +257,7 @@ class Model2D(ModelBase):
         else:
             self.eval()
         flow, mask, merged, flow_teacher, merged_teacher, loss_distill = self.flownet(
-            torch.cat((imgs, gt), 1), scale=[4, 2, 1])
+            (imgs, gt), scale=[4, 2, 1])
         mask = mask[2]
         h, w = min(img0.shape[2], mask.shape[2]), min(img0.shape[3], mask.shape[3])
         gt = gt[:, :, :h, :w]
