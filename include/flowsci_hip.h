@@ -105,15 +105,18 @@ int fs_upsample_warp3d_pair_bwd(const float* img0, const float* img1, const floa
  * other consumers (Flow-3D/model/IFNet.py: the flow of a block feeds :190-191 the warps, :183 the next block's
  * input `torch.cat`, :213 the running-flow accumulation and :262 the distillation term).  Each add* (nullable)
  * is a [B,6,D,H,W] tensor or a 6-channel slice of a wider one: batch_stride* = its batch stride in floats
- * (>= 6*D*H*W), channel stride D*H*W.  add0 may alias grad_flow6 / grad_flow_total. */
+ * (>= 6*D*H*W), channel stride D*H*W.  add0 may alias grad_flow6 / grad_flow_total.  The gradients of the two
+ * warped frames may be channel slices too (they are channels 2 and 3 of the next block's input gradient):
+ * gout_batch_stride* = their batch stride in floats, 0 = dense (C*D*H*W). */
 int fs_warp3d_pair_bwd_acc3(const float* img0, const float* img1, const float* flow6,
-                            const float* grad_out0, const float* grad_out1, float* grad_img0, float* grad_img1,
+                            const float* grad_out0, long long gout_batch_stride0, const float* grad_out1,
+                            long long gout_batch_stride1, float* grad_img0, float* grad_img1,
                             const float* add0, long long batch_stride0, const float* add1, long long batch_stride1,
                             const float* add2, long long batch_stride2, float* grad_flow6,
                             int B, int C, const int* in_dhw, int D, int H, int W, fs_stream_t stream);
 int fs_upsample_warp3d_pair_bwd3(const float* img0, const float* img1, const float* flow6,
-                                 const float* grad_out0, const float* grad_out1,
-                                 const float* add0, long long batch_stride0, const float* add1, long long batch_stride1,
+                                 const float* grad_out0, long long gout_batch_stride0, const float* grad_out1,
+                                 long long gout_batch_stride1, const float* add0, long long batch_stride0, const float* add1, long long batch_stride1,
                                  const float* add2, long long batch_stride2, float* grad_flow_total, float* grad_delta,
                                  float* ws, int B, int C, const int* in_dhw, int Ds, int Hs, int Ws,
                                  int factor, float scale, fs_stream_t stream);

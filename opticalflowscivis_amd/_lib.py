@@ -32,9 +32,9 @@ SIGNATURES = {
     "fs_warp3d_pair_fwd": [_f32p] * 5 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_warp3d_pair_bwd": [_f32p] * 8 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_warp3d_pair_bwd_acc": [_f32p] * 9 + [_int, _int, _intp, _int, _int, _int, _stream],
-    "fs_warp3d_pair_bwd_acc3": [_f32p] * 7 + [_f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _int, _int, _intp, _int, _int,
+    "fs_warp3d_pair_bwd_acc3": [_f32p] * 3 + [_f32p, _i64, _f32p, _i64] + [_f32p] * 2 + [_f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _int, _int, _intp, _int, _int,
                                 _int, _stream],
-    "fs_upsample_warp3d_pair_bwd3": [_f32p] * 5 + [_f32p, _i64, _f32p, _i64, _f32p, _i64] + [_f32p] * 3 +
+    "fs_upsample_warp3d_pair_bwd3": [_f32p] * 3 + [_f32p, _i64, _f32p, _i64] + [_f32p, _i64, _f32p, _i64, _f32p, _i64] + [_f32p] * 3 +
                                     [_int, _int, _intp, _int, _int, _int, _int, _float, _stream],
     "fs_upsample_warp3d_pair_fwd": [_f32p] * 7 + [_int, _int, _intp, _int, _int, _int, _int, _float, _stream],
     "fs_upsample_warp3d_pair_bwd": [_f32p] * 9 + [_int, _int, _intp, _int, _int, _int, _int, _float, _stream],

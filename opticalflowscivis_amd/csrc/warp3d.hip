@@ -54,7 +54,11 @@ struct W3P {
 // flow[:, 3:6] (Flow-3D/model/IFNet.py:190-191); one launch serves both and reads / writes the
 // 6-channel flow tensors in place (no slicing copies).
 struct W3Fwd { const float* in[2]; float* out[2]; };
-struct W3Bwd { const float* in[2]; const float* gout[2]; float* gin[2]; };
+struct W3Bwd {
+  const float* in[2]; const float* gout[2]; float* gin[2];
+  long long gbs[2];  // batch stride of gout in floats (0 = dense, C*D*H*W): the gradient of a warped frame may arrive as
+                     // a channel slice of a wider tensor (torch.cat's backward of the next block's input)
+};
 
 // Fused "flow = prev + scale * trilinear_upsample(delta)" producer of the forward kernel (SURVEY §8f.1,
 // Flow-3D/model/IFNet.py:118 followed by :190-191): the flow tile of a slice is formed in registers from
@@ -469,6 +473,7 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
   const size_t ivol = (size_t)p.Di * p.Hi * p.Wi;
   const float* fb = flow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol;
   float* gfb = gflow ? gflow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol : nullptr;
+  const float* gob = gout + (size_t)b * (io.gbs[blockIdx.y] ? (size_t)io.gbs[blockIdx.y] : (size_t)p.C * vol);
   // gradients reaching the flow from its other consumers, summed into the stored tile (the first may alias gflow)
   const float* gab[3];
 #pragma unroll
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
   {
     const float* f = fb + (size_t)d0 * HW;
     M::load(f, p, h0, w0, r0); M::load(f + vol, p, h0, w0, r1); M::load(f + 2 * vol, p, h0, w0, r2);
-    M::load(gout + (size_t)b * p.C * vol + (size_t)d0 * HW, p, h0, w0, rg);
+    M::load(gob + (size_t)d0 * HW, p, h0, w0, rg);
   }
   for (int d = d0; d < dEnd; ++d) {
     M::to_lds(sF[0], r0); M::to_lds(sF[1], r1); M::to_lds(sF[2], r2);
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
     for (int c = 0; c < p.C; ++c) {
       if (c > 0) {
         __syncthreads();  // previous channel's sG readers are done
-        M::load(gout + ((size_t)b * p.C + c) * vol + (size_t)d * HW, p, h0, w0, rg);
+        M::load(gob + (size_t)c * vol + (size_t)d * HW, p, h0, w0, rg);
       }
       M::to_lds(sG, rg);
       __syncthreads();
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
     if (d + 1 < dEnd) {  // next slice's tiles fly during the store phase
       const float* f = fb + (size_t)(d + 1) * HW;
       M::load(f, p, h0, w0, r0); M::load(f + vol, p, h0, w0, r1); M::load(f + 2 * vol, p, h0, w0, r2);
-      M::load(gout + (size_t)b * p.C * vol + (size_t)(d + 1) * HW, p, h0, w0, rg);
+      M::load(gob + (size_t)(d + 1) * HW, p, h0, w0, rg);
     }
     if (gfb != nullptr) {
       float* g = gfb + (size_t)d * HW;
@@ -643,7 +648,7 @@ int launch_bwd(const W3Bwd& io, int npair, bool with_gin, const float* flow, flo
   p.flowC = 3 * npair;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = vec_ok(p, flow, gflow, io.gout[0], io.gout[1]) && vec_ok(p, gadd.a[0], gadd.a[1], gadd.a[2], nullptr) &&
-                   gadd.bs[0] % 4 == 0 && gadd.bs[1] % 4 == 0 && gadd.bs[2] % 4 == 0;
+                   gadd.bs[0] % 4 == 0 && gadd.bs[1] % 4 == 0 && gadd.bs[2] % 4 == 0 && io.gbs[0] % 4 == 0 && io.gbs[1] % 4 == 0;
   const dim3 g(grid, npair);
   if (vec) launch_bwd_t<256, true>(io, g, with_gin, flow, gflow, gadd, p, st);
   else launch_bwd_t<256, false>(io, g, with_gin, flow, gflow, gadd, p, st);
@@ -734,7 +739,8 @@ extern "C" int fs_warp3d_pair_bwd_acc(const float* img0, const float* img1, cons
 // the distillation term; handing each consumer its own alias of the flow keeps autograd from summing them in
 // two extra passes over 805 MB tensors (opticalflowscivis_amd/ops.py::_WarpPairAcc).
 extern "C" int fs_warp3d_pair_bwd_acc3(const float* img0, const float* img1, const float* flow6,
-                                       const float* grad_out0, const float* grad_out1, float* grad_img0,
+                                       const float* grad_out0, long long gout_batch_stride0, const float* grad_out1,
+                                       long long gout_batch_stride1, float* grad_img0,
                                        float* grad_img1, const float* add0, long long batch_stride0,
                                        const float* add1, long long batch_stride1, const float* add2,
                                        long long batch_stride2, float* grad_flow6, int B, int C, const int* in_dhw,
@@ -748,7 +754,9 @@ extern "C" int fs_warp3d_pair_bwd_acc3(const float* img0, const float* img1, con
   if (rc != FS_OK) return rc;
   const long long fl = (long long)6 * D * H * W;
   if ((add0 && batch_stride0 < fl) || (add1 && batch_stride1 < fl) || (add2 && batch_stride2 < fl)) return FS_ERR_ARG;
-  W3Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}};
+  const long long gl = (long long)C * D * H * W;  // 0 = dense
+  if ((gout_batch_stride0 && gout_batch_stride0 < gl) || (gout_batch_stride1 && gout_batch_stride1 < gl)) return FS_ERR_ARG;
+  W3Bwd io = {{img0, img1}, {grad_out0, grad_out1}, {grad_img0, grad_img1}, {gout_batch_stride0, gout_batch_stride1}};
   return launch_bwd(io, 2, grad_img0 != nullptr, flow6, grad_flow6,
                     W3Add{{add0, add1, add2}, {batch_stride0, batch_stride1, batch_stride2}}, p, stream);
 }
@@ -782,7 +790,8 @@ extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, flo
 // flow_out from its other consumers, nullable; may alias grad_flow_total) -- which is also the gradient of
 // prev_flow -- and grad_delta = scale * adjoint_upsample(grad_flow_total).  ws: B*6*(D*H*Ws + D*Hs*Ws) floats.
 extern "C" int fs_upsample_warp3d_pair_bwd3(const float* img0, const float* img1, const float* flow6,
-                                            const float* grad_out0, const float* grad_out1, const float* add0,
+                                            const float* grad_out0, long long gout_batch_stride0,
+                                            const float* grad_out1, long long gout_batch_stride1, const float* add0,
                                             long long batch_stride0, const float* add1, long long batch_stride1,
                                             const float* add2, long long batch_stride2, float* grad_flow_total,
                                             float* grad_delta, float* ws, int B, int C, const int* in_dhw, int Ds,
@@ -792,7 +801,8 @@ extern "C" int fs_upsample_warp3d_pair_bwd3(const float* img0, const float* img1
   if (Ds < 1 || Hs < 1 || Ws < 1) return FS_ERR_SHAPE;
   if ((long long)Ds * Hs * Ws * factor * factor * factor >= (1ll << 31)) return FS_ERR_SHAPE;
   const int D = Ds * factor, H = Hs * factor, W = Ws * factor;
-  int rc = fs_warp3d_pair_bwd_acc3(img0, img1, flow6, grad_out0, grad_out1, nullptr, nullptr, add0, batch_stride0, add1,
+  int rc = fs_warp3d_pair_bwd_acc3(img0, img1, flow6, grad_out0, gout_batch_stride0, grad_out1, gout_batch_stride1,
+                                   nullptr, nullptr, add0, batch_stride0, add1,
                                    batch_stride1, add2, batch_stride2, grad_flow_total, B, C, in_dhw, D, H, W, stream);
   if (rc != FS_OK) return rc;
   return fs_interp3d_bwd_scaled(grad_flow_total, grad_delta, ws, B, 6, Ds, Hs, Ws, D, H, W, factor, 1, scale,

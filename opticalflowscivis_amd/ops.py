@@ -322,10 +322,26 @@ def _flow_addends(grads, flow):
     return args, keep, nbytes
 
 
+def _gout_strided(g, like):
+    """(tensor, batch stride or 0) of a warped frame's gradient for fs_*_bwd*3: dense, or a channel slice of a wider
+    contiguous tensor (torch.cat's backward) handed to the kernel with its batch stride; anything else is copied."""
+    vol = like.shape[2] * like.shape[3] * like.shape[4]
+    inner = (vol, like.shape[3] * like.shape[4], like.shape[4], 1)
+    if g.is_contiguous():
+        return g, 0
+    if (g.dim() == 5 and tuple(g.stride()[1:]) == inner and g.stride(0) >= g.shape[1] * vol and g.stride(0) % 4 == 0
+            and g.data_ptr() % 16 == 0):
+        return g, int(g.stride(0))
+    return g.contiguous(), 0
+
+
 def _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow, gflow_add=None):
     """(grad_img0, grad_img1, grad_flow); `gflow_add` (3-D only): a gradient, or a list of up to three, reaching
     the flow from its other consumers, summed into grad_flow by the same launch."""
-    g0, g1 = g0.contiguous(), g1.contiguous()
+    if flow.dim() == 5 and gflow_add is not None:
+        (g0, s0), (g1, s1) = _gout_strided(g0, flow), _gout_strided(g1, flow)
+    else:
+        g0, g1, s0, s1 = g0.contiguous(), g1.contiguous(), 0, 0
     gi0 = torch.zeros_like(img0) if need_img else None
     gi1 = torch.zeros_like(img1) if need_img else None
     B, C = img0.shape[:2]
@@ -339,7 +355,7 @@ def _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow, gflow_add=None
                 aargs, keep, abytes = _flow_addends(adds, flow)
                 gflow = torch.empty_like(flow)
                 _call("fs_warp3d_pair_bwd_acc3", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
-                      g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), *aargs, gflow.data_ptr(),
+                      g0.data_ptr(), s0, g1.data_ptr(), s1, _ptr(gi0), _ptr(gi1), *aargs, gflow.data_ptr(),
                       B, C, _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb + abytes)
                 del keep
             else:
@@ -482,15 +498,15 @@ class _UpsampleWarpPair(torch.autograd.Function):
         if g0 is None and g1 is None and not adds:
             return (None,) * 6
         oshape = (B, C, D, H, W)
-        g0 = flow.new_zeros(oshape) if g0 is None else g0.contiguous()
-        g1 = flow.new_zeros(oshape) if g1 is None else g1.contiguous()
+        g0, s0 = (flow.new_zeros(oshape), 0) if g0 is None else _gout_strided(g0, flow)
+        g1, s1 = (flow.new_zeros(oshape), 0) if g1 is None else _gout_strided(g1, flow)
         aargs, keep, abytes = _flow_addends(adds, flow)
         gtot = torch.empty_like(flow)
         gdelta = flow.new_empty(dshape)
         ws = flow.new_empty(B * 6 * (D * H * Ws + D * Hs * Ws))
         with torch.cuda.device(flow.device):
             _call("fs_upsample_warp3d_pair_bwd3", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(), g0.data_ptr(),
-                  g1.data_ptr(), *aargs, gtot.data_ptr(), gdelta.data_ptr(), ws.data_ptr(), B, C,
+                  s0, g1.data_ptr(), s1, *aargs, gtot.data_ptr(), gdelta.data_ptr(), ws.data_ptr(), B, C,
                   _in_dhw(img0, flow), Ds, Hs, Ws, factor, scale, _stream(flow),
                   algo_bytes=8 * flow.numel() + 8 * g0.numel() * 2 + abytes + 4 * (flow.numel() + gdelta.numel()))
         del keep

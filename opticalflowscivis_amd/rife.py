@@ -181,6 +181,7 @@ class Model3D(ModelBase):
             self.train()
         else:
             self.eval()
+        gt = gt.contiguous()  # (a channel slice of the loader's [B,3,...] batch: one copy here, none in the consumers)
         flow, mask, merged, flow_teacher, merged_teacher, loss_distill = self.flownet(
             (imgs, gt), scale=[4, 2, 1])
         sp = tuple(min(a, b) for a, b in zip(imgs.shape[2:], mask.shape[2:]))

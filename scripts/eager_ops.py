@@ -32,3 +32,14 @@ print("==== aten ops by input shape ====")
 for e in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total):
     if e.key.startswith("aten::") and e.self_device_time_total > 20:
         print("%-28s n=%4d  self %8.3f ms  %s" % (e.key, e.count, e.self_device_time_total / 1e3, str(e.input_shapes)[:150]))
+print("==== parents of the large copy_/add_/fill_ calls ====")
+import collections
+cnt = collections.Counter()
+for e in prof.events():
+    if e.name in ("aten::copy_", "aten::add_", "aten::fill_", "aten::cat", "aten::sum") and e.device_time_total > 30:
+        chain, p = [], e.cpu_parent
+        while p is not None and len(chain) < 4:
+            chain.append(p.name[:40]); p = p.cpu_parent
+        cnt[(e.name, str(e.input_shapes)[:60], " <- ".join(chain))] += 1
+for k, v in sorted(cnt.items(), key=lambda kv: -kv[1]):
+    print(v, k)

@@ -146,6 +146,14 @@ def test_upsample_warp_pair_vs_composition_and_oracle(ops, small, factor, with_p
         g2 = torch.autograd.grad(l2, ins2, retain_graph=True)
         for x, y in zip(g1, g2):
             assert float((x - y).abs().max()) < 2e-5 * max(1.0, float(y.abs().max()))
+    # the warped frames consumed through torch.cat (the next block's input): their gradients arrive as channel
+    # slices of a wider tensor and are read in place, batch stride 3 * D*H*W
+    Gw = _rnd((B, 3) + tuple(a0.shape[2:]), 40).to(DEV)
+    filler = _rnd(tuple(a0.shape), 41).to(DEV)
+    l1 = (torch.cat((filler, a0, a1), 1) * Gw).sum() + consumers(f_f, f_f2, f_f3)
+    l2 = (torch.cat((filler, c0, c1), 1) * Gw).sum() + consumers(f_c, f_c, f_c)
+    for x, y in zip(torch.autograd.grad(l1, ins1, retain_graph=True), torch.autograd.grad(l2, ins2, retain_graph=True)):
+        assert float((x - y).abs().max()) < 2e-5 * max(1.0, float(y.abs().max()))
     # only the flow consumer (no gradient reaches the warps)
     g1 = torch.autograd.grad((f_f * Gf).sum(), ins1)
     g2 = torch.autograd.grad((f_c * Gf).sum(), ins2)
@@ -177,6 +185,11 @@ def test_warp_pair_acc_folds_in_the_other_consumers_gradient(ops):
                                 (fout2 * Gf).sum() + (fout3.square() * 0.5).sum(), [fa], retain_graph=True)
     (gb,) = torch.autograd.grad((r0 * G0).sum() + (r1 * G1).sum() + (torch.cat((other, fb), 1) * Gc).sum() +
                                 (fb * Gf).sum() + (fb.square() * 0.5).sum(), [fb], retain_graph=True)
+    assert float((ga - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
+    # the warped frames through torch.cat as well (gradients = channel slices, batch stride 3 * D*H*W)
+    Gw = torch.randn(B, 3, D, H, W, generator=g).to(DEV)
+    (ga,) = torch.autograd.grad((torch.cat((img0, w0, w1), 1) * Gw).sum() + (fout2 * Gf).sum(), [fa], retain_graph=True)
+    (gb,) = torch.autograd.grad((torch.cat((img0, r0, r1), 1) * Gw).sum() + (fb * Gf).sum(), [fb], retain_graph=True)
     assert float((ga - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
     # each path alone
     (ga,) = torch.autograd.grad((w0 * G0).sum(), [fa], retain_graph=True)
