@@ -520,6 +520,22 @@ int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B, int Cg, in
                   int Do, int Ho, int Wo, int Di, int Hi, int Wi,
                   int kernel, int stride, int pad, fs_stream_t stream);
 
+/* IFBlock's first convolution without its `torch.cat` (Flow-3D/model/IFNet.py:183 `x = torch.cat((x, flow), 1)`
+ * over `torch.cat((img0, img1, warped_img0, warped_img1, mask), 1)`, :190-191): the Cin <= 12 input channels are
+ * planes of the tensors they already live in.  src[c] = device pointer to channel c of sample 0 (16-byte aligned),
+ * batch_strides[c] = the batch stride of its tensor in floats (a multiple of 4, >= D*H*W); both are HOST arrays of
+ * Cin entries, read at launch.  fs_conv3d_fwd_prelu_ms == fs_conv3d_fwd_prelu without `residual`;
+ * fs_conv3d_wrw_ms == fs_conv3d_wrw with that source.  FS_ERR_UNSUPPORTED when the shape has no loader-wave
+ * kernel (k = 4, <= 32 output / gradient channels, W % 4 == 0, enough bricks): concatenate and use the plain
+ * entry points. */
+int fs_conv3d_fwd_prelu_ms(const float* const* src, const long long* batch_strides, const float* w, const float* bias,
+                           const float* prelu_weight, float* y, float* z, float* ws,
+                           int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                           int kernel, int stride, int pad, int num_prelu_weights, fs_stream_t stream);
+int fs_conv3d_wrw_ms(const float* g, const float* const* src, const long long* batch_strides, float* dw,
+                     int B, int Cg, int Cs, int Do, int Ho, int Wo, int Di, int Hi, int Wi,
+                     int kernel, int stride, int pad, fs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ _stream = ctypes.c_void_p
 _intp = ctypes.POINTER(ctypes.c_int)  # host array of ints (or None)
 _i64p = ctypes.POINTER(ctypes.c_longlong)  # host out-parameter
 _i64 = ctypes.c_longlong
+_ptrv = ctypes.POINTER(ctypes.c_void_p)  # host array of device pointers
 
 # name -> argtypes; restype is int unless listed in _RESTYPES
 SIGNATURES = {
@@ -87,6 +88,8 @@ SIGNATURES = {
     "fs_corr3d_fwd": [_f32p] * 3 + [_int] * 6 + [_stream],
     "fs_corr3d_bwd": [_f32p] * 5 + [_int] * 6 + [_stream],
     "fs_conv3d_wrw": [_f32p] * 3 + [_int] * 12 + [_stream],
+    "fs_conv3d_fwd_prelu_ms": [_ptrv, _i64p] + [_f32p] * 6 + [_int] * 13 + [_stream],
+    "fs_conv3d_wrw_ms": [_f32p, _ptrv, _i64p, _f32p] + [_int] * 12 + [_stream],
     "fs_wssim_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_wssim_bwd": [_f32p] * 6 + [_int] * 5 + [_stream],
     "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _intp, _int, _int, _int, _int, _stream],

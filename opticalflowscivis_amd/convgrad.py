@@ -205,6 +205,76 @@ class _ConvPReLUFn(torch.autograd.Function):
         return gx, gw, gb, ga, None, None, None
 
 
+class _ConvPReLUCatFn(torch.autograd.Function):
+    """PReLU(conv3d(torch.cat(pieces, 1), w, b)) -- IFBlock's first convolution over `torch.cat((img0, img1,
+    warped_img0, warped_img1, mask, flow), 1)` (Flow-3D/model/IFNet.py:183, 190-191) -- WITHOUT the concatenation:
+    forward and weight gradient read every channel where it already lies (fs_conv3d_fwd_prelu_ms /
+    fs_conv3d_wrw_ms: one buffer descriptor per channel in the loader waves); the input gradient is computed as one
+    tensor and handed out as channel slices, exactly what torch.cat's backward would return.  Shapes without such a
+    kernel concatenate inside this node."""
+
+    @staticmethod
+    def forward(ctx, w, b, a, stride, padding, *pieces):
+        from . import ops
+        k = w.shape[2]
+        res = ops.conv3d_fwd_prelu_ms(pieces, w, b, a, k, stride[0], padding[0])
+        ctx.ms = res is not None
+        if res is None:
+            x = torch.cat(pieces, 1)
+            y, z = _conv_forward(x, w, b, stride, padding, False, a)
+            ctx.save_for_backward(w, y, a, x)
+        else:
+            y, z = res
+            ctx.save_for_backward(w, y, a, *pieces)
+        ctx.cfg = (stride, padding, b is not None, [int(t.shape[1]) for t in pieces])
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        from . import ops
+        w, y, a = ctx.saved_tensors[:3]
+        src = ctx.saved_tensors[3:]
+        stride, padding, has_bias, splits = ctx.cfg
+        gy, ga, gb = ops.prelu_backward(y, gz.contiguous(), a, want_bias_grad=has_bias)
+        need = ctx.needs_input_grad[5:]
+        gx = None
+        if any(need):
+            # (the HIP transposed-convolution path only looks at the input's extent; ATen's wants the tensor)
+            k3 = tuple(w.shape[2:])
+            hip = _hip_tr_ok(gy, w.shape[1], k3, stride, padding) and all(
+                n in (2 * m, 2 * m + 1) for n, m in zip(src[0].shape[2:], gy.shape[2:]))
+            gx = _conv_grad_input(src[0] if (hip or not ctx.ms) else torch.cat(src, 1), w, gy, stride, padding, False)
+        gw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.ms:
+                gw = ops.conv3d_wrw_ms(gy, src, w.shape[2], stride[0], padding[0])
+                if gw is None:
+                    gw = _conv_grad_weight(torch.cat(src, 1), w, gy, stride, padding, False)
+            else:
+                gw = _conv_grad_weight(src[0], w, gy, stride, padding, False)
+        gp = [None] * len(splits)
+        if gx is not None:
+            gp = [g if n else None for g, n in zip(gx.split(splits, 1), need)]
+        return (gw, gb, ga, None, None) + tuple(gp)
+
+
+def conv_prelu_cat(block, pieces):
+    """`block` = ConvPReLU(Conv3d, PReLU) applied to torch.cat(pieces, 1), the concatenation skipped where the HIP
+    kernels can read the pieces in place (training on the GPU, fp32, k = 4 / stride 2); None otherwise."""
+    conv, act = block[0], block[1]
+    x0 = pieces[0]
+    if os.environ.get("FLOWSCI_CONV0_CAT") == "1":  # A/B switch: concatenate as the reference does
+        return None
+    if not (_hip_autograd(x0) and x0.dim() == 5 and x0.dtype == torch.float32 and isinstance(conv, Conv3d)
+            and act.weight.numel() in (1, conv.out_channels) and conv.groups == 1
+            and _tuple(conv.dilation, 3) == (1, 1, 1) and conv.padding_mode == "zeros"
+            and tuple(conv.weight.shape[2:]) == (4, 4, 4) and _tuple(conv.stride, 3) == (2, 2, 2)
+            and sum(int(t.shape[1]) for t in pieces) == conv.in_channels <= 12 and conv.out_channels <= 32):
+        return None
+    return _ConvPReLUCatFn.apply(conv.weight, conv.bias, act.weight, _tuple(conv.stride, 3), _tuple(conv.padding, 3),
+                                 *pieces)
+
+
 class _HeadFn(torch.autograd.Function):
     """out = deconv2(PReLU(deconv1(x))) [+ addend] -- an IFBlock head (Flow-3D/model/IFNet.py:66-77) -- as ONE autograd
     node, so that the backward pass can fold the PReLU backward into the epilogue of deconv2's input-gradient

@@ -54,6 +54,13 @@ struct FP {
   const float* dslope;
   int dnslope;
   float* dpart;
+  // optional multi-source input (loader-wave kernels): the Cin = nsrc <= 12 input channels are planes of
+  // different tensors -- src[c] = channel c of sample 0, sbs[c] = its tensor's batch stride in floats -- so that
+  // IFBlock's `torch.cat((img0, img1, warped0, warped1, mask, flow), 1)` (Flow-3D/model/IFNet.py:183) is never
+  // materialised: the loader waves read each plane where it lies.  nsrc = 0: one tensor X.
+  int nsrc;
+  const float* src[12];
+  long long sbs[12];
 };
 
 // Wt[ci][tap][co] (ci < CinP, co < CoutP; zero outside the real channels)
@@ -327,7 +334,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
     // piece k of loader wave wv fills the 16-byte slots 256 (wv + 4 k) + 4 lane .. + 3 of an image
     const int gz0 = oz0 * S - p.pad, gy0 = oy0 * S - p.pad, gx0 = ox0 * S - XL;
+    // x pieces: offset inside their channel and the channel (0 .. CI-1) of the chunk they belong to: a chunk's
+    // channels have one descriptor each (they may be planes of different tensors), a piece that straddles two
+    // channels is issued once per channel under the lanes' predicate
     unsigned xoff[NXW], woff[NWW];
+    int xch[NXW];
 #pragma unroll
     for (int k = 0; k < NXW; ++k) {
       const int i = 256 * (wv + 4 * k) + 4 * lane;
@@ -336,7 +347,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
       const int y = r2 / XP, x = r2 - y * XP;
       const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
       const bool ok = i < NX && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
-      xoff[k] = ok ? ((unsigned)c * (unsigned)xvol + ((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u : DMA_OOB;
+      xoff[k] = ok ? (((unsigned)gz * p.Hi + gy) * p.Wi + gx) * 4u : DMA_OOB;
+      xch[k] = i < NX ? c : CI - 1;
     }
 #pragma unroll
     for (int k = 0; k < NWW; ++k) {
@@ -345,17 +357,29 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
       woff[k] = i < NW ? ((unsigned)row * (unsigned)p.CoutP + (unsigned)j) * 4u : DMA_OOB;
     }
     auto stage = [&](int c0, int buf) {
-      // channels past Cin read as zero: the descriptor ends after the chunk's real channels
-      const int nch = (p.Cin - c0 < CI) ? (p.Cin - c0) : CI;
-      __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(X + ((size_t)b * p.Cin + c0) * xvol), (short)0, (int)((unsigned)nch * (unsigned)xvol * 4u), 0x00020000);
+      // channels past Cin read as zero: their descriptor is empty
+      __amdgpu_buffer_rsrc_t rx[CI];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const int ch = c0 + c;
+        const bool live = ch < p.Cin;
+        const int chc = live ? ch : 0;
+        const float* base = p.nsrc ? p.src[chc] + (size_t)b * (size_t)p.sbs[chc]
+                                   : X + ((size_t)b * p.Cin + chc) * xvol;
+        rx[c] = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, live ? (int)((unsigned)xvol * 4u) : 0, 0x00020000);
+      }
       __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(Wt + (size_t)c0 * K3 * p.CoutP + co0), (short)0, 0x7fffffff, 0x00020000);
       float* base = lds + buf * BUF;
 #pragma unroll
       for (int k = 0; k < NXW; ++k)
-        if (256 * (wv + 4 * k) < NXL)  // wave-uniform
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + 256 * (wv + 4 * k)), 16, xoff[k], 0, 0, 0);
+        if (256 * (wv + 4 * k) < NXL) {  // wave-uniform
+#pragma unroll
+          for (int c = 0; c < CI; ++c)
+            if (256 * (wv + 4 * k) < (c + 1) * CHS && 256 * (wv + 4 * k) + 256 > c * CHS)  // the piece touches channel c
+              if (xch[k] == c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx[c], (lds_ptr_t)(base + 256 * (wv + 4 * k)), 16, xoff[k], 0, 0, 0);
+        }
 #pragma unroll
       for (int k = 0; k < NWW; ++k)
         if (256 * (wv + 4 * k) < NWL)  // wave-uniform
@@ -631,11 +655,17 @@ struct DPrelu {  // fused PReLU backward of the layer that produced this convolu
   float* gb = nullptr;
 };
 
+struct MultiSrc {  // the input as per-channel planes (FP::src / FP::sbs)
+  const float* const* src;
+  const long long* batch_strides;
+};
+
 static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
                            const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
                            int Ho, int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream,
-                           const DPrelu* dp = nullptr) {
-  FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y); FS_REQUIRE_PTR(ws);
+                           const DPrelu* dp = nullptr, const MultiSrc* ms = nullptr) {
+  if (ms == nullptr) FS_REQUIRE_PTR(x);
+  FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y); FS_REQUIRE_PTR(ws);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1 || Do < 1 || Ho < 1 || Wo < 1)
     return FS_ERR_SHAPE;
@@ -655,6 +685,19 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   p.slope = slope; p.Z = z; p.nslope = nslope; p.addend = addend;
   p.dy = dp ? dp->act_y : nullptr; p.dslope = dp ? dp->slope : nullptr; p.dnslope = dp ? dp->nslope : 0;
   p.dpart = dp ? dp->part : nullptr;
+  p.nsrc = 0;
+  bool ms_aligned = true;
+  if (ms != nullptr) {
+    if (Cin > 12) return FS_ERR_UNSUPPORTED;
+    p.nsrc = Cin;
+    const long long vol = (long long)Di * Hi * Wi;
+    for (int c = 0; c < Cin; ++c) {
+      if (ms->src[c] == nullptr) return FS_ERR_NULLPTR;
+      if (ms->batch_strides[c] < vol) return FS_ERR_ARG;
+      p.src[c] = ms->src[c]; p.sbs[c] = ms->batch_strides[c];
+      ms_aligned = ms_aligned && ((uintptr_t)ms->src[c] & 15) == 0 && ms->batch_strides[c] % 4 == 0;
+    }
+  }
   int cinp;
   wt_dims(Cin, Cout, kernel, &cinp, &p.CoutP);
   hipStream_t st = (hipStream_t)stream;
@@ -667,8 +710,10 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   // pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets inside one staged channel
   // chunk, enough bricks to fill the chip with one workgroup per CU
   static const bool reg_only = getenv("FLOWSCI_FWD_REG") != nullptr;
-  const bool ws_ok = !reg_only && Wi % 4 == 0 && Wo > 16 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 &&
-                     (long long)(kernel == 3 ? 4 : 2) * Di * Hi * Wi * 4 < (1ll << 31);
+  const bool ws_ok = !reg_only && Wi % 4 == 0 && Wo > 16 && (((ms ? (uintptr_t)0 : (uintptr_t)x) | (uintptr_t)ws) & 15) == 0 &&
+                     ms_aligned && (long long)(kernel == 3 ? 4 : 2) * Di * Hi * Wi * 4 < (1ll << 31);
+  // only the 32-channel loader-wave kernel reads per-channel planes (IFBlock's conv0[0] at scale 1)
+  if (ms != nullptr && !(kernel == 4 && ws_ok && dp == nullptr)) return FS_ERR_UNSUPPORTED;
   if (kernel == 3) {
     // big bricks (2 x 8 x 32 / 2 x 16 x 16 voxels) when they fill the chip, else quarter-size bricks
     // (1 x 4 x 32 / 1 x 8 x 16): the 16^3 / 32^3 trunk layers of the coarse blocks have only 8K-64K
@@ -704,6 +749,7 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     FS_LAUNCH_CHECK();
     return FS_OK;
   }
+  if (ms != nullptr && !(p.CoutP == 32 && k4tiles >= 512)) return FS_ERR_UNSUPPORTED;
   if (p.CoutP == 32) {
     if (ws_ok && k4tiles >= 512) return launch_ws<4, 2, 2, 1, 4, 2, 8, 32>(x, ws, bias, y, p, st);
     if (Wo > 16) return launch<4, 2, 2, 1, 2, 1, 8, 32>(x, ws, bias, y, p, st);
@@ -739,6 +785,21 @@ extern "C" int fs_conv3d_fwd_prelu(const float* x, const float* w, const float* 
   FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
   return conv3d_fwd_impl(x, w, bias, prelu_weight, num_prelu_weights, residual, y, z, ws, B, Cin, Cout, Di, Hi, Wi,
                          Do, Ho, Wo, kernel, stride, pad, 0, stream);
+}
+
+// fs_conv3d_fwd_prelu over an input that is never concatenated: channel c of the [B, Cin, D,H,W] input is the plane
+// src[c] (sample 0) of a tensor with batch stride batch_strides[c] floats (host arrays, read at launch; Cin <= 12,
+// 16-byte aligned planes, strides multiples of 4).  FS_ERR_UNSUPPORTED when the shape has no loader-wave kernel
+// (the caller then concatenates and takes fs_conv3d_fwd_prelu).
+extern "C" int fs_conv3d_fwd_prelu_ms(const float* const* src, const long long* batch_strides, const float* w,
+                                      const float* bias, const float* prelu_weight, float* y, float* z, float* ws,
+                                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                      int kernel, int stride, int pad, int num_prelu_weights, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(src); FS_REQUIRE_PTR(batch_strides); FS_REQUIRE_PTR(prelu_weight); FS_REQUIRE_PTR(z);
+  const MultiSrc ms = {src, batch_strides};
+  return conv3d_fwd_impl(nullptr, w, bias, prelu_weight, num_prelu_weights, nullptr, y, z, ws, B, Cin, Cout, Di, Hi, Wi,
+                         Do, Ho, Wo, kernel, stride, pad, 0, stream, nullptr, &ms);
 }
 
 // Input gradient of a convolution whose INPUT was z = prelu(act_y) (a ConvTranspose3d(4,2,1) read as the strided

@@ -44,6 +44,9 @@ struct WP {
   int segs;         // ceil(Wo / KW)
   long long steps;  // B*Do*Ho*segs
   int spw;          // K-steps per workgroup
+  int nsrc = 0;                  // multi-source src (WB::src), loader-wave kernel only
+  const float* const* srcv = nullptr;
+  const long long* sbsv = nullptr;
 };
 
 // (round-1 history: a K-step used to be ONE row of 32 ox -- 9.6x source re-read for k=3, a barrier per
@@ -56,6 +59,12 @@ struct WB {
   int bz, by, bx;    // bricks per axis
   long long bricks;  // B*bz*by*bx
   int spw;           // bricks per workgroup
+  // optional multi-source `src` (loader-wave kernel): its Cs = nsrc <= 12 channels are planes of different
+  // tensors, src[c] = channel c of sample 0, sbs[c] = that tensor's batch stride in floats (the never-materialised
+  // torch.cat of IFBlock's input, see csrc/convfwd.hip FP::src).  nsrc = 0: one tensor.
+  int nsrc;
+  const float* src[12];
+  long long sbs[12];
 };
 
 constexpr int pad_to(int n, int want) { return n + (((want - n) % 32) + 32) % 32; }
@@ -369,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
     // source image: byte offset from the brick origin and border class (bit 0/1: low / high z halo, 2/3: y,
     // 4/5: x); pad slots and channels past Cs are permanently out of range
     unsigned soff[NSW], scls[NSW];
+    int sch[NSW];  // (multi-source) the chunk channel a piece belongs to
     const int zhi = p.Di + p.pad - (p.bz - 1) * TZ * S, yhi = p.Hi + p.pad - (p.by - 1) * TYB * S,
               xhi = p.Wi + XL - (p.bx - 1) * KWX * S;  // first invalid brick coordinate in the LAST brick of an axis
 #pragma unroll
@@ -378,7 +388,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
       const int z = r1 / PSP, r2 = r1 - z * PSP;
       const int y = r2 / XP, x = r2 - y * XP;
       const bool ok = q < NSF && c0 + c < p.Cs;
-      soff[k] = ok ? ((unsigned)c * (unsigned)svol + ((unsigned)z * p.Hi + (unsigned)y) * p.Wi + (unsigned)x) * 4u : DMA_OOB;
+      // (multi-source: every channel has its own descriptor, the offset stays inside the plane)
+      soff[k] = ok ? ((p.nsrc ? 0u : (unsigned)c * (unsigned)svol) + ((unsigned)z * p.Hi + (unsigned)y) * p.Wi + (unsigned)x) * 4u
+                   : DMA_OOB;
+      sch[k] = q < NSF ? c : NC - 1;
       scls[k] = (z < p.pad ? 1u : 0u) | (z >= zhi ? 2u : 0u) | (y < p.pad ? 4u : 0u) | (y >= yhi ? 8u : 0u) |
                 (x < XL ? 16u : 0u) | (x >= xhi ? 32u : 0u);
     }
@@ -427,11 +440,35 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(dbase + 256 * (wv + 4 * i)), 16, v, pos0, 0, 0);
         }
       }
+      if (p.nsrc == 0) {
 #pragma unroll
-      for (int k = 0; k < NSW; ++k) {
-        if (256 * (wv + 4 * k) < NSL) {  // wave-uniform
-          const unsigned vo = (scls[k] & bmask) == 0u ? soff[k] : DMA_OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dbase + NGL + 256 * (wv + 4 * k)), 16, vo, 0, 0, 0);
+        for (int k = 0; k < NSW; ++k) {
+          if (256 * (wv + 4 * k) < NSL) {  // wave-uniform
+            const unsigned vo = (scls[k] & bmask) == 0u ? soff[k] : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dbase + NGL + 256 * (wv + 4 * k)), 16, vo, 0, 0, 0);
+          }
+        }
+      } else {
+        // one descriptor per channel of the chunk; a piece that straddles two channels is issued once per channel
+        // under the lanes' predicate
+        __amdgpu_buffer_rsrc_t rc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const bool live = c0 + c < p.Cs;
+          const int ch = live ? c0 + c : 0;
+          rc[c] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src[ch] + (size_t)b * (size_t)p.sbs[ch] + org), (short)0,
+                                                    live ? 0x7fffffff : 0, 0x00020000);
+        }
+#pragma unroll
+        for (int k = 0; k < NSW; ++k) {
+          if (256 * (wv + 4 * k) < NSL) {  // wave-uniform
+            const unsigned vo = (scls[k] & bmask) == 0u ? soff[k] : DMA_OOB;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              if (256 * (wv + 4 * k) < (c + 1) * CHSP && 256 * (wv + 4 * k) + 256 > c * CHSP)  // the piece touches channel c
+                if (sch[k] == c)
+                  __builtin_amdgcn_raw_ptr_buffer_load_lds(rc[c], (lds_ptr_t)(dbase + NGL + 256 * (wv + 4 * k)), 16, vo, 0, 0, 0);
+          }
         }
       }
       if (++bxi == p.bx) { bxi = 0; if (++byi == p.by) { byi = 0; if (++bzi == p.bz) { bzi = 0; ++b; } } }
@@ -554,6 +591,8 @@ int launch_dma(const float* G, const float* Src, float* dW, const WP& w, hipStre
   WB p;
   p.B = w.B; p.Cg = w.Cg; p.Cs = w.Cs; p.Do = w.Do; p.Ho = w.Ho; p.Wo = w.Wo;
   p.Di = w.Di; p.Hi = w.Hi; p.Wi = w.Wi; p.pad = w.pad;
+  p.nsrc = w.nsrc;
+  for (int c = 0; c < w.nsrc; ++c) { p.src[c] = w.srcv[c]; p.sbs[c] = w.sbsv[c]; }
   p.bz = fs::cdiv(p.Do, TZ); p.by = fs::cdiv(p.Ho, TY * (KW / KWX)); p.bx = fs::cdiv(p.Wo, KWX);
   p.bricks = (long long)p.B * p.bz * p.by * p.bx;
   const int mtiles = fs::cdiv(p.Cg, 32 * MT);
@@ -580,11 +619,11 @@ extern "C" int fs_debug_wrw_stamps(unsigned long long* out) {
 }
 #endif
 
-extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B, int Cg, int Cs, int Do,
-                             int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride, int pad,
-                             fs_stream_t stream) {
-  FS_ENTER();
-  FS_REQUIRE_PTR(g); FS_REQUIRE_PTR(src); FS_REQUIRE_PTR(dw);
+static int conv3d_wrw_impl(const float* g, const float* src, const float* const* srcv, const long long* sbsv, float* dw,
+                           int B, int Cg, int Cs, int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride,
+                           int pad, fs_stream_t stream) {
+  FS_REQUIRE_PTR(g); FS_REQUIRE_PTR(dw);
+  if (srcv == nullptr) FS_REQUIRE_PTR(src);
   if (B < 1 || Cg < 1 || Cs < 1 || Do < 1 || Ho < 1 || Wo < 1 || Di < 1 || Hi < 1 || Wi < 1)
     return FS_ERR_SHAPE;
   if (!((kernel == 3 && stride == 1) || (kernel == 4 && stride == 2)) || pad < 0 || pad >= kernel)
@@ -601,14 +640,29 @@ extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B,
   p.pad = pad;
   p.segs = fs::cdiv(Wo, KW);
   p.steps = (long long)B * Do * Ho * p.segs;
+  bool ms_aligned = true;
+  if (srcv != nullptr) {
+    if (Cs > 12) return FS_ERR_UNSUPPORTED;
+    p.nsrc = Cs; p.srcv = srcv; p.sbsv = sbsv;
+    for (int c = 0; c < Cs; ++c) {
+      if (srcv[c] == nullptr) return FS_ERR_NULLPTR;
+      if (sbsv[c] < (long long)Di * Hi * Wi) return FS_ERR_ARG;
+      ms_aligned = ms_aligned && ((uintptr_t)srcv[c] & 15) == 0 && sbsv[c] % 4 == 0;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   // DMA-staged kernel: 16-byte pieces (W % 4 == 0 on both grids, 16-byte aligned tensors), a full brick column,
   // pad <= stride, 31-bit byte offsets inside one (b, chunk) slab.  `FLOWSCI_WRW_REG=1`: the register-staged
   // kernel everywhere (scripts/wrwbench.py compares the two).
   static const bool reg_only = getenv("FLOWSCI_WRW_REG") != nullptr;
   const bool dma_ok = !reg_only && pad <= stride && (Wo >= KW || Wo == 16) && Wo % 4 == 0 && Wi % 4 == 0 &&
-                      (((uintptr_t)g | (uintptr_t)src) & 15) == 0 && (long long)64 * Do * Ho * Wo * 4 < (1ll << 31) &&
-                      (long long)16 * Di * Hi * Wi * 4 < (1ll << 31);
+                      (((uintptr_t)g | (srcv ? (uintptr_t)0 : (uintptr_t)src)) & 15) == 0 && ms_aligned &&
+                      (long long)64 * Do * Ho * Wo * 4 < (1ll << 31) && (long long)16 * Di * Hi * Wi * 4 < (1ll << 31);
+  // per-channel planes: only the loader-wave kernel of IFBlock's conv0[0] (k = 4, <= 32 gradient channels)
+  if (srcv != nullptr) {
+    if (dma_ok && kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) return launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st);
+    return FS_ERR_UNSUPPORTED;
+  }
   if (dma_ok) {
     if (kernel == 3 && Cg > 32 && Cs >= 8 && Wo == 16) return launch_dma<3, 1, 16, 2, 1, 4, 3, 1, 16>(g, src, dw, p, st);
     if (kernel == 3 && Cg > 32 && Cs >= 8) return launch_dma<3, 1, 16, 2, 1, 4, 3, 1>(g, src, dw, p, st);
@@ -624,4 +678,22 @@ extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B,
   const int cost2 = (Cs + 1) / 2, cost4 = 2 * ((Cs + 3) / 4);
   if (cost2 < cost4) return launch_brick<4, 2, 2, 1, 2>(g, src, dw, p, st);
   return launch_brick<4, 2, 4, 1, 2>(g, src, dw, p, st);
+}
+
+extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B, int Cg, int Cs, int Do,
+                             int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride, int pad,
+                             fs_stream_t stream) {
+  FS_ENTER();
+  return conv3d_wrw_impl(g, src, nullptr, nullptr, dw, B, Cg, Cs, Do, Ho, Wo, Di, Hi, Wi, kernel, stride, pad, stream);
+}
+
+// fs_conv3d_wrw over a source that is never concatenated: channel c of the [B, Cs, Di,Hi,Wi] source is the plane
+// src[c] (sample 0) of a tensor with batch stride batch_strides[c] floats (host arrays, read at launch; Cs <= 12,
+// 16-byte aligned planes, strides multiples of 4).  FS_ERR_UNSUPPORTED when the shape has no loader-wave kernel.
+extern "C" int fs_conv3d_wrw_ms(const float* g, const float* const* src, const long long* batch_strides, float* dw,
+                                int B, int Cg, int Cs, int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kernel,
+                                int stride, int pad, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(src); FS_REQUIRE_PTR(batch_strides);
+  return conv3d_wrw_impl(g, nullptr, src, batch_strides, dw, B, Cg, Cs, Do, Ho, Wo, Di, Hi, Wi, kernel, stride, pad, stream);
 }

@@ -101,11 +101,17 @@ class IFBlock(nn.Module):
                       one launch, ops.upsample_warp_pair), `mask` is mask_base + upsample(mask_delta);
           "delta"  -- (flow_delta, mask_delta) at full resolution, nothing accumulated."""
         mode = _INTERP[self.nd]
+        h0 = None
         if isinstance(x, (tuple, list)):
-            # the caller's pieces (img0, img1, warped, mask, ...): at scale 1 they are concatenated with
+            # the caller's pieces (img0, img1, warped, mask, ...): at scale 1 the first convolution reads them
+            # and the flow where they lie (3-D training: convgrad.conv_prelu_cat) or they are concatenated with
             # the flow in ONE pass instead of cat(cat(pieces), flow)
             if scale == 1 and flow is not None:
-                x, flow = torch.cat(tuple(x) + (flow,), 1), None
+                if self.nd == 3:
+                    h0 = convgrad.conv_prelu_cat(self.conv0[0], tuple(x) + (flow,))
+                if h0 is None:
+                    x = torch.cat(tuple(x) + (flow,), 1)
+                flow = None
             else:
                 x = torch.cat(tuple(x), 1)
         if scale != 1:
@@ -114,7 +120,7 @@ class IFBlock(nn.Module):
             if scale != 1:
                 flow = _resize(flow, 1. / scale, mode, 1. / scale)
             x = torch.cat((x, flow), 1)
-        x = self.conv0(x)
+        x = self.conv0(x) if h0 is None else self.conv0[1](h0)
         res = convgrad.res_unit if self.nd == 3 else (lambda blk, t: blk(t) + t)
         x = res(self.convblock0, x)
         x = res(self.convblock1, x)

@@ -92,6 +92,24 @@ def _call(name, *args, algo_bytes=0, algo_flops=0, record_as=None):
     _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops))
 
 
+def _call_rc(name, *args, algo_bytes=0, algo_flops=0, record_as=None, allow=()):
+    """_call for entry points that may answer with a status in `allow` (FS_ERR_UNSUPPORTED: "no such kernel for
+    this shape, take the unfused path"): returns the status instead of raising on those."""
+    fn = getattr(_lib.lib(), name)
+    timed = not (_timing is None or (_timing_only is not None and (record_as or name) not in _timing_only))
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = fn(*args)
+    if timed:
+        e1.record()
+        if rc == 0:
+            _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops))
+    if rc not in allow:
+        _lib.check(rc, name)
+    return rc
+
+
 # --------------------------------------------------------------------------------------------
 # a2: Flow-3D/model/warplayer.py:9-41
 # --------------------------------------------------------------------------------------------
@@ -1420,6 +1438,83 @@ def conv3d_wrw(g, src, k, stride, pad):
 
 
 FS_ERR_UNSUPPORTED = 5
+
+
+def _channel_planes(pieces):
+    """(pointer array, batch-stride array, Cin, keep-alive list) for fs_*_ms: every channel of every piece as the
+    plane it already is.  A piece is a [B, Ci, D,H,W] tensor, contiguous or a channel slice of a wider contiguous
+    one; None when a piece has other strides / alignment (the caller concatenates instead)."""
+    B, dhw = pieces[0].shape[0], tuple(pieces[0].shape[2:])
+    vol = dhw[0] * dhw[1] * dhw[2]
+    inner = (vol, dhw[1] * dhw[2], dhw[2], 1)
+    ptrs, strides = [], []
+    for t in pieces:
+        if (not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 5 or
+                t.shape[0] != B or tuple(t.shape[2:]) != dhw or tuple(t.stride()[1:]) != inner or
+                t.stride(0) < t.shape[1] * vol or t.stride(0) % 4 or t.data_ptr() % 16 or vol % 4):
+            return None
+        for c in range(t.shape[1]):
+            ptrs.append(t.data_ptr() + 4 * c * vol)
+            strides.append(t.stride(0))
+    n = len(ptrs)
+    if n > 12:
+        return None
+    return (ctypes.c_void_p * n)(*ptrs), (ctypes.c_longlong * n)(*strides), n
+
+
+def conv3d_fwd_prelu_ms(pieces, w, bias, prelu_weight, k, stride, pad):
+    """(y, prelu(y)) of conv3d(torch.cat(pieces, 1), w, bias, stride, pad) without the concatenation
+    (fs_conv3d_fwd_prelu_ms: the loader waves read every channel where it lies), or None when no such kernel
+    covers the shape -- the caller then concatenates."""
+    planes = _channel_planes(pieces)
+    if planes is None:
+        return None
+    pv, sv, Cin = planes
+    w = _need_cuda_f32("w", w, 5)
+    a = _need_cuda_f32("prelu_weight", prelu_weight, 1)
+    Cout = w.shape[0]
+    if w.shape[1] != Cin or tuple(w.shape[2:]) != (k, k, k):
+        raise ValueError("weight %s does not fit %d input channels" % (tuple(w.shape), Cin))
+    if bias is not None:
+        bias = _need_cuda_f32("bias", bias, 1)
+    x0 = pieces[0]
+    B = x0.shape[0]
+    Di, Hi, Wi = x0.shape[2:]
+    Do, Ho, Wo = [(n + 2 * pad - k) // stride + 1 for n in (Di, Hi, Wi)]
+    if min(Do, Ho, Wo) < 1:
+        return None
+    y = x0.new_empty((B, Cout, Do, Ho, Wo))
+    z = torch.empty_like(y)
+    ws = x0.new_empty(int(_lib.lib().fs_conv3d_fwd_ws_floats(Cin, Cout, int(k))))
+    xbytes = 4 * B * Cin * Di * Hi * Wi
+    with torch.cuda.device(x0.device):
+        rc = _call_rc("fs_conv3d_fwd_prelu_ms", pv, sv, w.data_ptr(), _ptr(bias), a.data_ptr(), y.data_ptr(), z.data_ptr(),
+                   ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(a.numel()),
+                      _stream(x0), algo_bytes=xbytes + 8 * y.numel(), algo_flops=2 * y.numel() * Cin * int(k) ** 3,
+                      record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
+    if rc == FS_ERR_UNSUPPORTED:
+        return None
+    return y, z
+
+
+def conv3d_wrw_ms(g, pieces, k, stride, pad):
+    """conv3d_wrw(g, torch.cat(pieces, 1), ...) without the concatenation (fs_conv3d_wrw_ms), or None."""
+    planes = _channel_planes(pieces)
+    if planes is None:
+        return None
+    pv, sv, Cs = planes
+    g = _need_cuda_f32("g", g, 5)
+    B, Cg = g.shape[:2]
+    Di, Hi, Wi = pieces[0].shape[2:]
+    dw = g.new_zeros(Cg, Cs, k, k, k)
+    with torch.cuda.device(g.device):
+        rc = _call_rc("fs_conv3d_wrw_ms", g.data_ptr(), pv, sv, dw.data_ptr(), B, Cg, Cs, g.shape[2], g.shape[3], g.shape[4],
+                   Di, Hi, Wi, int(k), int(stride), int(pad), _stream(g),
+                      algo_bytes=4 * (g.numel() + B * Cs * Di * Hi * Wi), algo_flops=2 * g.numel() * Cs * int(k) ** 3,
+                      record_as="fs_conv3d_wrw", allow=(FS_ERR_UNSUPPORTED,))
+    if rc == FS_ERR_UNSUPPORTED:
+        return None
+    return dw
 
 
 def conv3d_deconv_grad_input_dprelu(gy, w, act_y, prelu_weight):
