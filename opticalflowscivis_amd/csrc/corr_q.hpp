@@ -330,13 +330,18 @@ __global__ __launch_bounds__(512) void corr_bwd_q_kernel(C2Set a, int B, int C, 
   constexpr int ND = 2 * MD + 1;
   constexpr int SR = TY + 2 * MD, SV = (TX + 2 * MD + 3) / 4;
   constexpr int RV = (4 + 2 * MD + 3) / 4;    // float4 per channel of a row segment
-  constexpr int WP = 88;                       // window row pitch (2 channels x 40 px, + 8: rows r and r + 4 half a bank cycle apart)
+  // window row pitch: 2 channels x 40 px, + 8 spare.  A lane reads 16 bytes at float offset 8 quad + 4 k of its row (the
+  // pair interleave), so the 8 quads of a row cover every other group of 4 banks; the ds_read_b128 lane groups hold
+  // rows r and r + 4 (lane_quad), which must fill the gaps: rows with bit 2 set are stored 4 floats to the right
+  // (4 * 88 + 4 = 356 = 36 mod 64 banks).  Without the skew 34 % of the kernel's LDS cycles were bank conflicts
+  // (profiles/r02_corr_pmc_counters.txt).
+  constexpr int WP = 88;
   constexpr int WPAIR = SR * WP;
   constexpr int WFLOATS = (CBW / 2) * WPAIR;
   constexpr int GP = 40;                       // row pitch of a staged gradient plane (lane_quad)
   constexpr int GBUF = ND * TY * GP;           // one displacement row: ND planes x 8 rows
   constexpr int KW = CBW / 4, KG = (ND + 7) / 8;
-  static_assert(SR <= 16 && SV <= 16 && 8 * SV <= WP, "staging maps");
+  static_assert(SR <= 16 && SV <= 16 && 8 * SV + 4 <= WP, "staging maps");
   __shared__ __attribute__((aligned(16))) float s[WFLOATS + 2 * GBUF];
 
   const int CG = (C + CBW - 1) / CBW;
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(512) void corr_bwd_q_kernel(C2Set a, int B, int C, 
       }
       va = keep4(va, 2 * cp < nch ? wmask : 0);
       vb = keep4(vb, 2 * cp + 1 < nch ? wmask : 0);
-      float* wp = s + cp * WPAIR + wr * WP + 8 * wvx;
+      float* wp = s + cp * WPAIR + wr * WP + (wr & 4) + 8 * wvx;
       *reinterpret_cast<float4*>(wp) = make_float4(va.x, vb.x, va.y, vb.y);
       *reinterpret_cast<float4*>(wp + 4) = make_float4(va.z, vb.z, va.w, vb.w);
     }
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(512) void corr_bwd_q_kernel(C2Set a, int B, int C, 
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       v2f r2[4 * RV];  // r2[m] = (c0, c1) at pixel qx + m of window row qy + j
-      const float* rp = s + (wv * 2 + c) * WPAIR + (qy + j) * WP + 2 * qx;
+      const float* rp = s + (wv * 2 + c) * WPAIR + (qy + j) * WP + ((qy + j) & 4) + 2 * qx;
 #pragma unroll
       for (int k = 0; k < 2 * RV; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(rp + 4 * k);
