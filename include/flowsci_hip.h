@@ -367,6 +367,11 @@ int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, float* ws, int
  * with upsample = 0. */
 int fs_downsample3d_fwd(const float* in, float* out, int B, int C, int Din, int Hin, int Win,
                         int factor, float scale, fs_stream_t stream);
+/* the same over an input whose C <= 12 channels are planes of different tensors (IFBlock's `torch.cat` in front of its
+ * down-sampling, Flow-3D/model/IFNet.py:183 + :85): src[c] = channel c of sample 0, batch_strides[c] = that tensor's
+ * batch stride in floats (host arrays, read at launch). */
+int fs_downsample3d_fwd_ms(const float* const* src, const long long* batch_strides, float* out, int B, int C,
+                           int Din, int Hin, int Win, int factor, float scale, fs_stream_t stream);
 
 /* The 2-D pair (Flow-2D/model/IFNet.py:89, 92, 115-116): out = scale * F.interpolate(in, scale_factor =
  * factor (upsample = 1) or 1/factor (upsample = 0), mode="bilinear", align_corners=False), factor in {2, 4},

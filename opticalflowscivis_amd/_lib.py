@@ -43,6 +43,7 @@ SIGNATURES = {
     "fs_warp2d_pair_bwd": [_f32p] * 8 + [_int, _int, _intp, _int, _int, _int, _stream],
     "fs_interp3d_bwd_scaled": [_f32p] * 3 + [_int] * 10 + [_float, _stream],
     "fs_downsample3d_fwd": [_f32p] * 2 + [_int] * 6 + [_float, _stream],
+    "fs_downsample3d_fwd_ms": [_ptrv, _i64p, _f32p] + [_int] * 6 + [_float, _stream],
     "fs_resize2d_fwd": [_f32p] * 2 + [_int] * 8 + [_float, _stream],
     "fs_resize2d_bwd": [_f32p] * 2 + [_int] * 8 + [_float, _stream],
     "fs_occ_check2d": [_f32p] * 4 + [_int] * 3 + [_float, _float, _int, _stream],

@@ -32,7 +32,25 @@ struct IP {
   int up;           // 1: up-sampling by s, 0: down-sampling by s
   int s;
   long long nBC;    // B*C
+  // optional per-channel input planes (fs_downsample3d_fwd_ms: the C <= 12 channels of `small` live in different
+  // tensors -- IFBlock's torch.cat in front of its down-sampling, Flow-3D/model/IFNet.py:183 + :85): src[c] =
+  // channel c of sample 0, sbs[c] = that tensor's batch stride in floats.  nsrc = 0: one tensor.
+  int C, nsrc;
+  const float* src[12];
+  long long sbs[12];
 };
+
+// start of input plane bc = b * C + c
+__device__ __forceinline__ const float* in_plane(const float* __restrict__ small, const IP& p, long long bc, long long nin) {
+  if (p.nsrc == 0) return small + bc * nin;
+  const int b = (int)(bc / p.C), c = (int)(bc - (long long)b * p.C);
+  const float* q = p.src[0];
+  long long st = p.sbs[0];
+#pragma unroll
+  for (int i = 1; i < 12; ++i)
+    if (i < p.nsrc && c == i) { q = p.src[i]; st = p.sbs[i]; }  // (selects, not an indexed read of the arguments)
+  return q + (long long)b * st;
+}
 
 // weight with which output index o reads input index i along one axis (ATen
 // area_pixel_compute_source_index + the i0/i1/lambda of upsample_trilinear3d)
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(256) void upsample3d_scale_add_kernel(const float* 
     const int zp = (z0 < p.Di - 1) ? 1 : 0, yp = (y0 < p.Hi - 1) ? 1 : 0, xp = (x0 < p.Wi - 1) ? 1 : 0;
     const float lz1 = sz - (float)z0, ly1 = sy - (float)y0, lx1 = sx - (float)x0;
     const float lz0 = 1.f - lz1, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-    const float* s = small + bc * nin + ((long long)z0 * p.Hi + y0) * p.Wi + x0;
+    const float* s = in_plane(small, p, bc, nin) + ((long long)z0 * p.Hi + y0) * p.Wi + x0;
     const int dy = yp * p.Wi, dz = zp * p.Hi * p.Wi;
     const float v =
         lz0 * (ly0 * (lx0 * s[0] + lx1 * s[xp]) + ly1 * (lx0 * s[dy] + lx1 * s[dy + xp])) +
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(256) void upsample3d_scale_add_v4_kernel(const floa
     float lz0, lz1, ly0, ly1;
     fs::trilinear_axis(z, p.Di, p.rs, z0, zp, lz0, lz1);
     fs::trilinear_axis(y, p.Hi, p.rs, y0, yp, ly0, ly1);
-    const float* s00 = small + bc * nin + ((long long)z0 * p.Hi + y0) * p.Wi;
+    const float* s00 = in_plane(small, p, bc, nin) + ((long long)z0 * p.Hi + y0) * p.Wi;
     const float* s01 = s00 + yp * p.Wi;
     const float* s10 = s00 + (long long)zp * p.Hi * p.Wi;
     const float* s11 = s10 + yp * p.Wi;
@@ -346,6 +364,7 @@ extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, flo
     return FS_ERR_SHAPE;
   if (factor != 2 && factor != 4) return FS_ERR_ARG;
   IP p;
+  p.C = 1; p.nsrc = 0;
   p.Di = Din; p.Hi = Hin; p.Wi = Win; p.Do = Dout; p.Ho = Hout; p.Wo = Wout;
   p.up = upsample ? 1 : 0;
   p.s = factor;
@@ -399,6 +418,7 @@ extern "C" int fs_upsample3d_scale_add(const float* small, const float* prev, fl
   if (factor != 2 && factor != 4) return FS_ERR_ARG;
   if ((long long)Din * Hin * Win * factor * factor * factor >= (1ll << 31)) return FS_ERR_SHAPE;
   IP p;
+  p.C = 1; p.nsrc = 0;
   p.Di = Din; p.Hi = Hin; p.Wi = Win;
   p.Do = Din * factor; p.Ho = Hin * factor; p.Wo = Win * factor;
   p.up = 1; p.s = factor; p.rs = 1.0f / (float)factor;
@@ -416,19 +436,30 @@ extern "C" int fs_upsample3d_scale_add(const float* small, const float* prev, fl
 
 // out = scale * F.interpolate(in, scale_factor=1/factor, mode="trilinear", align_corners=False): the generic
 // ATen-order kernel with the source-index scale `factor`; output extent floor(in / factor).
-extern "C" int fs_downsample3d_fwd(const float* in, float* out, int B, int C, int Din, int Hin, int Win,
-                                   int factor, float scale, fs_stream_t stream) {
-  FS_ENTER();
-  FS_REQUIRE_PTR(in); FS_REQUIRE_PTR(out);
+static int downsample3d_impl(const float* in, const float* const* srcv, const long long* sbsv, float* out, int B, int C,
+                             int Din, int Hin, int Win, int factor, float scale, fs_stream_t stream) {
+  FS_REQUIRE_PTR(out);
+  if (srcv == nullptr) FS_REQUIRE_PTR(in);
   if (B < 1 || C < 1 || Din < 1 || Hin < 1 || Win < 1) return FS_ERR_SHAPE;
   if (factor != 2 && factor != 4) return FS_ERR_ARG;
   if (Din / factor < 1 || Hin / factor < 1 || Win / factor < 1) return FS_ERR_SHAPE;
   if ((long long)Din * Hin * Win >= (1ll << 31)) return FS_ERR_SHAPE;
   IP p;
+  p.C = 1; p.nsrc = 0;
   p.Di = Din; p.Hi = Hin; p.Wi = Win;
   p.Do = Din / factor; p.Ho = Hin / factor; p.Wo = Win / factor;
   p.up = 0; p.s = factor; p.rs = (float)factor;
   p.nBC = (long long)B * C;
+  p.C = C; p.nsrc = 0;
+  if (srcv != nullptr) {
+    if (C > 12) return FS_ERR_ARG;
+    p.nsrc = C;
+    for (int c = 0; c < C; ++c) {
+      if (srcv[c] == nullptr) return FS_ERR_NULLPTR;
+      if (sbsv[c] < (long long)Din * Hin * Win) return FS_ERR_ARG;
+      p.src[c] = srcv[c]; p.sbs[c] = sbsv[c];
+    }
+  }
   const long long total = p.nBC * p.Do * p.Ho * p.Wo;
   if ((p.Wo & 3) == 0 && ((uintptr_t)out & 15) == 0)
     hipLaunchKernelGGL(upsample3d_scale_add_v4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream,
@@ -438,6 +469,21 @@ extern "C" int fs_downsample3d_fwd(const float* in, float* out, int B, int C, in
                        (const float*)nullptr, out, p, scale);
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+
+extern "C" int fs_downsample3d_fwd(const float* in, float* out, int B, int C, int Din, int Hin, int Win,
+                                   int factor, float scale, fs_stream_t stream) {
+  FS_ENTER();
+  return downsample3d_impl(in, nullptr, nullptr, out, B, C, Din, Hin, Win, factor, scale, stream);
+}
+
+// fs_downsample3d_fwd over an input that is never concatenated: channel c is the plane src[c] (sample 0) of a tensor
+// with batch stride batch_strides[c] floats (host arrays of C <= 12 entries, read at launch).
+extern "C" int fs_downsample3d_fwd_ms(const float* const* src, const long long* batch_strides, float* out, int B, int C,
+                                      int Din, int Hin, int Win, int factor, float scale, fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(src); FS_REQUIRE_PTR(batch_strides);
+  return downsample3d_impl(nullptr, src, batch_strides, out, B, C, Din, Hin, Win, factor, scale, stream);
 }
 
 static int resize2d_dims(int Hin, int Win, int Hout, int Wout, int factor, int upsample) {

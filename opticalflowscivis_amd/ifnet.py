@@ -102,6 +102,7 @@ class IFBlock(nn.Module):
           "delta"  -- (flow_delta, mask_delta) at full resolution, nothing accumulated."""
         mode = _INTERP[self.nd]
         h0 = None
+        scale_x = scale  # 1 once x is at the block's working resolution
         if isinstance(x, (tuple, list)):
             # the caller's pieces (img0, img1, warped, mask, ...): at scale 1 the first convolution reads them
             # and the flow where they lie (3-D training: convgrad.conv_prelu_cat) or they are concatenated with
@@ -113,8 +114,13 @@ class IFBlock(nn.Module):
                     x = torch.cat(tuple(x) + (flow,), 1)
                 flow = None
             else:
-                x = torch.cat(tuple(x), 1)
-        if scale != 1:
+                # scales 2 / 4 (3-D, GPU): the down-sampling reads the pieces in place as well
+                xd = ops.interpolate3d_cat(tuple(x), scale) if (self.nd == 3 and x[0].is_cuda and scale in (2, 4)) else None
+                if xd is not None:
+                    x, scale_x = xd, 1
+                else:
+                    x = torch.cat(tuple(x), 1)
+        if scale_x != 1 and h0 is None:
             x = _resize(x, 1. / scale, mode)
         if flow is not None:
             if scale != 1:

@@ -1206,6 +1206,48 @@ class _Interp3D(torch.autograd.Function):
         return gx, None, None, None
 
 
+class _DownsampleCat(torch.autograd.Function):
+    """F.interpolate(torch.cat(pieces, 1), scale_factor=1/factor, trilinear) without the concatenation
+    (fs_downsample3d_fwd_ms reads every channel where it lies); backward: the adjoint over the concatenated
+    gradient, handed out as channel slices as torch.cat's backward would."""
+
+    @staticmethod
+    def forward(ctx, factor, *pieces):
+        planes = _channel_planes(pieces)
+        x0 = pieces[0]
+        B, (Di, Hi, Wi) = x0.shape[0], x0.shape[2:]
+        if planes is None or min(Di, Hi, Wi) // factor < 1:
+            raise ValueError("pieces cannot be read in place")  # (interpolate3d_cat checks first)
+        pv, sv, C = planes
+        y = x0.new_empty((B, C, Di // factor, Hi // factor, Wi // factor))
+        with torch.cuda.device(x0.device):
+            _call("fs_downsample3d_fwd_ms", pv, sv, y.data_ptr(), B, C, Di, Hi, Wi, int(factor), 1.0, _stream(x0),
+                  algo_bytes=4 * (B * C * Di * Hi * Wi + y.numel()), record_as="fs_downsample3d_fwd")
+        ctx.cfg = ((B, C, Di, Hi, Wi), int(factor), [int(t.shape[1]) for t in pieces])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, factor, splits = ctx.cfg
+        gy = _need_cuda_f32("grad_output", gy, 5)
+        gx = gy.new_empty(shape)
+        B, C, Di, Hi, Wi = shape
+        Do, Ho, Wo = gy.shape[2:]
+        with torch.cuda.device(gy.device):
+            _call("fs_interp3d_bwd_scaled", gy.data_ptr(), gx.data_ptr(), 0, B, C, Di, Hi, Wi, Do, Ho, Wo, factor, 0, 1.0,
+                  _stream(gy), algo_bytes=4 * (gy.numel() + gx.numel()), record_as="fs_interp3d_bwd")
+        need = ctx.needs_input_grad[1:]
+        return (None,) + tuple(g if n else None for g, n in zip(gx.split(splits, 1), need))
+
+
+def interpolate3d_cat(pieces, factor):
+    """F.interpolate(torch.cat(pieces, 1), scale_factor=1/factor, mode="trilinear", align_corners=False) for
+    factor 2 / 4 with the pieces read in place, or None when they cannot be (the caller concatenates)."""
+    if factor not in (2, 4) or _channel_planes(pieces) is None or min(pieces[0].shape[2:]) // factor < 1:
+        return None
+    return _DownsampleCat.apply(int(factor), *pieces)
+
+
 class _UpsampleScaleAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, small, prev, factor, scale):

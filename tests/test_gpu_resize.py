@@ -232,3 +232,27 @@ def test_warp2d_rife_input_extent_differs_from_flow_extent(ops):
     assert float((s.cpu() - ref0.detach()).abs().max()) < 2e-5
     with pytest.raises(ValueError):  # only the RIFE warp defines it
         ops.warp2d_pwc(x.to(DEV), f[:, :2].contiguous().to(DEV), with_mask=False)
+
+
+def test_downsample_reads_its_pieces_in_place(ops):
+    """ops.interpolate3d_cat == F.interpolate(torch.cat(pieces, 1)) bit for bit (same kernel, channels read where they
+    lie: contiguous frames and channel slices of a wider tensor), gradients equal to the concatenated path's."""
+    g = torch.Generator().manual_seed(17)
+    B, D, H, W = 2, 16, 24, 40
+    wide = torch.randn(B, 4, D, H, W, generator=g).to(DEV)
+    base = [torch.randn(B, 1, D, H, W, generator=g).to(DEV), wide[:, 1:2], wide[:, 2:4], torch.randn(B, 1, D, H, W, generator=g).to(DEV)]
+    for factor in (2, 4):
+        pa = [t.clone().requires_grad_(i != 0) for i, t in enumerate(base)]
+        pb = [t.clone().requires_grad_(i != 0) for i, t in enumerate(base)]
+        ya = ops.interpolate3d_cat(tuple(pa), factor)
+        yb = ops.interpolate3d(torch.cat(pb, 1), 1.0 / factor)
+        assert ya is not None and torch.equal(ya, yb)
+        ref = F.interpolate(torch.cat([t.cpu() for t in base], 1), scale_factor=1.0 / factor, mode="trilinear",
+                            align_corners=False, recompute_scale_factor=False)
+        assert float((ya.detach().cpu() - ref).abs().max()) < 1e-6
+        G = torch.randn(ya.shape, generator=g).to(DEV)
+        ga = torch.autograd.grad((ya * G).sum(), pa[1:])
+        gb = torch.autograd.grad((yb * G).sum(), pb[1:])
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b)
+    assert ops.interpolate3d_cat(tuple(base), 3) is None
