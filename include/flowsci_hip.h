@@ -192,6 +192,8 @@ int fs_occ_check2d(const float* flow_f, const float* flow_b, float* occ_f, float
  *   out[b,(dy+md)(2md+1)+(dx+md),y,x] = (1/C) sum_c f1[b,c,y,x] f2[b,c,y+dy,x+dx], zero pad.
  * md in 1..4.  bwd: grad_f1 / grad_f2 nullable (at least one), fully overwritten; no atomics,
  * bitwise reproducible.  The reference's rbot1/rbot2 scratch tensors have no equivalent.
+ * Sizes: B*C*H*W and (2md+1)^2*H*W below 2^29 floats (32-bit byte offsets inside a tensor / a sample's
+ * cost volume), FS_ERR_SHAPE otherwise; any alignment of rows (W need not be a multiple of 4).
  */
 int fs_corr2d_fwd(const float* f1, const float* f2, float* out,
                   int B, int C, int H, int W, int max_displacement, fs_stream_t stream);
@@ -245,6 +247,7 @@ int fs_plane_norm_bwd4(const float* fa, const float* fb, const float* fc, const 
 /* 3-D correlation: NEW capability named by BASELINE.json (config 4); the reference has no 3-D cost
  * volume, so this generalises the 2-D layer above (dz-major, then dy, dx; channel mean; zero pad):
  *   f1, f2 [B,C,D,H,W] -> out [B,(2md+1)^3,D,H,W].  Pinned to the reference only through D = 1.
+ * Sizes: B*C*D*H*W and (2md+1)^3*D*H*W below 2^29 floats, FS_ERR_SHAPE otherwise.
  */
 int fs_corr3d_fwd(const float* f1, const float* f2, float* out,
                   int B, int C, int D, int H, int W, int max_displacement, fs_stream_t stream);

@@ -29,7 +29,7 @@ namespace {
 
 #include "corr_q.hpp"
 
-// ---- coarse pyramid levels: direct kernels (h*w <= 512) -----------------------------------------------
+// ---- coarse pyramid levels: direct kernels (thresholds: kSmall* below) ------------------------------------
 // out[b, d, p] = (1/C) sum_c f1n[b,c,p] * f2n[b,c,p+d]: item = (b, d, p), CS channel slices per item laid
 // out CS-strided inside the wave (lane = slice * (64/CS) + item-in-wave), reduced with shuffles.
 template <int MD, int CS>
