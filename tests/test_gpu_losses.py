@@ -802,3 +802,46 @@ def test_conv0_reads_its_pieces_in_place(ops, with_gt):
     (gwc,) = torch.autograd.grad((zc * Gs.float().to(DEV)).sum(), [blk[0].weight]) if zc is not None else (None,)
     if gwc is not None:
         assert float((gwc.double().cpu() - gwd).abs().max()) < 2e-4 * float(gwd.abs().max())
+
+
+def test_corr_kernels_on_ragged_shapes(ops):
+    """Seeded sweep of fs_corr2d / fs_corr3d (forward + both gradients) against the oracle over shapes that stress the
+    tiled kernels' edges: rows of 1..5 and 31..70 floats (never 16-byte aligned, partial vectors at both row ends and
+    at the tensor's first / last float), single rows and slices, 1..65 channels (partial 8- and 32-channel groups),
+    md 1..4, both sides of the direct / tiled thresholds."""
+    import random
+    rnd = random.Random(1)
+    for it in range(28):
+        md = rnd.choice([1, 2, 3, 4])
+        B, C = rnd.choice([1, 2, 3]), rnd.choice([1, 2, 3, 5, 8, 17, 31, 32, 33, 40, 65])
+        H, W = rnd.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 23, 33]), rnd.choice([1, 2, 3, 4, 5, 31, 32, 33, 37, 63, 64, 65, 70])
+        g = torch.Generator().manual_seed(it)
+        f1, f2 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+        nd = 2 * md + 1
+        G = torch.randn(B, nd * nd, H, W, generator=g)
+        a, b = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+        ref = ocorr.corr2d_closed(a, b, md)
+        r1, r2 = torch.autograd.grad((ref * G).sum(), [a, b])
+        c, d = f1.to(DEV).requires_grad_(), f2.to(DEV).requires_grad_()
+        out = ops.corr2d(c, d, md)
+        g1, g2 = torch.autograd.grad((out * G.to(DEV)).sum(), [c, d])
+        where = ((B, C, H, W), md)
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5, where
+        assert float((g1.cpu() - r1).abs().max()) < 5e-5 and float((g2.cpu() - r2).abs().max()) < 5e-5, where
+    for it in range(10):
+        md = rnd.choice([1, 2, 4])
+        B, C = rnd.choice([1, 2]), rnd.choice([1, 3, 8, 33, 40])
+        D, H, W = rnd.choice([1, 2, 5, 9]), rnd.choice([1, 4, 9, 17]), rnd.choice([3, 8, 33, 40])
+        g = torch.Generator().manual_seed(100 + it)
+        f1, f2 = torch.randn(B, C, D, H, W, generator=g), torch.randn(B, C, D, H, W, generator=g)
+        nd = 2 * md + 1
+        G = torch.randn(B, nd ** 3, D, H, W, generator=g)
+        a, b = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+        ref = ocorr.corr3d_closed(a, b, md)
+        r1, r2 = torch.autograd.grad((ref * G).sum(), [a, b])
+        c, d = f1.to(DEV).requires_grad_(), f2.to(DEV).requires_grad_()
+        out = ops.corr3d(c, d, md)
+        g1, g2 = torch.autograd.grad((out * G.to(DEV)).sum(), [c, d])
+        where = ((B, C, D, H, W), md)
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5, where
+        assert float((g1.cpu() - r1).abs().max()) < 1e-4 and float((g2.cpu() - r2).abs().max()) < 1e-4, where
