@@ -2,9 +2,9 @@
 // matrix cores (v_mfma_f32_32x32x2_f32) for gfx950.
 //
 // Not one of the §8(a) rows (companions: convfwd.hip, convtr.hip).  MIOpen (ROCm 7.2, no gfx950 tuning
-// db) spends 10-80 ms per layer on this one reduction, and the stock-PyTorch replacement (convgrad.py,
-// FLOWSCI_CONV_WRW=gemm: materialised im2col + split-K GEMM) still moves ~125 GB of im2col per 256^3
-// step.  The weight gradient is a GEMM with a tiny output and a huge reduction,
+// db) spends 10-80 ms per layer on this one reduction, and a stock-PyTorch replacement (materialised im2col
+// + split-K GEMM, round 1's first attempt, since removed) still moved ~125 GB of im2col per 256^3 step.
+// The weight gradient is a GEMM with a tiny output and a huge reduction,
 //
 //   dW[g, c, kz,ky,kx] = sum_{b,oz,oy,ox} G[b,g,oz,oy,ox] * S[b,c, oz*s+kz-p, oy*s+ky-p, ox*s+kx-p]
 //
