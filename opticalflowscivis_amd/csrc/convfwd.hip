@@ -756,8 +756,22 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     return launch<4, 2, 2, 1, 2, 1, 8, 16>(x, ws, bias, y, p, st);
   }
   if (ws_ok && 2 * k4tiles * (p.CoutP / 64) >= 512) return launch_ws<4, 2, 2, 2, 2, 1, 8, 32>(x, ws, bias, y, p, st);
-  if (Wo > 16) return launch<4, 2, 2, 2, 2, 1, 8, 32>(x, ws, bias, y, p, st);
-  return launch<4, 2, 2, 2, 2, 1, 8, 16>(x, ws, bias, y, p, st);
+  // coarse blocks (block1's conv0[1] at 32^3, block0's at 16^3 and the input gradients of their heads): 2 x 8 x 32
+  // bricks are 128 / 32 workgroups for 256 CUs -- quarter-size bricks, and 32-channel workgroups below one per CU
+  // (64 -> 128 at 32^3 -> 16^3: 0.29 ms at 28 TFLOP/s with 32 workgroups)
+  const bool wide = Wo > 16;
+  const long long big = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, wide ? 8 : 16) * fs::cdiv(Wo, wide ? 32 : 16) * (p.CoutP / 64);
+  if (big >= 256) {
+    if (wide) return launch<4, 2, 2, 2, 2, 1, 8, 32>(x, ws, bias, y, p, st);
+    return launch<4, 2, 2, 2, 2, 1, 8, 16>(x, ws, bias, y, p, st);
+  }
+  const long long small = (long long)B * Do * fs::cdiv(Ho, wide ? 4 : 8) * fs::cdiv(Wo, wide ? 32 : 16) * (p.CoutP / 64);
+  if (small >= 256) {
+    if (wide) return launch<4, 2, 2, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
+    return launch<4, 2, 2, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
+  }
+  if (wide) return launch<4, 2, 2, 1, 1, 1, 4, 32>(x, ws, bias, y, p, st);
+  return launch<4, 2, 2, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
 }
 
 extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B,

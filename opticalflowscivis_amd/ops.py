@@ -1618,8 +1618,14 @@ def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
             return big
         small = B * Do * cd(Ho, 4 * r) * cd(Wo, tw) * mg
         return small if small >= 256 else 2 * small  # 32-channel workgroups when 64-channel ones cannot fill the chip
-    mg = 1 if Cout <= 32 else cd(Cout, 64)
-    return B * Do * cd(Ho, 8 * r) * cd(Wo, tw) * mg
+    if Cout <= 32:
+        return B * Do * cd(Ho, 8 * r) * cd(Wo, tw)
+    mg = cd(Cout, 64)
+    big = B * cd(Do, 2) * cd(Ho, 8 * r) * cd(Wo, tw) * mg
+    if big >= 256:
+        return big
+    small = B * Do * cd(Ho, 4 * r) * cd(Wo, tw) * mg  # quarter-size bricks, then 32-channel workgroups
+    return small if small >= 256 else 2 * small
 
 
 def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=None):
