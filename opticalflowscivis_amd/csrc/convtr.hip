@@ -1129,8 +1129,10 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   p.tiles = (long long)B * p.tz * p.ty * p.tx;
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
   // loader-wave kernels: 16-byte pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets
-  // inside a staged 4-channel chunk, at least two bricks per CU.  `FLOWSCI_TR_REG=1`: the register-staged kernels.
-  const bool ws_ok = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && p.tiles >= 512 &&
+  // inside a staged 4-channel chunk.  They also win when the launch cannot fill the chip (block0's 128 -> 64
+  // deconvolution at 16^3: 128 bricks per 32-channel slice, 0.42 -> 0.29 ms): one 8-wave workgroup per CU overlaps
+  // its staging with its MFMAs, two half-empty 4-wave workgroups do not.  `FLOWSCI_TR_REG=1`: the register-staged kernels.
+  const bool ws_ok = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && p.tiles >= 128 &&
                      (long long)4 * Di * Hi * Wi * 4 < (1ll << 31);
   if (Cout <= 16) {
     hipLaunchKernelGGL(wprep_tr16_kernel, dim3((cinp * 64 * 16 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
