@@ -606,24 +606,36 @@ int launch(const float* X, const float* Wt, const float* bias, float* Y, FP& p, 
   return FS_OK;
 }
 
-// ga[c] = sum of the slope-gradient partials of channel c (all channels when the slope is shared), gb[c] = sum of the
-// bias-gradient partials: one block per output, fixed order, fp64 -- deterministic
-__global__ __launch_bounds__(256) void dprelu_finish_kernel(const float* __restrict__ part, int rows_per_group, int CP,
-                                                            int Cout, float* __restrict__ ga, float* __restrict__ gb,
-                                                            int nslope) {
+// The per-wave partial rows [rows][32 channels][2: slope-gradient term, bias-gradient term] are summed in two fixed
+// stages, fp64 -- deterministic: kFinishBlocks workgroups reduce contiguous row ranges reading whole 256-byte rows (a
+// block per output walking its column with a 256-byte stride took 47 us per head), then one block per output adds the
+// kFinishBlocks partials in order.  ga[c]: all channels when the slope is shared.
+constexpr int kFinishBlocks = 128;
+__global__ __launch_bounds__(256) void dprelu_finish1_kernel(const float* __restrict__ part, int rows,
+                                                             double* __restrict__ partial) {
+  const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int chunk = (rows + kFinishBlocks - 1) / kFinishBlocks;
+  const int r0 = blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+  double s = 0.0;
+  for (int r = r0 + sub; r < r1; r += 4) s += (double)part[(size_t)r * 64 + col];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0) partial[(size_t)blockIdx.x * 64 + col] = ((red[col] + red[64 + col]) + red[128 + col]) + red[192 + col];
+}
+__global__ __launch_bounds__(64) void dprelu_finish2_kernel(const double* __restrict__ partial, int Cout,
+                                                            float* __restrict__ ga, float* __restrict__ gb, int nslope) {
   const bool bias_blk = (int)blockIdx.x >= nslope;
   const int c = bias_blk ? blockIdx.x - nslope : blockIdx.x;
   const bool all = !bias_blk && nslope == 1 && Cout != 1;
-  __shared__ double red[256];
-  double s = 0.0;
   const int c_lo = all ? 0 : c, c_hi = all ? Cout : c + 1;
-  for (int cc = c_lo; cc < c_hi; ++cc) {
-    const float* src = part + ((size_t)(cc / CP) * rows_per_group * CP + (cc % CP)) * 2 + (bias_blk ? 1 : 0);
-    for (int i = threadIdx.x; i < rows_per_group; i += 256) s += (double)src[(size_t)i * CP * 2];
-  }
+  double s = 0.0;  // thread g < kFinishBlocks / 2 adds partials g and g + 64 of its channels, then a fixed tree
+  for (int cc = c_lo; cc < c_hi; ++cc)
+    for (int g = threadIdx.x; g < kFinishBlocks; g += 64) s += partial[(size_t)g * 64 + cc * 2 + (bias_blk ? 1 : 0)];
+  __shared__ double red[64];
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
+  for (int st = 32; st > 0; st >>= 1) {
     if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
@@ -744,8 +756,12 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
       return FS_ERR_UNSUPPORTED;
     const int rc = launch_ws<4, 2, 2, 1, 4, 2, 8, 32>(x, ws, bias, y, p, st);
     if (rc != FS_OK) return rc;
-    hipLaunchKernelGGL(dprelu_finish_kernel, dim3(dp->nslope + Cout), dim3(256), 0, st, dp->part, (int)(k4tiles * 4), 32,
-                       Cout, dp->ga, dp->gb, dp->nslope);
+    // (the stage-1 partials live behind the rows in `part`: fs_conv3d_fwd_dprelu_part_floats reserves them, 8-byte aligned)
+    const long long rows = k4tiles * 4;
+    double* partial = reinterpret_cast<double*>(dp->part + (rows * 64 + 1) / 2 * 2);
+    hipLaunchKernelGGL(dprelu_finish1_kernel, dim3(kFinishBlocks), dim3(256), 0, st, dp->part, (int)rows, partial);
+    hipLaunchKernelGGL(dprelu_finish2_kernel, dim3(dp->nslope + Cout), dim3(64), 0, st, partial, Cout, dp->ga, dp->gb,
+                       dp->nslope);
     FS_LAUNCH_CHECK();
     return FS_OK;
   }
@@ -822,7 +838,7 @@ extern "C" int fs_conv3d_fwd_prelu_ms(const float* const* src, const long long* 
 // fixed order).  FS_ERR_UNSUPPORTED when the shape / alignment has no such kernel: use fs_conv3d_fwd + fs_prelu_bwd.
 extern "C" long long fs_conv3d_fwd_dprelu_part_floats(int B, int Cout, int Do, int Ho, int Wo) {
   if (B < 1 || Cout < 1 || Cout > 32 || Do < 1 || Ho < 1 || Wo < 1) return -1;
-  return (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, 8) * fs::cdiv(Wo, 32) * 4 * 32 * 2;
+  return (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, 8) * fs::cdiv(Wo, 32) * 4 * 32 * 2 + 2 + kFinishBlocks * 64 * 2;
 }
 
 extern "C" int fs_conv3d_fwd_dprelu(const float* x, const float* w, const float* act_y, const float* prelu_weight,
