@@ -45,7 +45,25 @@ struct TP {
   // optional residual: Y = conv + bias + addend (same shape as Y) -- IFNet's `flow = flow + flow_d`
   const float* addend;
   const float* Ybase;  // = Y (to locate the addend plane of a channel)
+  // 32-channel slices of a wider output in ONE launch of the 32-row kernels (blockIdx.y = slice): floats between the
+  // slices' re-laid-out weights; the output-side pointers move by 32 channels per slice
+  long long wslice;
 };
+
+// blockIdx.y-th 32-channel slice of a launch that covers several (block0's 128 -> 64 deconvolution: two half-empty
+// launches one after the other become one that fills the chip)
+__device__ __forceinline__ void tr_slice(TP& p, const float*& Wt, const float*& bias, float*& Y) {
+  const int sl = blockIdx.y;
+  if (sl == 0) return;
+  const size_t off = (size_t)sl * 32 * ((size_t)p.Dout * p.Hout * p.Wout);
+  Wt += (size_t)sl * p.wslice;
+  if (bias) bias += 32 * sl;
+  Y += off;
+  if (p.Z) p.Z += off;
+  if (p.slope && p.nslope != 1) p.slope += 32 * sl;
+  if (p.addend) p.addend += off;
+  p.Ybase += off;
+}
 
 // tap a (0/1) of output parity p along one axis: input offset d and kernel index k
 __device__ __forceinline__ constexpr int tap_d(int p, int a) { return p == 0 ? (a == 0 ? 0 : -1) : (a == 0 ? 1 : 0); }
@@ -144,9 +162,13 @@ __device__ __forceinline__ void store8_quad(float* __restrict__ yc, const float 
 
 template <int TZ, int TY>
 __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __restrict__ X,
-                                                          const float* __restrict__ Wt,
-                                                          const float* __restrict__ bias,
-                                                          float* __restrict__ Y, TP p) {
+                                                          const float* __restrict__ Wt_,
+                                                          const float* __restrict__ bias_,
+                                                          float* __restrict__ Y_, TP p) {
+  const float* Wt = Wt_;
+  const float* bias = bias_;
+  float* Y = Y_;
+  tr_slice(p, Wt, bias, Y);
   static_assert(TZ * TY == 4, "one 32-position row per wave");
   constexpr int CI = 4;
   constexpr int ZT = TZ + 2, YT = TY + 2, XT = 34;
@@ -474,9 +496,13 @@ __device__ __forceinline__ void tr_loader(const float* __restrict__ X, const flo
 
 template <int TZ, int TY>
 __global__ __launch_bounds__(512, 2) void convtr_mfma_ws_kernel(const float* __restrict__ X,
-                                                             const float* __restrict__ Wt,
-                                                             const float* __restrict__ bias,
-                                                             float* __restrict__ Y, TP p) {
+                                                             const float* __restrict__ Wt_,
+                                                             const float* __restrict__ bias_,
+                                                             float* __restrict__ Y_, TP p) {
+  const float* Wt = Wt_;
+  const float* bias = bias_;
+  float* Y = Y_;
+  tr_slice(p, Wt, bias, Y);
   static_assert(TZ * TY == 4, "one 32-position row per matrix wave");
   constexpr int CI = 4;
   constexpr int ZT = TZ + 2, YT = TY + 2, XP = 40;
@@ -1057,17 +1083,18 @@ extern "C" int fs_debug_tr_stamps(unsigned long long* out) {
 
 extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   if (Cin < 1 || Cout < 1 || (Cout > 32 && (Cout % 32 != 0 || Cout > 128))) return -1;
-  if (Cout > 32) Cout = 32;  // 32-channel slices, one after the other
+  const int slices = Cout > 32 ? Cout / 32 : 1;  // 32-channel slices, each with its own re-laid-out weights
+  if (Cout > 32) Cout = 32;
   const long long cinp = (Cin + 3) / 4 * 4;
   // W'[ci][neighbour][row] (+ pad) of the all-parities kernel (<= 12 channels), or the slabs of the class kernels
   const long long p8 = Cout <= 12 ? cinp * p8_ws_ci(Cout <= 2 ? 1 : (Cout <= 6 ? 3 : 6)) : 0;
   const long long cls = Cout <= 6 ? 0 : cinp * 64 * (Cout <= 16 ? 16 : 32);
-  return p8 > cls ? p8 : cls;
+  return (p8 > cls ? p8 : cls) * slices;
 }
 
 static int conv3d_tr_slice(const float* x, const float* w, const float* bias, const float* slope, int nslope,
                           const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di,
-                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream, int CoutT = 0) {
+                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream, int CoutT = 0, int slices = 1) {
   FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1) return FS_ERR_SHAPE;
@@ -1086,6 +1113,7 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   p.Dq = (Dout + 1) / 2; p.Hq = (Hout + 1) / 2; p.Wq = (Wout + 1) / 2;
   p.slope = slope; p.Z = z; p.nslope = nslope;
   p.addend = addend; p.Ybase = y;
+  p.wslice = 0;
   hipStream_t st = (hipStream_t)stream;
   if ((long long)B * p.Dq * p.Hq * p.Wq >= (1ll << 31) * 256) return FS_ERR_SHAPE;
   static const bool reg_only = getenv("FLOWSCI_TR_REG") != nullptr;
@@ -1132,7 +1160,7 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   // inside a staged 4-channel chunk.  They also win when the launch cannot fill the chip (block0's 128 -> 64
   // deconvolution at 16^3: 128 bricks per 32-channel slice, 0.42 -> 0.29 ms): one 8-wave workgroup per CU overlaps
   // its staging with its MFMAs, two half-empty 4-wave workgroups do not.  `FLOWSCI_TR_REG=1`: the register-staged kernels.
-  const bool ws_ok = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && p.tiles >= 128 &&
+  const bool ws_ok = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && p.tiles * slices >= 128 &&
                      (long long)4 * Di * Hi * Wi * 4 < (1ll << 31);
   if (Cout <= 16) {
     hipLaunchKernelGGL(wprep_tr16_kernel, dim3((cinp * 64 * 16 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
@@ -1142,12 +1170,14 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
     else
       hipLaunchKernelGGL((convtr_mfma16_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
   } else {
-    hipLaunchKernelGGL(wprep_tr_kernel, dim3((cinp * 64 * 32 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
-                       cinp, p.CoutT);
+    p.wslice = (long long)cinp * 64 * 32;
+    for (int sl = 0; sl < slices; ++sl)
+      hipLaunchKernelGGL(wprep_tr_kernel, dim3((cinp * 64 * 32 + 255) / 256), dim3(256), 0, st, w + (size_t)sl * 32 * 64,
+                         ws + (size_t)sl * p.wslice, Cin, Cout, cinp, p.CoutT);
     if (ws_ok)
-      hipLaunchKernelGGL((convtr_mfma_ws_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(512), 0, st, x, ws, bias, y, p);
+      hipLaunchKernelGGL((convtr_mfma_ws_kernel<2, 2>), dim3((unsigned)p.tiles, slices), dim3(512), 0, st, x, ws, bias, y, p);
     else
-      hipLaunchKernelGGL((convtr_mfma_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
+      hipLaunchKernelGGL((convtr_mfma_kernel<2, 2>), dim3((unsigned)p.tiles, slices), dim3(256), 0, st, x, ws, bias, y, p);
   }
   FS_LAUNCH_CHECK();
   return FS_OK;
@@ -1162,15 +1192,9 @@ static int conv3d_tr_impl(const float* x, const float* w, const float* bias, con
   if (Cout <= 32) return conv3d_tr_slice(x, w, bias, slope, nslope, addend, y, z, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout,
                                          Wout, stream);
   if (Cout % 32 != 0 || Cout > 128 || Dout < 1 || Hout < 1 || Wout < 1) return FS_ERR_ARG;
-  const size_t yvol = (size_t)Dout * Hout * Wout;
-  for (int c0 = 0; c0 < Cout; c0 += 32) {
-    const int rc = conv3d_tr_slice(x, w + (size_t)c0 * 64, bias ? bias + c0 : nullptr,
-                                   slope ? (nslope == 1 ? slope : slope + c0) : nullptr, nslope == 1 ? 1 : (nslope ? 32 : 0),
-                                   addend ? addend + c0 * yvol : nullptr, y + c0 * yvol, z ? z + c0 * yvol : nullptr, ws, B,
-                                   Cin, 32, Di, Hi, Wi, Dout, Hout, Wout, stream, Cout);
-    if (rc != FS_OK) return rc;
-  }
-  return FS_OK;
+  // all 32-channel slices in one launch (grid.y): pointers of slice 0, the kernels step to theirs
+  return conv3d_tr_slice(x, w, bias, slope, nslope == 1 ? 1 : (nslope ? 32 : 0), addend, y, z, ws, B, Cin, 32, Di, Hi, Wi, Dout,
+                         Hout, Wout, stream, Cout, Cout / 32);
 }
 
 extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws, int B,
