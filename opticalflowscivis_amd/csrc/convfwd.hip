@@ -790,10 +790,17 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     return launch<4, 2, 2, 2, 2, 1, 8, 16>(x, ws, bias, y, p, st);
   }
   const long long small = (long long)B * Do * fs::cdiv(Ho, wide ? 4 : 8) * fs::cdiv(Wo, wide ? 32 : 16) * (p.CoutP / 64);
+  // (loader-wave form here too: 64 -> 128 at 32^3 0.111 -> 0.081 ms, 32 -> 64 at 64^3 0.164 -> 0.151 ms)
+  const bool ws4 = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && ms == nullptr &&
+                   (long long)2 * Di * Hi * Wi * 4 < (1ll << 31);
   if (small >= 256) {
+    if (ws4 && wide) return launch_ws<4, 2, 2, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
+    if (ws4) return launch_ws<4, 2, 2, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
     if (wide) return launch<4, 2, 2, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
     return launch<4, 2, 2, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
   }
+  if (ws4 && wide) return launch_ws<4, 2, 2, 1, 1, 1, 4, 32>(x, ws, bias, y, p, st);
+  if (ws4) return launch_ws<4, 2, 2, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
   if (wide) return launch<4, 2, 2, 1, 1, 1, 4, 32>(x, ws, bias, y, p, st);
   return launch<4, 2, 2, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
 }
