@@ -717,9 +717,8 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   const int total = cinp * K3 * p.CoutP;
   hipLaunchKernelGGL(wprep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, ws, Cout, Cin, K3, cinp,
                      p.CoutP, wmode);
-  // loader-wave kernels (k = 4: 100 / 129 TFLOP/s vs 92 / 120 for conv0a / conv0b at 256^3; k = 3: the small layers
-  // below -- the 64-channel layers at 64^3 run at 132 TFLOP/s in either form and stay on the two-workgroups-per-CU
-  // kernel): 16-byte
+  // loader-wave kernels (k = 4: 100 / 129 TFLOP/s vs 92 / 120 for conv0a / conv0b at 256^3; k = 3: every 32-column
+  // layer, see below): 16-byte
   // pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets inside one staged channel
   // chunk, enough bricks to fill the chip with one workgroup per CU
   static const bool reg_only = getenv("FLOWSCI_FWD_REG") != nullptr;
@@ -735,6 +734,11 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     const long long big = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, wide ? 8 : 16) * fs::cdiv(Wo, wide ? 32 : 16) *
                           (p.CoutP / 64);
     if (big >= 512) {
+      // loader-wave form since its epilogue stores 16 bytes per lane (round 2; before that the two forms tied at
+      // 132 TFLOP/s): 64 -> 64 at 64^3 0.886 -> 0.860 ms = 135 TFLOP/s, -0.9 ms per step (A/B on one box)
+      if (wide && !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && dp == nullptr &&
+          (long long)4 * Di * Hi * Wi * 4 < (1ll << 31))
+        return launch_ws<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
       if (wide) return launch<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
       return launch<3, 1, 4, 2, 4, 2, 8, 16>(x, ws, bias, y, p, st);
     }
@@ -743,7 +747,7 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     const long long small = (long long)B * Do * fs::cdiv(Ho, wide ? 4 : 8) * fs::cdiv(Wo, wide ? 32 : 16) * (p.CoutP / 64);
     // the coarse blocks' trunk layers take the loader-wave form (64 -> 64 at 32^3: 0.145 -> 0.125 ms = 116 TFLOP/s;
     // 128 -> 128 at 16^3: 0.107 -> 0.068 ms = 106 TFLOP/s): with about one workgroup per CU, eight waves that overlap
-    // staging and MFMAs beat two independent four-wave workgroups; at 64^3 (>= 512 big bricks) the two forms tie
+    // staging and MFMAs beat two independent four-wave workgroups
     const bool ws3 = !reg_only && Wi % 4 == 0 && (((ms ? (uintptr_t)0 : (uintptr_t)x) | (uintptr_t)ws) & 15) == 0 &&
                      (long long)4 * Di * Hi * Wi * 4 < (1ll << 31) && dp == nullptr;
     if (small < 256) {
