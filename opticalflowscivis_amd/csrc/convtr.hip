@@ -923,6 +923,18 @@ __global__ __launch_bounds__(512, 2) void convtr_p8_kernel(const float* __restri
                                   (size_t)(iok ? yo : 0) * p.Wout;
         const float* __restrict__ arow = p.addend ? p.addend + (row - Y) : nullptr;
         (void)yvol;
+        // the running-flow / mask addend of this row tile: all its 16-byte loads first, so that they are in flight
+        // together instead of one load -> wait -> add -> store chain per position tile
+        float4 apre[NT];
+        if (arow != nullptr) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int qa = evn ? q0 + 16 * n + col : q0 + 16 * n + col - 1;
+            const int x0 = 2 * qa - 1;
+            const bool full = iok && qa >= 1 && qa + 1 < qend && x0 + 3 < p.Wout;
+            apre[n] = full ? *reinterpret_cast<const float4*>(arow + x0) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int q = q0 + 16 * n + col;
@@ -943,10 +955,7 @@ __global__ __launch_bounds__(512, 2) void convtr_p8_kernel(const float* __restri
             const int x0 = 2 * qa - 1;     // outputs x0 .. x0 + 3 <- positions qa, qa, qa + 1, qa + 1
             const bool full = qa >= 1 && qa + 1 < qend && x0 + 3 < p.Wout;
             if (full) {
-              if (arow) {
-                const float4 a4 = *reinterpret_cast<const float4*>(arow + x0);
-                v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
-              }
+              if (arow) { v.x += apre[n].x; v.y += apre[n].y; v.z += apre[n].z; v.w += apre[n].w; }
               *reinterpret_cast<float4*>(row + x0) = v;  // 4-byte aligned 16-byte store
             } else {
               const float vv[4] = {v.x, v.y, v.z, v.w};
