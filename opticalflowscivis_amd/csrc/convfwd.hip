@@ -538,6 +538,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
         const bool cok = co < p.Cout;
         const float bv = (bias != nullptr && cok) ? bias[co] : 0.f;
         const float sv = (Zp != nullptr && cok) ? slope[p.nslope == 1 ? 0 : co] : 0.f;
+        // the addend (a residual unit's skip tensor / skip gradient) of this channel: its NT 16-byte loads first, in
+        // flight together, instead of one load -> wait -> add -> store chain per row
+        float4 apre[NT];
+        if (ad != nullptr) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int oy = oy0 + (wy + n) * R + ly;
+            const bool in = cok && oy < p.Ho && xq + 3 < p.Wo;
+            const size_t o = ((size_t)b * p.Cout + (cok ? co : 0)) * yvol + ((size_t)oz * p.Ho + (oy < p.Ho ? oy : 0)) * p.Wo + xq;
+            apre[n] = in ? *reinterpret_cast<const float4*>(ad + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           float a0 = acc[m][n][4 * j], a1 = acc[m][n][4 * j + 1], a2 = acc[m][n][4 * j + 2], a3 = acc[m][n][4 * j + 3];
@@ -552,8 +564,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
           const size_t o = ((size_t)b * p.Cout + co) * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + xq;
           float4 v = make_float4(a0 + bv, a1 + bv, a2 + bv, a3 + bv);
           if (xq + 3 < p.Wo) {
-            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ad != nullptr) av = *reinterpret_cast<const float4*>(ad + o);
+            const float4 av = ad != nullptr ? apre[n] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (Zp != nullptr) {
               *reinterpret_cast<float4*>(Yp + o) = v;
               *reinterpret_cast<float4*>(Zp + o) = make_float4((v.x > 0.f ? v.x : sv * v.x) + av.x, (v.y > 0.f ? v.y : sv * v.y) + av.y,
