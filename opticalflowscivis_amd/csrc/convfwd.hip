@@ -453,59 +453,93 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
   }
 
   if (p.dy != nullptr) {
-    // ---- fused PReLU-backward epilogue
+    // ---- fused PReLU-backward epilogue: g * prelu'(act_y) stored instead of g, per-wave partial sums of the slope
+    // gradient (g * act_y where act_y <= 0) and of the stored values (the producing layer's bias gradient).  Same 4 x 4
+    // (lane x register) quad transpose as the plain epilogue below: a lane ends up with 4 consecutive x of ONE
+    // channel -- one 16-byte load of act_y and one 16-byte store per (channel block, row) instead of four dword pairs.
     const float* __restrict__ dy = p.dy;
     float* __restrict__ Yg = Y;
-    float pa[MT][16], pb[MT][16];
+    const int oz = oz0 + wz;
+    const int qi = lane & 3;
+    const int xq = ox0 + (lx & ~3);
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    auto swap1 = [](float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, false)); };
+    auto swap2 = [](float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, false)); };
+    float pa[MT][4], pb[MT][4];  // this lane's channel of block j: qi + 8 j + 4 kh
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pa[m][r] = pb[m][r] = 0.f;
-    const int oz = oz0 + wz, ox = ox0 + lx;
-    if (oz < p.Do && ox < p.Wo) {
-      const size_t yvol = (size_t)p.Do * p.Ho * p.Wo;
+      for (int j = 0; j < 4; ++j) pa[m][j] = pb[m][j] = 0.f;
+    const size_t yvol = (size_t)p.Do * p.Ho * p.Wo;
+    if (oz < p.Do) {  // wave-uniform
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int oy = oy0 + (wy + n) * R + ly;
-        if (oy >= p.Ho) continue;
-        const size_t o0 = (size_t)b * p.Cout * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + ox;
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          float yv[16];
+        for (int j = 0; j < 4; ++j) {
+          const int co = co0 + m * 32 + qi + 8 * j + 4 * kh;
+          const bool cok = co < p.Cout;
+          const float sl = cok ? p.dslope[p.dnslope == 1 ? 0 : co] : 0.f;
+          float4 yv[NT];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {  // all loads of the tile first
-            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            yv[r] = co < p.Cout ? dy[o0 + (size_t)co * yvol] : 1.f;
+          for (int n = 0; n < NT; ++n) {  // all loads of the channel first
+            const int oy = oy0 + (wy + n) * R + ly;
+            const bool in = cok && oy < p.Ho && xq + 3 < p.Wo;
+            const size_t o = ((size_t)b * p.Cout + (cok ? co : 0)) * yvol + ((size_t)oz * p.Ho + (oy < p.Ho ? oy : 0)) * p.Wo + xq;
+            yv[n] = in ? *reinterpret_cast<const float4*>(dy + o) : make_float4(1.f, 1.f, 1.f, 1.f);
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (co < p.Cout) {
-              const float g = acc[m][n][r];
-              const float sl = p.dslope[p.dnslope == 1 ? 0 : co];
-              const float o = yv[r] > 0.f ? g : sl * g;
-              pa[m][r] += yv[r] > 0.f ? 0.f : yv[r] * g;
-              pb[m][r] += o;
-              Yg[o0 + (size_t)co * yvol] = o;
+          for (int n = 0; n < NT; ++n) {
+            float a0 = acc[m][n][4 * j], a1 = acc[m][n][4 * j + 1], a2 = acc[m][n][4 * j + 2], a3 = acc[m][n][4 * j + 3];
+            {
+              const float rA = swap1(b0 ? a0 : a1), rB = swap1(b0 ? a2 : a3);
+              if (b0) { a0 = rA; a2 = rB; } else { a1 = rA; a3 = rB; }
+              const float rC = swap2(b1 ? a0 : a2), rD = swap2(b1 ? a1 : a3);
+              if (b1) { a0 = rC; a1 = rD; } else { a2 = rC; a3 = rD; }
+            }
+            const int oy = oy0 + (wy + n) * R + ly;
+            if (!cok || oy >= p.Ho || xq >= p.Wo) continue;
+            const size_t o = ((size_t)b * p.Cout + co) * yvol + ((size_t)oz * p.Ho + oy) * p.Wo + xq;
+            if (xq + 3 < p.Wo) {
+              const float g[4] = {a0, a1, a2, a3};
+              const float y4[4] = {yv[n].x, yv[n].y, yv[n].z, yv[n].w};
+              float o4[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                o4[e] = y4[e] > 0.f ? g[e] : sl * g[e];
+                pa[m][j] += y4[e] > 0.f ? 0.f : y4[e] * g[e];
+                pb[m][j] += o4[e];
+              }
+              *reinterpret_cast<float4*>(Yg + o) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            } else {
+              const float g[4] = {a0, a1, a2, a3};
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (xq + e < p.Wo) {
+                  const float y1 = dy[o + e];
+                  const float o1 = y1 > 0.f ? g[e] : sl * g[e];
+                  pa[m][j] += y1 > 0.f ? 0.f : y1 * g[e];
+                  pb[m][j] += o1;
+                  Yg[o + e] = o1;
+                }
             }
           }
         }
-      }
     }
-    // the 32 lanes of a half-wave hold the same channels: butterfly over them, lane 0 / 32 writes the wave's row
+    // lanes with equal (lane & 3) of a half-wave hold the same channels: butterfly over those 8, the first quad of
+    // each half-wave writes the wave's row
     float* __restrict__ prow = p.dpart + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * CP * 2;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a = pa[m][r], bsum = pb[m][r];
+      for (int j = 0; j < 4; ++j) {
+        float a = pa[m][j], bsum = pb[m][j];
 #pragma unroll
-        for (int sft = 1; sft < 32; sft <<= 1) {
+        for (int sft = 4; sft < 32; sft <<= 1) {
           a += __shfl_xor(a, sft);
           bsum += __shfl_xor(bsum, sft);
         }
-        if (col == 0) {
-          const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (col < 4) {
+          const int cl = m * 32 + qi + 8 * j + 4 * kh;
           prow[cl * 2] = a;
           prow[cl * 2 + 1] = bsum;
         }
