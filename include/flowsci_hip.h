@@ -476,8 +476,13 @@ int fs_conv3d_fwd_add(const float* x, const float* w, const float* bias, const f
  * backward of the layer in between folded into the epilogue -- grad_act_y = conv(x) * prelu'(act_y), plus the PReLU
  * weight gradient and the first deconvolution's bias gradient (deterministic: per-wave partials in `part`,
  * fs_conv3d_fwd_dprelu_part_floats floats, summed in a fixed order).  FS_ERR_UNSUPPORTED: no such kernel for this
- * shape / alignment -- use fs_conv3d_fwd followed by fs_prelu_bwd. */
-long long fs_conv3d_fwd_dprelu_part_floats(int B, int Cout, int Do, int Ho, int Wo);
+ * shape / alignment -- use fs_conv3d_fwd followed by fs_prelu_bwd.
+ * kernel 3 (stride 1, pad 1): the same for the INNER PReLU of an IFBlock residual unit (Flow-3D/model/IFNet.py:101-104,
+ * `convblock(x) + x` with convblock = conv, PReLU, conv, PReLU): x = grad w.r.t. the second convolution's output,
+ * w = that convolution's weight as stored (read flipped + transposed, as fs_conv3d_fwd wmode 1), act_y = the first
+ * convolution's output. */
+long long fs_conv3d_fwd_dprelu_part_floats(int B, int Cout, int Do, int Ho, int Wo);    /* kernel 4 */
+long long fs_conv3d_fwd_dprelu_part_floats_k3(int B, int Cout, int Do, int Ho, int Wo); /* kernel 3 */
 int fs_conv3d_fwd_dprelu(const float* x, const float* w, const float* act_y, const float* prelu_weight,
                          int num_prelu_weights, float* grad_act_y, float* grad_prelu_weight, float* grad_bias,
                          float* part, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,

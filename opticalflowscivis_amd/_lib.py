@@ -57,6 +57,7 @@ SIGNATURES = {
     "fs_conv3d_fwd": [_f32p] * 5 + [_int] * 13 + [_stream],
     "fs_upsample3d_scale_add": [_f32p] * 3 + [_int] * 6 + [_float, _stream],
     "fs_conv3d_fwd_dprelu_part_floats": [_int] * 5,
+    "fs_conv3d_fwd_dprelu_part_floats_k3": [_int] * 5,
     "fs_conv3d_fwd_dprelu": [_f32p] * 4 + [_int] + [_f32p] * 5 + [_int] * 12 + [_stream],
     "fs_conv3d_fwd_prelu": [_f32p] * 8 + [_int] * 13 + [_stream],
     "fs_conv3d_fwd_add": [_f32p] * 6 + [_int] * 13 + [_stream],
@@ -98,7 +99,8 @@ SIGNATURES = {
                       _stream],
 }
 _RESTYPES = {"fs_error_string": ctypes.c_char_p, "fs_conv3d_fwd_ws_floats": ctypes.c_longlong,
-             "fs_conv3d_tr_ws_floats": ctypes.c_longlong, "fs_conv3d_fwd_dprelu_part_floats": ctypes.c_longlong}
+             "fs_conv3d_tr_ws_floats": ctypes.c_longlong, "fs_conv3d_fwd_dprelu_part_floats": ctypes.c_longlong,
+             "fs_conv3d_fwd_dprelu_part_floats_k3": ctypes.c_longlong}
 
 
 class FlowsciLibraryError(RuntimeError):

@@ -373,8 +373,16 @@ class _ResUnitFn(torch.autograd.Function):
         gout = gout.contiguous()
         gy2, ga2, gb2 = ops.prelu_backward(y2, gout, a2, want_bias_grad=ctx.has_bias[1])
         gw2 = _conv_grad_weight(z1, w2, gy2, s3, p3, False) if ctx.needs_input_grad[4] else None
-        gz1 = ops.conv3d_fwd(gy2, w2, None, k, 1, p, 1)
-        gy1, ga1, gb1 = ops.prelu_backward(y1, gz1, a1, want_bias_grad=ctx.has_bias[0])
+        # the unit's inner PReLU backward runs in the epilogue of conv2's input-gradient convolution where that kernel
+        # exists (fs_conv3d_fwd_dprelu, kernel 3); else two passes
+        fused = ops.conv3d_k3_grad_input_dprelu(gy2, w2, y1, a1) if k == 3 else None
+        if fused is not None:
+            gy1, ga1, gb1 = fused
+            if not ctx.has_bias[0]:
+                gb1 = None
+        else:
+            gz1 = ops.conv3d_fwd(gy2, w2, None, k, 1, p, 1)
+            gy1, ga1, gb1 = ops.prelu_backward(y1, gz1, a1, want_bias_grad=ctx.has_bias[0])
         gw1 = _conv_grad_weight(x, w1, gy1, s3, p3, False) if ctx.needs_input_grad[1] else None
         gx = ops.conv3d_fwd(gy1, w1, None, k, 1, p, 1, None, gout) if ctx.needs_input_grad[0] else None
         return gx, gw1, gb1, ga1, gw2, gb2, ga2

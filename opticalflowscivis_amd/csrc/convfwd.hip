@@ -651,32 +651,41 @@ int launch(const float* X, const float* Wt, const float* bias, float* Y, FP& p, 
   return FS_OK;
 }
 
-// The per-wave partial rows [rows][32 channels][2: slope-gradient term, bias-gradient term] are summed in two fixed
-// stages, fp64 -- deterministic: kFinishBlocks workgroups reduce contiguous row ranges reading whole 256-byte rows (a
-// block per output walking its column with a 256-byte stride took 47 us per head), then one block per output adds the
-// kFinishBlocks partials in order.  ga[c]: all channels when the slope is shared.
+// The per-wave partial rows [channel group][rows][CP channels][2: slope-gradient term, bias-gradient term] are summed
+// in two fixed stages, fp64 -- deterministic: kFinishBlocks workgroups per channel group reduce contiguous row ranges
+// reading whole rows (a block per output walking its column with a 256-byte stride took 47 us per head), then one
+// block per output adds the kFinishBlocks partials in order.  ga[c]: all channels when the slope is shared.
 constexpr int kFinishBlocks = 128;
-__global__ __launch_bounds__(256) void dprelu_finish1_kernel(const float* __restrict__ part, int rows,
+// part: [channel group][rows][CP channels][2]; blockIdx = (row range, channel group)
+__global__ __launch_bounds__(256) void dprelu_finish1_kernel(const float* __restrict__ part, int rows, int CP,
                                                              double* __restrict__ partial) {
-  const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int CP2 = 2 * CP;  // 64 or 128 columns
+  const int col = threadIdx.x % CP2, sub = threadIdx.x / CP2, nsub = 256 / CP2;
   const int chunk = (rows + kFinishBlocks - 1) / kFinishBlocks;
   const int r0 = blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+  const float* src = part + (size_t)blockIdx.y * rows * CP2;
   double s = 0.0;
-  for (int r = r0 + sub; r < r1; r += 4) s += (double)part[(size_t)r * 64 + col];
+  for (int r = r0 + sub; r < r1; r += nsub) s += (double)src[(size_t)r * CP2 + col];
   __shared__ double red[256];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (sub == 0) partial[(size_t)blockIdx.x * 64 + col] = ((red[col] + red[64 + col]) + red[128 + col]) + red[192 + col];
+  if (sub == 0) {
+    double t = red[col];
+    for (int k = 1; k < nsub; ++k) t += red[k * CP2 + col];
+    partial[((size_t)blockIdx.y * kFinishBlocks + blockIdx.x) * CP2 + col] = t;
+  }
 }
-__global__ __launch_bounds__(64) void dprelu_finish2_kernel(const double* __restrict__ partial, int Cout,
+__global__ __launch_bounds__(64) void dprelu_finish2_kernel(const double* __restrict__ partial, int CP, int Cout,
                                                             float* __restrict__ ga, float* __restrict__ gb, int nslope) {
   const bool bias_blk = (int)blockIdx.x >= nslope;
   const int c = bias_blk ? blockIdx.x - nslope : blockIdx.x;
   const bool all = !bias_blk && nslope == 1 && Cout != 1;
   const int c_lo = all ? 0 : c, c_hi = all ? Cout : c + 1;
-  double s = 0.0;  // thread g < kFinishBlocks / 2 adds partials g and g + 64 of its channels, then a fixed tree
-  for (int cc = c_lo; cc < c_hi; ++cc)
-    for (int g = threadIdx.x; g < kFinishBlocks; g += 64) s += partial[(size_t)g * 64 + cc * 2 + (bias_blk ? 1 : 0)];
+  double s = 0.0;
+  for (int cc = c_lo; cc < c_hi; ++cc) {
+    const double* src = partial + (size_t)(cc / CP) * kFinishBlocks * 2 * CP + (cc % CP) * 2 + (bias_blk ? 1 : 0);
+    for (int g = threadIdx.x; g < kFinishBlocks; g += 64) s += src[(size_t)g * 2 * CP];
+  }
   __shared__ double red[64];
   red[threadIdx.x] = s;
   __syncthreads();
@@ -758,6 +767,17 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   int cinp;
   wt_dims(Cin, Cout, kernel, &cinp, &p.CoutP);
   hipStream_t st = (hipStream_t)stream;
+  // after a loader-wave launch with the fused PReLU-backward epilogue: finish its partial sums (CP = channels per
+  // workgroup; the stage-1 partials live behind the rows in `part`, 8-byte aligned)
+  auto dp_finish = [&](int CP) {
+    const long long rows = p.tiles * 4;
+    const int mg = p.CoutP / CP;
+    double* partial = reinterpret_cast<double*>(dp->part + (rows * mg * CP * 2 + 1) / 2 * 2);
+    hipLaunchKernelGGL(dprelu_finish1_kernel, dim3(kFinishBlocks, mg), dim3(256), 0, st, dp->part, (int)rows, CP, partial);
+    hipLaunchKernelGGL(dprelu_finish2_kernel, dim3(dp->nslope + Cout), dim3(64), 0, st, partial, CP, Cout, dp->ga, dp->gb,
+                       dp->nslope);
+    return hipGetLastError() == hipSuccess ? FS_OK : FS_ERR_LAUNCH;
+  };
   const int K3 = kernel * kernel * kernel;
   const int total = cinp * K3 * p.CoutP;
   hipLaunchKernelGGL(wprep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, ws, Cout, Cin, K3, cinp,
@@ -778,32 +798,38 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     const bool wide = Wo > 16;
     const long long big = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, wide ? 8 : 16) * fs::cdiv(Wo, wide ? 32 : 16) *
                           (p.CoutP / 64);
-    if (big >= 512) {
-      // loader-wave form since its epilogue stores 16 bytes per lane (round 2; before that the two forms tied at
-      // 132 TFLOP/s): 64 -> 64 at 64^3 0.886 -> 0.860 ms = 135 TFLOP/s, -0.9 ms per step (A/B on one box)
-      if (wide && !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && dp == nullptr &&
-          (long long)4 * Di * Hi * Wi * 4 < (1ll << 31))
-        return launch_ws<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
-      if (wide) return launch<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
-      return launch<3, 1, 4, 2, 4, 2, 8, 16>(x, ws, bias, y, p, st);
-    }
-    // fewer than one 64-channel workgroup per CU (block0's 128-channel layers at 16^3: 64 bricks x 2): 32 output
-    // channels per workgroup instead -- twice the workgroups, half the serial MFMA chain of each
-    const long long small = (long long)B * Do * fs::cdiv(Ho, wide ? 4 : 8) * fs::cdiv(Wo, wide ? 32 : 16) * (p.CoutP / 64);
-    // the coarse blocks' trunk layers take the loader-wave form (64 -> 64 at 32^3: 0.145 -> 0.125 ms = 116 TFLOP/s;
-    // 128 -> 128 at 16^3: 0.107 -> 0.068 ms = 106 TFLOP/s): with about one workgroup per CU, eight waves that overlap
-    // staging and MFMAs beat two independent four-wave workgroups
+    // every 32-column layer and the 16-column layers of block0 take the loader-wave form (16-byte pieces: Wi % 4 == 0,
+    // aligned input and workspace, 31-bit byte offsets inside a staged chunk): 64 -> 64 at 64^3 0.886 -> 0.860 ms =
+    // 135 TFLOP/s since its epilogue stores 16 bytes per lane (the two forms tied at 132 before); 64 -> 64 at 32^3
+    // 0.145 -> 0.125 ms; 128 -> 128 at 16^3 0.107 -> 0.068 ms -- with about one workgroup per CU, eight waves that
+    // overlap staging and MFMAs beat two independent four-wave workgroups
     const bool ws3 = !reg_only && Wi % 4 == 0 && (((ms ? (uintptr_t)0 : (uintptr_t)x) | (uintptr_t)ws) & 15) == 0 &&
-                     (long long)4 * Di * Hi * Wi * 4 < (1ll << 31) && dp == nullptr;
-    if (small < 256) {
-      if (ws3 && !wide && Cin % 8 == 0) return launch_ws<3, 1, 8, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
-      if (!wide && Cin % 8 == 0) return launch<3, 1, 8, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);  // 8-channel chunks
-      if (wide) return launch<3, 1, 4, 1, 1, 1, 4, 32>(x, ws, bias, y, p, st);
-      return launch<3, 1, 4, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
+                     (long long)4 * Di * Hi * Wi * 4 < (1ll << 31);
+    // the fused PReLU-backward epilogue (dp) exists in the loader-wave kernels only: the caller falls back otherwise
+    if (dp != nullptr && (bias != nullptr || z != nullptr || addend != nullptr || !ws3)) return FS_ERR_UNSUPPORTED;
+    int rc = FS_ERR_UNSUPPORTED, cp = 0;
+    const long long small = (long long)B * Do * fs::cdiv(Ho, wide ? 4 : 8) * fs::cdiv(Wo, wide ? 32 : 16) * (p.CoutP / 64);
+    if (big >= 512) {
+      if (ws3 && wide) { rc = launch_ws<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st); cp = 64; }
+      else if (dp != nullptr) return FS_ERR_UNSUPPORTED;
+      else if (wide) return launch<3, 1, 4, 2, 4, 2, 8, 32>(x, ws, bias, y, p, st);
+      else return launch<3, 1, 4, 2, 4, 2, 8, 16>(x, ws, bias, y, p, st);
+    } else if (small < 256) {
+      // fewer than one 64-channel workgroup per CU (block0's 128-channel layers at 16^3: 64 bricks x 2): 32 output
+      // channels per workgroup instead -- twice the workgroups, half the serial MFMA chain of each
+      if (ws3 && !wide && Cin % 8 == 0) { rc = launch_ws<3, 1, 8, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st); cp = 32; }
+      else if (dp != nullptr) return FS_ERR_UNSUPPORTED;
+      else if (!wide && Cin % 8 == 0) return launch<3, 1, 8, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);  // 8-channel chunks
+      else if (wide) return launch<3, 1, 4, 1, 1, 1, 4, 32>(x, ws, bias, y, p, st);
+      else return launch<3, 1, 4, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
+    } else {
+      if (ws3 && wide) { rc = launch_ws<3, 1, 4, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st); cp = 64; }
+      else if (dp != nullptr) return FS_ERR_UNSUPPORTED;
+      else if (wide) return launch<3, 1, 4, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
+      else return launch<3, 1, 4, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
     }
-    if (ws3 && wide) return launch_ws<3, 1, 4, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
-    if (wide) return launch<3, 1, 4, 2, 1, 1, 4, 32>(x, ws, bias, y, p, st);
-    return launch<3, 1, 4, 2, 1, 1, 4, 16>(x, ws, bias, y, p, st);
+    if (rc != FS_OK || dp == nullptr) return rc;
+    return dp_finish(cp);
   }
   const long long k4tiles = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, 8) * fs::cdiv(Wo, 32);
   if (dp != nullptr) {
@@ -813,14 +839,7 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
       return FS_ERR_UNSUPPORTED;
     const int rc = launch_ws<4, 2, 2, 1, 4, 2, 8, 32>(x, ws, bias, y, p, st);
     if (rc != FS_OK) return rc;
-    // (the stage-1 partials live behind the rows in `part`: fs_conv3d_fwd_dprelu_part_floats reserves them, 8-byte aligned)
-    const long long rows = k4tiles * 4;
-    double* partial = reinterpret_cast<double*>(dp->part + (rows * 64 + 1) / 2 * 2);
-    hipLaunchKernelGGL(dprelu_finish1_kernel, dim3(kFinishBlocks), dim3(256), 0, st, dp->part, (int)rows, partial);
-    hipLaunchKernelGGL(dprelu_finish2_kernel, dim3(dp->nslope + Cout), dim3(64), 0, st, partial, Cout, dp->ga, dp->gb,
-                       dp->nslope);
-    FS_LAUNCH_CHECK();
-    return FS_OK;
+    return dp_finish(32);
   }
   if (ms != nullptr && !(p.CoutP == 32 && k4tiles >= 512)) return FS_ERR_UNSUPPORTED;
   if (p.CoutP == 32) {
@@ -900,9 +919,22 @@ extern "C" int fs_conv3d_fwd_prelu_ms(const float* const* src, const long long* 
 // convolution of its grad_out, wmode 0): writes grad_act_y = conv(x) * prelu'(act_y) instead of the gradient w.r.t. z,
 // and the PReLU weight gradient / the producing layer's bias gradient (per-wave partials in `part`, finished in a
 // fixed order).  FS_ERR_UNSUPPORTED when the shape / alignment has no such kernel: use fs_conv3d_fwd + fs_prelu_bwd.
+// rows x channels of per-wave partials + the stage-1 partials of the finish, for the brick choice conv3d_fwd_impl makes
+// (kernel 4: the 32-channel loader-wave kernel; kernel 3: its three loader-wave variants)
 extern "C" long long fs_conv3d_fwd_dprelu_part_floats(int B, int Cout, int Do, int Ho, int Wo) {
   if (B < 1 || Cout < 1 || Cout > 32 || Do < 1 || Ho < 1 || Wo < 1) return -1;
   return (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, 8) * fs::cdiv(Wo, 32) * 4 * 32 * 2 + 2 + kFinishBlocks * 64 * 2;
+}
+extern "C" long long fs_conv3d_fwd_dprelu_part_floats_k3(int B, int Cout, int Do, int Ho, int Wo) {
+  if (B < 1 || Cout < 1 || Do < 1 || Ho < 1 || Wo < 1) return -1;
+  const long long coutp = (Cout + 63) / 64 * 64;
+  const bool wide = Wo > 16;
+  const long long mg64 = coutp / 64;
+  const long long big = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, wide ? 8 : 16) * fs::cdiv(Wo, wide ? 32 : 16);
+  const long long small = (long long)B * Do * fs::cdiv(Ho, wide ? 4 : 8) * fs::cdiv(Wo, wide ? 32 : 16);
+  const long long tiles = big * mg64 >= 512 ? big : small;  // bricks per channel group
+  // rows = 4 per brick and channel group; a row holds the group's channels x 2: coutp x 2 floats per brick row in total
+  return tiles * 4 * coutp * 2 + 2 + (long long)kFinishBlocks * coutp * 2 * 2;
 }
 
 extern "C" int fs_conv3d_fwd_dprelu(const float* x, const float* w, const float* act_y, const float* prelu_weight,
@@ -917,6 +949,8 @@ extern "C" int fs_conv3d_fwd_dprelu(const float* x, const float* w, const float*
   DPrelu dp;
   dp.act_y = act_y; dp.slope = prelu_weight; dp.nslope = num_prelu_weights; dp.part = part;
   dp.ga = grad_prelu_weight; dp.gb = grad_bias;
+  // kernel 4: the strided convolution of a ConvTranspose3d's grad_out (wmode 0); kernel 3: the input gradient of a
+  // stride-1 'same' Conv3d, w as stored [Cout_conv][Cin_conv][27] read flipped and transposed (wmode 1)
   return conv3d_fwd_impl(x, w, nullptr, nullptr, 0, nullptr, grad_act_y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
-                         kernel, stride, pad, 0, stream, &dp);
+                         kernel, stride, pad, kernel == 3 ? 1 : 0, stream, &dp);
 }

@@ -1605,6 +1605,40 @@ def conv3d_deconv_grad_input_dprelu(gy, w, act_y, prelu_weight):
     return out, ga, gb
 
 
+def conv3d_k3_grad_input_dprelu(gy, w, act_y, prelu_weight):
+    """Input gradient of a stride-1 'same' Conv3d (weight w [Cout, Cin, 3,3,3]) whose INPUT was z = prelu(act_y) -- the
+    inner PReLU of an IFBlock residual unit: (grad_act_y, grad_prelu_weight, grad_bias of the layer that produced act_y)
+    in one launch (fs_conv3d_fwd_dprelu, kernel 3: the PReLU backward is the convolution's epilogue), or None when the
+    fused kernel does not cover the shape (the caller then runs conv3d_fwd wmode 1 + prelu_backward)."""
+    gy = _need_cuda_f32("grad_output", gy, 5)
+    w = _need_cuda_f32("w", w, 5)
+    act_y = _need_cuda_f32("act_y", act_y, 5)
+    a = _need_cuda_f32("prelu_weight", prelu_weight, 1)
+    B, Cg = gy.shape[:2]
+    Cx = w.shape[1]                           # the gradient's channels = the convolution's input channels
+    if w.shape[0] != Cg or tuple(w.shape[2:]) != (3, 3, 3) or tuple(act_y.shape) != (B, Cx) + tuple(gy.shape[2:]):
+        raise ValueError("shapes do not belong to one convolution: %s %s %s" % (tuple(gy.shape), tuple(w.shape), tuple(act_y.shape)))
+    if a.numel() not in (1, Cx):
+        raise ValueError("prelu_weight must have 1 or %d elements" % Cx)
+    D, H, W = gy.shape[2:]
+    L = _lib.lib()
+    npart = int(L.fs_conv3d_fwd_dprelu_part_floats_k3(B, Cx, D, H, W))
+    if npart < 0:
+        return None
+    out = torch.empty_like(act_y)
+    ga, gb = torch.empty_like(a), act_y.new_empty(Cx)
+    part = act_y.new_empty(npart)
+    ws = act_y.new_empty(int(L.fs_conv3d_fwd_ws_floats(Cg, Cx, 3)))
+    with torch.cuda.device(gy.device):
+        rc = _call_rc("fs_conv3d_fwd_dprelu", gy.data_ptr(), w.data_ptr(), act_y.data_ptr(), a.data_ptr(), a.numel(),
+                      out.data_ptr(), ga.data_ptr(), gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, Cg, Cx, D, H, W,
+                      D, H, W, 3, 1, 1, _stream(gy), algo_bytes=4 * (gy.numel() + 2 * out.numel()),
+                      algo_flops=2 * out.numel() * Cg * 27, record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
+    if rc == FS_ERR_UNSUPPORTED:
+        return None
+    return out, ga, gb
+
+
 def conv3d_fwd_workgroups(B, Cout, out_dhw, k):
     """Workgroups fs_conv3d_fwd launches for this layer (mirrors its brick choice, csrc/convfwd.hip)."""
     Do, Ho, Wo = out_dhw

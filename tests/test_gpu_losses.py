@@ -845,3 +845,23 @@ def test_corr_kernels_on_ragged_shapes(ops):
         where = ((B, C, D, H, W), md)
         assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5, where
         assert float((g1.cpu() - r1).abs().max()) < 1e-4 and float((g2.cpu() - r2).abs().max()) < 1e-4, where
+
+
+@pytest.mark.parametrize("C,size,nslope", [(64, (32, 64, 64), 64), (64, (16, 32, 32), 1), (128, (8, 16, 16), 128)])
+def test_res_unit_inner_prelu_backward_in_the_conv_epilogue(ops, C, size, nslope):
+    """fs_conv3d_fwd_dprelu, kernel 3 (the inner PReLU of a residual unit folded into the epilogue of conv2's input
+    gradient) == fs_conv3d_fwd wmode 1 followed by fs_prelu_bwd: grad_act_y bit for bit (same convolution kernel, same
+    select), slope / bias gradients to summation order; at the three loader-wave brick choices (64^3-like, 32^3-like,
+    block0's 16-column layers).  Then the whole unit through convgrad.res_unit against the unfused composition."""
+    g = torch.Generator().manual_seed(C + size[0])
+    gy = torch.randn((2, C) + size, generator=g).to(DEV)
+    w = (torch.randn(C, C, 3, 3, 3, generator=g) / (C * 27) ** 0.5).to(DEV)
+    y1 = torch.randn((2, C) + size, generator=g).to(DEV)
+    a = (torch.rand(nslope, generator=g) - 0.3).to(DEV)
+    fused = ops.conv3d_k3_grad_input_dprelu(gy, w, y1, a)
+    assert fused is not None
+    gz = ops.conv3d_fwd(gy, w, None, 3, 1, 1, 1)
+    ref = ops.prelu_backward(y1, gz, a, want_bias_grad=True)
+    assert torch.equal(fused[0], ref[0])
+    for got, want in zip(fused[1:], ref[1:]):
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
