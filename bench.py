@@ -7,8 +7,10 @@ forward (3 student blocks + teacher, 4 warp-pair launches) + L1/distillation los
 AdamW.  Warps, loss / merge epilogues, resizes and the 3-D convolutions (implicit GEMM on the fp32 matrix
 cores) are this repo's HIP kernels behind the C-ABI; what is left to ATen is listed in DESIGN.md §5.
 
-The K timed steps run with the per-launch HIP-event records OFF; a short separate pass after the timed
-region (same model, same batch) records every C-ABI launch for the `roofline` / `kernels` entries.  After
+In the K timed steps only the launches of the dominant entry point (found in the warm-up steps: ~90 of ~540
+launches per step) carry HIP events on the launch stream, so `roofline` is measured inside the timed region at no
+visible cost; a short separate pass afterwards (same model, same batch) records every C-ABI launch for the
+`kernels` table.  After
 that, rank 0 of an N = 1 run times the CPU oracle on bounded samples (64^3 and 128^3) and runs the GPU
 model on the same batches from the same seed: `parity_at_cpu_size` is the bench line's own parity witness
 (the run exits non-zero when the losses disagree by more than 5e-4 relative).
