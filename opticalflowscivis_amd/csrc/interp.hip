@@ -21,6 +21,8 @@
 // (Flow-2D/model/IFNet.py:89,92,115-116) all evaluate ATen's area_pixel_compute_source_index /
 // lambda arithmetic in ATen's summation order with FMA contraction off (down-scaling: every lambda is 1/2 and
 // the result is bit-identical to F.interpolate; up-scaling: within an ulp of ATen's builds, which may contract).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -344,6 +346,85 @@ void up_adjoint_separable(const float* gout, float* gin, float* ws, const IP& p,
                      p.Do, p.Di, p.Hi * p.Wi, p.s, p.rs, oscale);
 }
 
+// The same adjoint in ONE pass: a workgroup owns a TZ x TY x 32 tile of the coarse gradient; its fine-gradient region
+// (s (T + 1) per axis) is reduced along x straight from global memory into LDS, then along y and z inside LDS.  The fine
+// gradient is read once (halo re-reads hit L2) and nothing intermediate goes to HBM: the three separable launches moved
+// 805 -> 402 -> 201 -> 100 MB through HBM for a [2,6,256^3] flow gradient (1.4 ms per step for both scales), this
+// one reads 805 MB and writes 100.  Tap weights from the forward's own index arithmetic (axis_w), as before.
+template <int S, int TZ, int TY>
+__global__ __launch_bounds__(256) void up_adjoint_fused_kernel(const float* __restrict__ g, float* __restrict__ out, IP p,
+                                                               float oscale) {
+  constexpr int NC = 2 * S, TX = 32;
+  constexpr int HZ = S * (TZ + 1), HY = S * (TY + 1);
+  __shared__ float w[(TZ + TY + TX) * NC];       // tap weights of the tile's coarse indices, per axis
+  __shared__ float s1[HZ * HY * TX];             // reduced along x
+  __shared__ float s2[HZ * TY * TX];             // ... and y
+  const int t = threadIdx.x;
+  const int ntx = (p.Di > 0) ? (p.Wi + TX - 1) / TX : 1, nty = (p.Hi + TY - 1) / TY, ntz = (p.Di + TZ - 1) / TZ;
+  long long tile = blockIdx.x;
+  const int x0 = (int)(tile % ntx) * TX; tile /= ntx;
+  const int y0 = (int)(tile % nty) * TY; tile /= nty;
+  const int z0 = (int)(tile % ntz) * TZ;
+  const long long bc = tile / ntz;
+  // coarse extent = (Di, Hi, Wi) (this is the gradient w.r.t. the up-sampling's INPUT), fine = (Do, Ho, Wo)
+  for (int i = t; i < (TZ + TY + TX) * NC; i += 256) {
+    const int a = i / NC, k = i - a * NC;
+    float v;
+    if (a < TZ) v = axis_w(S * (z0 + a) - S / 2 + k, z0 + a, p.Di, p.Do, p.rs);
+    else if (a < TZ + TY) v = axis_w(S * (y0 + a - TZ) - S / 2 + k, y0 + a - TZ, p.Hi, p.Ho, p.rs);
+    else v = axis_w(S * (x0 + a - TZ - TY) - S / 2 + k, x0 + a - TZ - TY, p.Wi, p.Wo, p.rs);
+    w[i] = v;
+  }
+  __syncthreads();
+  const float* gb = g + bc * ((long long)p.Do * p.Ho * p.Wo);
+  const int hz0 = S * z0 - S / 2, hy0 = S * y0 - S / 2, hx0 = S * x0 - S / 2;
+  {  // along x: thread = coarse column xl (weights in registers), rows strided over the workgroup
+    const int xl = t & 31;
+    float wx[NC];
+    int ox[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      wx[k] = w[(TZ + TY + xl) * NC + k];
+      ox[k] = min(max(hx0 + S * xl + k, 0), p.Wo - 1);  // (weight 0 where the index was clamped)
+    }
+    for (int r = t >> 5; r < HZ * HY; r += 8) {
+      const int hz = r / HY, hy = r - hz * HY;
+      const int oz = min(max(hz0 + hz, 0), p.Do - 1), oy = min(max(hy0 + hy, 0), p.Ho - 1);
+      const float* row = gb + ((long long)oz * p.Ho + oy) * p.Wo;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) acc = fmaf(wx[k], row[ox[k]], acc);
+      s1[r * TX + xl] = acc;
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < HZ * TY * TX; i += 256) {  // along y
+    const int xl = i & 31, q = i >> 5;
+    const int yl = q % TY, hz = q / TY;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc = fmaf(w[(TZ + yl) * NC + k], s1[(hz * HY + S * yl + k) * TX + xl], acc);
+    s2[i] = acc;
+  }
+  __syncthreads();
+  for (int i = t; i < TZ * TY * TX; i += 256) {  // along z
+    const int xl = i & 31, q = i >> 5;
+    const int yl = q % TY, zl = q / TY;
+    const int z = z0 + zl, y = y0 + yl, x = x0 + xl;
+    if (z >= p.Di || y >= p.Hi || x >= p.Wi) continue;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc = fmaf(w[zl * NC + k], s2[((S * zl + k) * TY + yl) * TX + xl], acc);
+    out[((bc * p.Di + z) * p.Hi + y) * (long long)p.Wi + x] = acc * oscale;
+  }
+}
+
+template <int S, int TZ, int TY>
+void up_adjoint_fused(const float* gout, float* gin, const IP& p, hipStream_t st, float oscale) {
+  const long long tiles = (long long)((p.Wi + 31) / 32) * ((p.Hi + TY - 1) / TY) * ((p.Di + TZ - 1) / TZ) * p.nBC;
+  hipLaunchKernelGGL((up_adjoint_fused_kernel<S, TZ, TY>), dim3((unsigned)tiles), dim3(256), 0, st, gout, gin, p, oscale);
+}
+
 }  // namespace
 
 // grad_in = scale * adjoint(grad_out) for the up-sampling direction with a workspace (the separable form,
@@ -390,7 +471,13 @@ extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, flo
       hipLaunchKernelGGL(interp3d_adjoint_kernel<3>, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
                          grad_in, p);
   } else if (ws != nullptr) {
-    if (factor == 2) up_adjoint_separable<4>(grad_out, grad_in, ws, p, st, scale);
+    // x2: one fused pass; FLOWSCI_INTERP_SEPARABLE=1: the three separable launches it replaced (A/B)
+    static const bool separable = getenv("FLOWSCI_INTERP_SEPARABLE") != nullptr;
+    const long long tiles2 = (long long)((p.Wi + 31) / 32) * ((p.Hi + 7) / 8) * ((p.Di + 3) / 4) * p.nBC;
+    // (x2: 0.83 -> 0.38 ms for a [2,6,256^3] gradient; x4: the fused form's stride-4 row gathers make it slower than
+    // the separable passes, 0.64 vs 0.45 ms, so that scale keeps them)
+    if (!separable && factor == 2 && tiles2 < (1ll << 31)) up_adjoint_fused<2, 4, 8>(grad_out, grad_in, p, st, scale);
+    else if (factor == 2) up_adjoint_separable<4>(grad_out, grad_in, ws, p, st, scale);
     else up_adjoint_separable<8>(grad_out, grad_in, ws, p, st, scale);
   } else if (factor == 2) {
     hipLaunchKernelGGL(interp3d_adjoint_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
