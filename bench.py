@@ -16,11 +16,16 @@ model on the same batches from the same seed: `parity_at_cpu_size` is the bench 
 (the run exits non-zero when the losses disagree by more than 5e-4 relative).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 5 --warmup 2          # starts its own 8 rank processes (see launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU, DDP over RCCL; each rank draws its own volume pairs (seed 1234+rank):
-weak scaling, the only collective is DDP's gradient all-reduce.  Rank 0 prints ONE JSON line.
+weak scaling, the only collective is DDP's gradient all-reduce.  Rank 0 prints ONE JSON line; its `ranks`
+record is the witness that the process group really had N members (an all-reduce of rank+1, every rank's device
+and its own step time).  Either launch form works: under torch.distributed.run the rank variables are already in
+the environment; called bare with --gpus N > 1 the process starts N fresh children of itself BEFORE anything
+touches the GPU (the reference does the same through torch.distributed.launch, Flow-3D/train.py:2,490).
 """
 import argparse
 import json
@@ -141,8 +146,11 @@ def cpu_baseline(sizes, dataset, dev, steps=2):
         # first step: also the warm-up (allocator, thread pool) and the parity reference
         po, oi = m.update(imgs, gt, learning_rate=1e-4, training=True)
         t0 = time.perf_counter()
+        o2 = None
         for _ in range(steps):
-            m.update(imgs, gt, learning_rate=1e-4, training=True)
+            _, oi_n = m.update(imgs, gt, learning_rate=1e-4, training=True)
+            o2 = float(oi_n["loss_G"].detach()) if o2 is None else o2  # step 2: sees step 1's backward + AdamW
+            del oi_n
         dt = (time.perf_counter() - t0) / steps
         vox_ratio = (size / 256.0) ** 3
         samples.append({"size": size, "batch": B, "s_per_step": round(dt, 4), "timed_steps": steps,
@@ -151,8 +159,10 @@ def cpu_baseline(sizes, dataset, dev, steps=2):
         torch.manual_seed(1234)
         g = Model(local_rank=-1, device=dev)
         pg, gi = g.update(imgs.to(dev), gt.to(dev), learning_rate=1e-4, training=True)
+        g2 = float(g.update(imgs.to(dev), gt.to(dev), learning_rate=1e-4, training=True)[1]["loss_G"].detach())
         torch.cuda.synchronize()
-        rec = {"size": size, "batch": B}
+        rec = {"size": size, "batch": B,
+               "loss_G_step2": {"gpu": g2, "oracle": o2, "rel": abs(g2 - o2) / max(abs(o2), 1e-12)}}
         for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G"):
             a, b = float(gi[k].detach()), float(oi[k].detach())
             rec[k] = {"gpu": a, "oracle": b, "rel": abs(a - b) / max(abs(b), 1e-12)}
@@ -174,25 +184,75 @@ def cpu_baseline(sizes, dataset, dev, steps=2):
             "samples": samples}
     top = parity[-1]
     witness = {"loss_gpu": top["loss_G"]["gpu"], "loss_oracle": top["loss_G"]["oracle"],
-               "rel": max(p[k]["rel"] for p in parity for k in ("loss_l1", "loss_tea", "loss_G")),
-               "tolerance_rel": 5e-4, "sizes": parity}
+               "rel": max(p[k]["rel"] for p in parity for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G")),
+               "tolerance_rel": 5e-4,
+               # the flow AFTER the step's forward is the backward fusions' witness only at step 2; the first
+               # step's flow pins the fused forward (distillation aliases, up-sample + warp launches)
+               "flow_max_abs_diff_px": max(p["flow_max_abs_diff_px"] for p in parity), "tolerance_flow_px": 1e-4,
+               "loss_G_step2_rel": max(p["loss_G_step2"]["rel"] for p in parity),
+               "sizes": parity}
     return base, witness
 
 
+def launch(args):
+    """`python bench.py --gpus N` without rank variables in the environment: start N fresh rank processes of
+    this same script (one per GPU, env:// rendezvous on 127.0.0.1), pass rank 0's stdout (the ONE JSON line)
+    through, send the other ranks' stdout to stderr, and return the worst exit status.  Nothing here may
+    initialise the GPU: the children are started from a process that has made no HIP call
+    (`torch.cuda.device_count()` does not initialise the runtime on this image), and no process is ever
+    replaced by exec.  When one rank dies the others are ended by their exact PIDs, so that a failure is an
+    exit code and not a hung rendezvous.
+    FLOWSCI_BENCH_SHARE_GPU=1 (tests on a one-GPU box only, never the driver): ranks are dealt round-robin
+    over the visible devices and the process group runs on gloo, because RCCL refuses two ranks on one device."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("FLOWSCI_BENCH_SHARE_GPU") == "1"
+    if ndev < 1:
+        sys.exit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
+    if args.gpus > ndev and not share:
+        sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, ndev))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FLOWSCI_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst, alive = 0, set(range(args.gpus))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                print("[bench launcher] rank %d exited with status %d" % (r, rc), file=sys.stderr, flush=True)
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                for o in sorted(alive):  # the exact children started above, nothing by pattern
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return worst
+
+
 def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args))
     # stdout must carry exactly ONE JSON line, but RCCL prints a version banner to fd 1 when its
     # communicator comes up.  Park the real stdout, send fd 1 to stderr for the run, and write the
     # result to the parked descriptor at the end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d (see docstring)" % args.gpus)
+        log("WORLD_SIZE=%d overrides --gpus %d" % (world, args.gpus))
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
@@ -204,7 +264,11 @@ def main():
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)  # RCCL on ROCm
+        if os.environ.get("FLOWSCI_BENCH_SHARE_GPU") == "1":  # tests: several ranks on one device (launch())
+            dist.init_process_group(backend="gloo", world_size=world, rank=rank)
+        else:
+            dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)  # RCCL on ROCm
+        world = dist.get_world_size()  # from here on N is what the process group says, not what the env said
 
     from opticalflowscivis_amd import ops
     from opticalflowscivis_amd.data import synthetic
@@ -268,8 +332,30 @@ def main():
                                      for i in range(args.steps)),
             torch.cuda.max_memory_allocated() / 2 ** 30))
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    ranks = None
     if ddp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # witness that the collective really spanned N processes: sum over ranks of (rank + 1) == N (N + 1) / 2,
+        # plus what every rank says about itself (device, its own mean step time, its loss)
+        wsum = torch.tensor([rank + 1.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(wsum, op=dist.ReduceOp.SUM)
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "device": dev.index,
+                "device_name": prop.name, "device_uuid": str(getattr(prop, "uuid", "")),
+                "pci_bus_id": getattr(prop, "pci_bus_id", None),
+                "ms_per_step": step_marks[0].elapsed_time(step_marks[-1]) / args.steps,
+                "loss_G": float(info["loss_G"].detach())}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ms = [g["ms_per_step"] for g in gathered]
+        ranks = {"world_size": world, "backend": dist.get_backend(),
+                 "launcher": os.environ.get("FLOWSCI_BENCH_LAUNCHER", "torch.distributed.run"
+                                            if "TORCHELASTIC_RUN_ID" in os.environ else "env"),
+                 "allreduce_sum_of_rank_plus_1": float(wsum.item()), "expected": world * (world + 1) / 2,
+                 "devices": len({(g["device"], g["device_uuid"]) for g in gathered}),
+                 "ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "per_rank": gathered}
+        if ranks["allreduce_sum_of_rank_plus_1"] != ranks["expected"]:
+            sys.exit("process group witness failed: %r" % ranks)
     dt = float(t.item())
 
     if rank == 0:
@@ -318,13 +404,17 @@ def main():
             "kernels": kern,
             "loss_G": loss,
         }
+        if ranks is not None:
+            out["ranks"] = ranks
         rc = 0
         if world == 1 and not args.no_cpu_baseline:
             del pred, info
             out["cpu_baseline"], out["parity_at_cpu_size"] = cpu_baseline(args.cpu_size, args.dataset, dev)
             w = out["parity_at_cpu_size"]
-            if not (w["rel"] <= w["tolerance_rel"]):
-                log("PARITY FAILURE: GPU and oracle losses differ by %.3e relative" % w["rel"])
+            if not (w["rel"] <= w["tolerance_rel"] and w["loss_G_step2_rel"] <= w["tolerance_rel"]
+                    and w["flow_max_abs_diff_px"] <= w["tolerance_flow_px"]):
+                log("PARITY FAILURE: GPU vs oracle: losses %.3e / step-2 loss %.3e relative, flow %.3e px" % (
+                    w["rel"], w["loss_G_step2_rel"], w["flow_max_abs_diff_px"]))
                 rc = 3
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

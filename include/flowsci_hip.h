@@ -32,7 +32,13 @@ enum {
   FS_ERR_UNSUPPORTED = 5 /* a fused entry point has no kernel for this shape / alignment: use the unfused ones */
 };
 
-/* Library version (major*10000 + minor*100 + patch). */
+/* ABI version of this header (major*10000 + minor*100 + patch).  ANY change to the argument list of an existing
+ * entry point bumps it, and a binding must refuse a library whose fs_version() differs from the header it was
+ * written against -- a stale .so would otherwise run with shifted arguments instead of failing.
+ *   100  round 1.
+ *   300  round 2 inserted `const int* in_hw` into fs_warp2d_{fwd,bwd} and fs_warp2d_pair_{fwd,bwd} (without bumping
+ *        the number: fixed in round 3) and added the f1-f4 / conv3d entry points. */
+#define FS_ABI_VERSION 300
 int fs_version(void);
 /* Static string for an FS_* code. */
 const char* fs_error_string(int code);

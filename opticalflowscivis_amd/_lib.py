@@ -14,6 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libflowsci_hip.so")
+ABI_VERSION = 300  # FS_ABI_VERSION of the include/flowsci_hip.h the SIGNATURES below were written against
 
 _f32p = ctypes.c_void_p  # device pointers travel as integers
 _int = ctypes.c_int
@@ -132,6 +133,12 @@ def lib():
             raise FlowsciLibraryError("libflowsci_hip.so does not export %s" % name) from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, _int)
+    got = handle.fs_version()
+    if got != ABI_VERSION:
+        raise FlowsciLibraryError(
+            "libflowsci_hip.so at %s reports ABI version %d, this binding was written for %d: argument lists "
+            "differ between them (include/flowsci_hip.h, FS_ABI_VERSION) -- rebuild with "
+            "`make -C opticalflowscivis_amd/csrc`" % (LIB_PATH, got, ABI_VERSION))
     _lib = handle
     return _lib
 

@@ -2,7 +2,7 @@
 #include "common.hpp"
 
 extern "C" int fs_version(void) {
-  FS_ENTER(); return 100; /* 0.1.0 */ }
+  FS_ENTER(); return FS_ABI_VERSION; }
 
 extern "C" const char* fs_error_string(int code) {
   switch (code) {

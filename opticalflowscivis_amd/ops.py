@@ -507,7 +507,8 @@ class _UpsampleWarpPair(torch.autograd.Function):
         img0, img1, flow = ctx.saved_tensors
         dshape, factor, scale, has_prev = ctx.cfg
         need_delta, need_prev = ctx.needs_input_grad[2], has_prev and ctx.needs_input_grad[3]
-        if not (need_delta or need_prev):
+        need_img = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if not (need_delta or need_prev or need_img):
             return (None,) * 6
         B, C = img0.shape[:2]
         Ds, Hs, Ws = dshape[2:]
@@ -516,6 +517,16 @@ class _UpsampleWarpPair(torch.autograd.Function):
         if g0 is None and g1 is None and not adds:
             return (None,) * 6
         oshape = (B, C, D, H, W)
+        gi0 = gi1 = None
+        if need_img and not (g0 is None and g1 is None):
+            # the frames carry no gradient in IFNet, so the fused launch below has no image-gradient output; a caller
+            # whose frames do require grad gets them from the plain pair backward (scatter with float atomics)
+            gi0, gi1, _ = _pair_backward(img0, img1, flow, flow.new_zeros(oshape) if g0 is None else g0,
+                                         flow.new_zeros(oshape) if g1 is None else g1, True, False)
+            gi0 = gi0 if ctx.needs_input_grad[0] else None
+            gi1 = gi1 if ctx.needs_input_grad[1] else None
+        if not (need_delta or need_prev):
+            return gi0, gi1, None, None, None, None
         g0, s0 = (flow.new_zeros(oshape), 0) if g0 is None else _gout_strided(g0, flow)
         g1, s1 = (flow.new_zeros(oshape), 0) if g1 is None else _gout_strided(g1, flow)
         aargs, keep, abytes = _flow_addends(adds, flow)
@@ -528,7 +539,7 @@ class _UpsampleWarpPair(torch.autograd.Function):
                   _in_dhw(img0, flow), Ds, Hs, Ws, factor, scale, _stream(flow),
                   algo_bytes=8 * flow.numel() + 8 * g0.numel() * 2 + abytes + 4 * (flow.numel() + gdelta.numel()))
         del keep
-        return None, None, (gdelta if need_delta else None), (gtot if need_prev else None), None, None
+        return gi0, gi1, (gdelta if need_delta else None), (gtot if need_prev else None), None, None
 
 
 def upsample_warp_pair(img0, img1, delta, prev, factor, scale=None):

@@ -8,6 +8,7 @@ Usage (each group imports a different reference package layout, so one process p
     python tests/golden/make_golden.py upflow_ops   # Corr_pyTorch, warps, census, photo losses
     python tests/golden/make_golden.py flow3d_e2e   # Flow-3D Model.update / inference
     python tests/golden/make_golden.py flow2d_e2e   # Flow-2D Model.update / inference
+    python tests/golden/make_golden.py flow3d_256   # Flow-3D Model.update at the BASELINE size (B=1, 256^3; ~35 GB, minutes)
     python tests/golden/make_golden.py upflow_e2e   # UPFlow_net forward losses / flows / grads
     python tests/golden/make_golden.py upflow_levels  # per pyramid level: decode_level_res inputs / outputs / grads
     python tests/golden/make_golden.py rife_next    # Flow-2D LapLoss
@@ -249,6 +250,56 @@ def flow3d_e2e():
     store["param_sums_after"] = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
     np.savez_compressed(os.path.join(OUT, "flow3d_e2e.npz"), **store)
     print("wrote flow3d_e2e.npz; losses", losses, "nparam", nparam)
+
+def flow3d_256():
+    """The reference's Flow-3D `Model.update` (Flow-3D/model/RIFE.py:81) at the size BASELINE's metric is quoted
+    on: one 256^3 droplet triplet (B = 1: the host cannot hold B = 2), seed 1234, two AdamW steps at lr 1e-4.
+    The input is NOT stored (201 MB): it is `synthetic.droplet3d_batch(1, 256, seed=1234)` of this repo, a
+    deterministic function of (seed, shape) whose per-frame sums are stored as a check.  Stored: the four losses
+    of both steps, every parameter's sum before / after, the interpolation PSNR, and every 8th voxel per axis of
+    the first step's final flow / merged frame / teacher frame / mask (plus whole-tensor moments)."""
+    _install_stubs()
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path[:0] = [REF + "/Flow-3D", REF]
+    import model.RIFE as R
+    import model.warplayer as WL
+    R.device = torch.device("cpu")
+    WL.device = torch.device("cpu")
+    spec = importlib.util.spec_from_file_location(
+        "flowsci_synthetic", os.path.join(repo, "opticalflowscivis_amd", "data", "synthetic.py"))
+    syn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(syn)
+    S = int(os.environ.get("FLOW3D_256_SIZE", "256"))
+    torch.manual_seed(1234)
+    m = _quiet(R.Model, local_rank=-1)
+    data = syn.droplet3d_batch(1, S, seed=1234)
+    imgs, gt = data[:, :2], data[:, 2:3]
+    store = dict(size=np.int64(S), data_sums=np.array([float(data[0, c].double().sum()) for c in range(3)]))
+    store["param_sums"] = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
+    losses = []
+    import time
+    for step in range(2):
+        t0 = time.time()
+        pred, info = _quiet(m.update, imgs, gt, learning_rate=1e-4, training=True)
+        losses.append([float(info[k].detach()) for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G")])
+        print("step", step, "%.1f s" % (time.time() - t0), losses[-1], flush=True)
+        if step == 0:
+            sl = (slice(None), slice(None), slice(0, None, 8), slice(0, None, 8), slice(0, None, 8))
+            for name, t in (("flow", info["flow"]), ("merged", pred), ("merged_tea", info["merged_tea"]),
+                            ("flow_tea", info["flow_tea"])):
+                t = t.detach()
+                store[name + "_s8"] = _np(t[sl].contiguous())
+                store[name + "_moments"] = np.array([float(t.double().mean()), float(t.double().abs().mean()),
+                                                     float(t.double().pow(2).mean()), float(t.abs().max())])
+            store["psnr"] = np.array(syn.psnr(pred.detach(), gt))
+            store["psnr_tea"] = np.array(syn.psnr(info["merged_tea"].detach(), gt))
+            store["param_sums_after1"] = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
+        del pred, info
+    store["update_losses"] = np.array(losses)
+    store["param_sums_after2"] = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
+    name = "flow3d_256.npz" if S == 256 else "flow3d_%d_probe.npz" % S
+    np.savez_compressed(os.path.join(OUT, name), **store)
+    print("wrote", name, "; losses", losses, os.path.getsize(os.path.join(OUT, name)) // 1024, "KB")
 
 
 def flow2d_e2e():
@@ -525,7 +576,7 @@ def ckpt():
           "loads its own unprefixed file:", int(store["ref_loads_plain"]))
 
 
-GROUPS = dict(ckpt=ckpt, rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
+GROUPS = dict(flow3d_256=flow3d_256, ckpt=ckpt, rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
               upflow_e2e=upflow_e2e, upflow_levels=upflow_levels)
 
 if __name__ == "__main__":
@@ -533,6 +584,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if which == "all":
         for g in GROUPS:
+            if g == "flow3d_256" and os.environ.get("GOLDEN_WITH_256") != "1":
+                continue  # ~35 GB of host memory and minutes: opt in
             if g == "ckpt":
                 for nd in ("3", "2"):
                     subprocess.check_call([sys.executable, os.path.abspath(__file__), g],

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, n), "libflowsci_hip.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names, "Python binding and header disagree"
     lib = _lib.lib()
-    assert lib.fs_version() >= 100
+    hdr = open(os.path.join(ROOT, "include", "flowsci_hip.h")).read()
+    abi = int(re.search(r"#define\s+FS_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.fs_version() == abi == _lib.ABI_VERSION  # header == library == binding, exactly
     assert lib.fs_error_string(0) == b"ok" and lib.fs_error_string(2) != b"ok"
 
 
@@ -59,6 +61,15 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libflowsci_hip.so")
     with pytest.raises(_lib.FlowsciLibraryError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """A library whose ABI version differs from the binding's must not be used (shifted arguments)."""
+    from opticalflowscivis_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 100)
+    with pytest.raises(_lib.FlowsciLibraryError, match="ABI version"):
         _lib.lib()
 
 

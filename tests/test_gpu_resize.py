@@ -161,6 +161,37 @@ def test_upsample_warp_pair_vs_composition_and_oracle(ops, small, factor, with_p
         assert float((x - y).abs().max()) < 2e-5 * max(1.0, float(y.abs().max()))
 
 
+@pytest.mark.parametrize("only_images", [False, True])
+def test_upsample_warp_pair_image_gradients(ops, only_images):
+    """frames that require grad get their gradient from the fused node too (IFNet never asks, a caller of
+    the public op may): == warp_pair(upsample3d_scale_add(...))'s, also when ONLY the frames require grad."""
+    B, small, factor = 2, (5, 6, 8), 2
+    full = tuple(factor * n for n in small)
+    delta, prev = _rnd((B, 6) + small, 51, 0.8), _rnd((B, 6) + full, 52, 1.5)
+    img0 = torch.rand((B, 2) + full, generator=torch.Generator().manual_seed(53))
+    img1 = torch.rand((B, 2) + full, generator=torch.Generator().manual_seed(54))
+    leaves = []
+    for _ in range(2):
+        leaves.append([img0.to(DEV).requires_grad_(), img1.to(DEV).requires_grad_(),
+                       delta.to(DEV).requires_grad_(not only_images), prev.to(DEV).requires_grad_(not only_images)])
+    (fa, fb, fc), a0, a1 = ops.upsample_warp_pair(leaves[0][0], leaves[0][1], leaves[0][2], leaves[0][3], factor)
+    f_c, c0, c1 = _composed(ops, leaves[1][0], leaves[1][1], leaves[1][2], leaves[1][3], factor)
+    G0, G1 = _rnd(a0.shape, 55).to(DEV), _rnd(a1.shape, 56).to(DEV)
+    Gf = _rnd(fa.shape, 57, 0.3).to(DEV)
+    l1 = (a0 * G0).sum() + (a1 * G1).sum() + ((fb * Gf).sum() if not only_images else 0)
+    l2 = (c0 * G0).sum() + (c1 * G1).sum() + ((f_c * Gf).sum() if not only_images else 0)
+    n = 2 if only_images else 4
+    g1 = torch.autograd.grad(l1, leaves[0][:n])
+    g2 = torch.autograd.grad(l2, leaves[1][:n])
+    for x, y in zip(g1, g2):
+        assert float(y.abs().max()) > 0
+        assert float((x - y).abs().max()) < 2e-5 * max(1.0, float(y.abs().max()))
+    # one frame only
+    (fa, fb, fc), a0, a1 = ops.upsample_warp_pair(leaves[0][0], img1.to(DEV), delta.to(DEV), prev.to(DEV), factor)
+    (g,) = torch.autograd.grad((a0 * G0).sum() + (a1 * G1).sum(), [leaves[0][0]])
+    assert float((g - g2[0]).abs().max()) < 2e-5 * max(1.0, float(g2[0].abs().max()))
+
+
 def test_warp_pair_acc_folds_in_the_other_consumers_gradient(ops):
     g = torch.Generator().manual_seed(41)
     B, D, H, W = 2, 8, 70, 37

@@ -65,6 +65,53 @@ def test_flow3d_step_vs_oracle_128():
     _check_step(m, o, synthetic.droplet3d_batch(1, 128, seed=1234), 3)
 
 
+def test_flow3d_step_at_256_vs_reference_golden(golden):
+    """the train step at the size BASELINE's metric is quoted on, against values the REFERENCE
+    itself produced (tests/golden/flow3d_256.npz, written by `make_golden.py flow3d_256` running
+    Flow-3D/model/RIFE.py:81 `update` on the CPU: B = 1 at 256^3 -- the build host cannot hold B = 2 -- droplet
+    triplet seed 1234, two AdamW steps at lr 1e-4).  Step 1 pins the forward (losses 5e-4 relative, final flow
+    1e-4 px on every 8th voxel per axis plus whole-tensor moments, interpolation PSNR 0.01 dB); the weights after
+    step 1 and the losses of step 2 pin the backward and the optimiser at this size."""
+    from opticalflowscivis_amd.data import synthetic
+    from opticalflowscivis_amd.flow3d.model.RIFE import Model
+    g = golden("flow3d_256")
+    S = int(g["size"])
+    assert S == 256
+    data = synthetic.droplet3d_batch(1, S, seed=1234)
+    np.testing.assert_array_equal(np.array([float(data[0, c].double().sum()) for c in range(3)]), g["data_sums"])
+    torch.manual_seed(1234)
+    m = Model(local_rank=-1, device=DEV)
+    ps0 = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
+    np.testing.assert_allclose(ps0, g["param_sums"], rtol=0, atol=1e-9)  # same seed => the reference's weights
+    imgs, gt = data[:, :2].to(DEV), data[:, 2:3].to(DEV)
+    sl = (slice(None), slice(None), slice(0, None, 8), slice(0, None, 8), slice(0, None, 8))
+    for step in range(2):
+        pred, info = m.update(imgs, gt, learning_rate=1e-4, training=True)
+        torch.cuda.synchronize()
+        got = [float(info[k].detach()) for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G")]
+        for k, a, b in zip(("loss_l1", "loss_tea", "loss_distill", "loss_G"), got, g["update_losses"][step]):
+            assert abs(a - b) <= 5e-4 * abs(b), (step, k, a, b)
+        if step == 0:
+            for name, t, tol in (("flow", info["flow"], 1e-4), ("flow_tea", info["flow_tea"], 1e-4),
+                                 ("merged", pred, 2e-5), ("merged_tea", info["merged_tea"], 2e-5)):
+                t = t.detach()
+                d = float((t[sl].cpu() - torch.from_numpy(g[name + "_s8"])).abs().max())
+                assert d < tol, (name, d)
+                mom = np.array([float(t.double().mean()), float(t.double().abs().mean()),
+                                float(t.double().pow(2).mean()), float(t.abs().max())])
+                np.testing.assert_allclose(mom, g[name + "_moments"], rtol=2e-5, atol=1e-7, err_msg=name)
+            assert abs(synthetic.psnr(pred.detach(), gt) - float(g["psnr"])) < 0.01
+            assert abs(synthetic.psnr(info["merged_tea"].detach(), gt) - float(g["psnr_tea"])) < 0.01
+            ps1 = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
+            # AdamW's first update is lr * sign(g) per weight (1e-4 each): an entry whose gradient is within rounding
+            # noise of 0 may go the other way and shifts its tensor's sum by 2e-4 -- the band allows 25 of them per
+            # tensor (of up to 442 368 entries), the same band as the 128^3 oracle comparison above
+            np.testing.assert_allclose(ps1, g["param_sums_after1"], rtol=1e-4, atol=5e-3)
+        del pred, info
+    ps2 = np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
+    np.testing.assert_allclose(ps2, g["param_sums_after2"], rtol=1e-4, atol=1e-2)
+
+
 def test_flow3d_step_vs_oracle_jets_c5():
     """BASELINE config C5's workload (5Jets-like smooth density field), per-GPU batch 2 at 64^3."""
     from opticalflowscivis_amd.data import synthetic
