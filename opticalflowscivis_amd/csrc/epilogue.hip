@@ -118,10 +118,12 @@ __global__ __launch_bounds__(256) void distill_bwd_kernel(const float* __restric
     const float root = sqrtf(q / (float)p.F);
     // d/df sqrt(mean_c d_c^2) = -d_c / (F * root); the reference's pow(0.5) backward is inf at
     // root == 0 (0 * inf = NaN when the mask is 0): emit 0 there instead.
+    // k == 0: the caller has discarded this loss term (Flow-2D's NaN / > 10 guard, RIFE.py:295-296, evaluated on
+    // the device): the gradient is exactly 0 then, also where the flows themselves are not finite (0 * NaN).
     const float sc = (root > 0.f) ? (k * lm / ((float)p.F * root)) : 0.f;
     for (int c = 0; c < p.F; ++c) {
       const long long e = (b * p.F + c) * (long long)p.S + r;
-      gfi[e] = -(ft[e] - fi[e]) * sc;
+      gfi[e] = (k == 0.f) ? 0.f : -(ft[e] - fi[e]) * sc;
     }
   }
 }
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void distill3_bwd_kernel(D3 a, const float* __
       const long long e = (b * p.F + c) * (long long)p.S + r;
       const float f = ft[e];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) a.gfi[k][e] = -(f - a.fi[k][e]) * sc[k];
+      for (int k = 0; k < 3; ++k) a.gfi[k][e] = (kk == 0.f) ? 0.f : -(f - a.fi[k][e]) * sc[k];  // see distill_bwd_kernel
     }
   }
 }

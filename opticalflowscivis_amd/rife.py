@@ -97,8 +97,8 @@ class ModelBase:
         synchronises or copies from the host, so the whole step is capturable; what the graph saves is
         the ~660 launches' CPU cost and the gaps between short kernels.  Single-process models only
         (capturing through DDP's reducer needs its own warm-up protocol and is not attempted).
-        Model2D keeps the reference's per-step host check of the distillation loss (RIFE.py:295) and is
-        therefore not capturable.
+        Model2D: pass `dataset=...` through `update_kwargs`; its NaN / > 10 guard on the distillation loss
+        (RIFE.py:295) runs on the device, so the 2-D step captures as well.
 
         Side effects on the optimiser, which outlive the returned `step` (graph capture needs device-resident
         optimiser scalars): every param group becomes `capturable=True`, its `'lr'` a 0-dim device tensor and
@@ -280,9 +280,15 @@ class Model2D(ModelBase):
         loss_photo = ops.rife2d_photometric(flow[2], merged[2], img0, img1)  # RIFE.py:274-279
         lambda_l1, lambda_tea, lambda_distill = 1, 1, 0.01  # RIFE.py:283-289
         lambda_reg, lambda_photo, lambda_flow = 1e-6, 1e-5, 0
-        ld = float(loss_distill.detach()) if torch.is_tensor(loss_distill) else float(loss_distill)
-        if math.isnan(ld) or ld > 10.:  # RIFE.py:295-296 (one host sync per step, as in the reference)
-            loss_distill = torch.tensor(0.)
+        # RIFE.py:295-296 `if math.isnan(loss_distill) or loss_distill > 10: loss_distill = 0`, evaluated on the
+        # device: same value, and a gradient of exactly 0 into the distillation term (torch.where selects, the
+        # distillation backward kernels emit 0 for a zero cotangent even over non-finite flows) -- no host
+        # synchronisation per step, so the whole step can be captured into a HIP graph (graphed_update)
+        if torch.is_tensor(loss_distill):
+            discard = torch.isnan(loss_distill) | (loss_distill > 10.)
+            loss_distill = torch.where(discard, torch.zeros_like(loss_distill), loss_distill)
+        elif math.isnan(loss_distill) or loss_distill > 10.:
+            loss_distill = 0.
         if dataset in ("droplet2d", "vimeo2d"):
             loss_flow = torch.tensor(0.)
         loss_G = loss_l1 * lambda_l1 + loss_tea * lambda_tea + loss_distill * lambda_distill + \

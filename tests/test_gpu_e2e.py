@@ -322,6 +322,59 @@ def test_flow3d_train_step_is_hip_graph_capturable():
     assert float((wg - w0).abs().max()) <= tot * 1.001 + 1e-7
 
 
+def test_flow2d_train_step_is_hip_graph_capturable():
+    """Flow-2D's NaN / > 10 guard on the distillation loss (Flow-2D/model/RIFE.py:295-296) runs
+    on the device, so the launch-bound C2 step (~600 launches) captures into one HIP graph; replays reproduce the
+    eager losses step by step."""
+    import copy
+    from opticalflowscivis_amd.flow2d.model.RIFE import Model
+    from opticalflowscivis_amd.data import synthetic
+    torch.manual_seed(7)
+    m = Model(local_rank=-1, device=DEV)
+    d1 = synthetic.droplet2d_batch(4, 64, 96, seed=3, radius=(8, 16)).to(DEV)
+    d2 = synthetic.droplet2d_batch(4, 64, 96, seed=4, radius=(8, 16)).to(DEV)
+    batches = [(d[:, :2].contiguous(), d[:, 2:3].contiguous()) for d in (d1, d2, d1)]
+    lrs = (1e-4, 3e-4, 1e-4)
+    state0 = copy.deepcopy(m.flownet.state_dict())
+    keys = ("loss_l1", "loss_tea", "loss_distill", "loss_photo", "loss_G")
+    eager = [[float(v[k].detach()) for k in keys]
+             for v in (m.update(bi, bg, "droplet2d", learning_rate=lr, training=True)[1]
+                       for (bi, bg), lr in zip(batches, lrs))]
+    m2 = Model(local_rank=-1, device=DEV)
+    m2.flownet.load_state_dict(state0)
+    step = m2.graphed_update(batches[0][0], batches[0][1], dataset="droplet2d")
+    for a, b in zip(m2.flownet.state_dict().values(), state0.values()):
+        assert torch.equal(a, b)
+    for i, ((bi, bg), lr) in enumerate(zip(batches, lrs)):
+        _, info = step(bi, bg, lr)
+        got = [float(info[k].detach()) for k in keys]
+        for k, a, b in zip(keys, got, eager[i]):
+            assert abs(a - b) < 5e-4 * max(abs(b), 1e-6) + 1e-7, (i, k, got, eager[i])
+
+
+def test_flow2d_distill_guard_on_device():
+    """RIFE.py:295-296 on the device: a distillation loss that is NaN or > 10 leaves loss_G and yields a gradient
+    of exactly 0 into the flows, also through non-finite operands; a regular one passes through untouched."""
+    from opticalflowscivis_amd import ops
+    g = torch.Generator().manual_seed(2)
+    shape, fshape = (2, 1, 24, 40), (2, 4, 24, 40)
+    gt = torch.rand(shape, generator=g).to(DEV)
+    mt = (gt + 0.01 * torch.randn(shape, generator=g).to(DEV))
+    ms = [(gt + 0.3 * torch.randn(shape, generator=g).to(DEV)) for _ in range(3)]
+    ft = torch.randn(fshape, generator=g).to(DEV)
+    for scale, bad in ((1.0, False), (1e3, True), (float("nan"), True)):
+        fl = [(scale * torch.randn(fshape, generator=g).to(DEV)).requires_grad_() for _ in range(3)]
+        ld = ops.distill_terms3(ms, mt, gt, fl, ft)
+        discard = torch.isnan(ld) | (ld > 10.)
+        assert bool(discard) == bad
+        kept = torch.where(discard, torch.zeros_like(ld), ld)
+        grads = torch.autograd.grad(kept * 0.01, fl)
+        if bad:
+            assert float(kept) == 0.0 and all(bool((x == 0).all()) for x in grads)
+        else:
+            assert float(kept) == float(ld) and any(float(x.abs().max()) > 0 for x in grads)
+
+
 def test_flow3d_training_trajectory_tracks_oracle():
     """25 AdamW steps from the same weights on the same batch: the product's losses follow the CPU oracle's
     step by step while loss_G falls (tests/tools/soak_vs_oracle.py follows them for 100+ steps, to 1/4 of the
