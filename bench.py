@@ -90,6 +90,9 @@ def parse():
                          "default so that N = 1 and N > 1 run the same code path; no per-kernel records)")
     ap.add_argument("--cpu-size", type=int, nargs="+", default=[64, 128],
                     help="edges of the bounded CPU samples (SURVEY 8d: 64^3 and 128^3); the last one is `value`")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the C2 (Flow-2D) and C3 (UPFlow) legs that follow the headline leg at N = 1")
+    ap.add_argument("--config-steps", type=int, default=20, help="timed steps of the C2 / C3 legs")
     ap.add_argument("--record-steps", type=int, default=2,
                     help="steps of the separate per-launch recording pass (roofline / kernels entries)")
     return ap.parse_args()
@@ -236,6 +239,124 @@ def launch(args):
                     procs[o].terminate()
         time.sleep(0.05)
     return worst
+
+
+HOT_2D = ("fs_warp2d_fwd", "fs_warp2d_bwd", "fs_warp2d_pair_fwd", "fs_warp2d_pair_bwd", "fs_corr2d_fwd",
+          "fs_corr2d_bwd", "fs_corr2d_pair_fwd", "fs_corr2d_pair_bwd", "fs_corr2d_norm_fwd", "fs_corr2d_norm_bwd",
+          "fs_census_dist_fwd", "fs_census_dist_bwd", "fs_robust_sum", "fs_robust_sum_bwd")
+
+
+def _time_steps(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _hot_kernels(fn, steps=2):
+    """Per-launch HIP-event records of `steps` steps -> {entry point: {...}} for the SURVEY 8a rows, plus the one
+    with the largest total time (its algorithmic GB/s is the figure the row is judged by)."""
+    from opticalflowscivis_amd import ops
+    ops.enable_kernel_timing(True)
+    for _ in range(steps):
+        fn()
+    rec = ops.kernel_timings()
+    ops.enable_kernel_timing(False)
+    out, launches = {}, 0
+    for name, rs in rec.items():
+        launches += len(rs)
+        if name not in HOT_2D:
+            continue
+        ms, nb, fl = (sum(r[i] for r in rs) for i in range(3))
+        out[name] = {"launches_per_step": len(rs) / steps, "ms_per_step": round(ms / steps, 4),
+                     "algo_GBps": round(nb / (ms * 1e-3) / 1e9, 1) if nb else None,
+                     "frac_of_hbm_peak": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if nb else None}
+        if fl:
+            out[name]["TFLOPps"] = round(fl / (ms * 1e-3) / 1e12, 2)
+    dom = max(out, key=lambda k: out[k]["ms_per_step"]) if out else None
+    return out, dom, launches / steps
+
+
+def config_c2(dev, steps, warmup, cpu):
+    """BASELINE config 2: Flow-2D droplet 160 x 224, batch 16, one unsupervised train step (Flow-2D/train.py:169):
+    eager, and replayed from one HIP graph (the step is launch-bound)."""
+    from opticalflowscivis_amd.data import synthetic
+    from opticalflowscivis_amd.flow2d.model.RIFE import Model
+    B = 16
+    data = synthetic.droplet2d_batch(B, 160, 224, seed=1234, device=dev)
+    imgs, gt = data[:, :2].contiguous(), data[:, 2:3].contiguous()
+    torch.manual_seed(1234)
+    m = Model(local_rank=-1, device=dev)
+    lr = 3e-4 * (10 / 2000.) / 4
+    eager = lambda: m.update(imgs, gt, "droplet2d", learning_rate=lr, training=True)
+    dt = _time_steps(eager, steps, warmup)
+    hot, dom, launches = _hot_kernels(eager)
+    out = {"workload": "Flow-2D droplet2d 160x224, batch 16, one train step (fwd + losses + bwd + AdamW)",
+           "unit": "frame-pairs/s", "ms_per_step": dt * 1e3, "pairs_per_s": B / dt, "steps": steps,
+           "hip_launches_per_step": launches, "hot_path_kernels": hot, "dominant_hot_path_kernel": dom}
+    g = m.graphed_update(imgs, gt, dataset="droplet2d")
+    dg = _time_steps(lambda: g(imgs, gt, lr), steps, warmup)
+    out["graph_replay"] = {"ms_per_step": dg * 1e3, "pairs_per_s": B / dg}
+    if cpu:
+        from oracle.ifnet_ref import ModelRef
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        torch.manual_seed(1234)
+        o = ModelRef(2)
+        hi, hg = imgs.cpu(), gt.cpu()
+        o.update(hi, hg, learning_rate=lr)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            o.update(hi, hg, learning_rate=lr)
+        dc = (time.perf_counter() - t0) / 3
+        out["cpu_baseline"] = {"value": B / dc, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                               "sample": "oracle Flow-2D train step, the full C2 batch (B=16, 160x224): 3 timed steps, "
+                                         "%.2f s/step" % dc}
+    return out
+
+
+def config_c3(dev, steps, warmup, cpu):
+    """BASELINE config 3: UPFlow on 150 x 450 pairs, batch 32, pyramid cost volume + census loss, one train step
+    (UPFlow/scripts/simple_train.py:278-285)."""
+    from opticalflowscivis_amd.data import synthetic
+    from opticalflowscivis_amd.upflow.scripts.simple_train import Loss_manager, Trainer
+    B = 32
+    conf = Trainer.Config(exp_dir="/tmp/upflow_bench")
+    conf.net_params = dict(conf.net_params, photo_loss_census_weight=1)
+    torch.manual_seed(0)
+    tr = Trainer(conf, device=dev)
+    opt = torch.optim.Adam(tr.net.parameters(), lr=1e-4, weight_decay=1e-4, amsgrad=True)
+    pairs = synthetic.vortex2d_pairs(B, 150, 450, seed=0, device=dev)
+    im1, im2 = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()
+    lm = Loss_manager()
+
+    def step():
+        o = tr.net({'im1': im1, 'im2': im2, 'if_loss': True})
+        loss = lm.compute_loss(o['loss_dict'], B)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    dt = _time_steps(step, steps, warmup)
+    hot, dom, launches = _hot_kernels(step)
+    out = {"workload": "UPFlow vortex pairs 3x150x450, batch 32, census on, one train step (fwd + losses + bwd + Adam)",
+           "unit": "frame-pairs/s", "ms_per_step": dt * 1e3, "pairs_per_s": B / dt, "steps": steps,
+           "hip_launches_per_step": launches, "hot_path_kernels": hot, "dominant_hot_path_kernel": dom,
+           "note": "the stock 2-D convolutions of the PWC network (MIOpen) are most of this step; "
+                   "hot_path_kernels are the SURVEY 8a rows"}
+    if cpu:
+        from oracle.upflow_port import c3_step_seconds
+        cores = usable_cores()
+        Bc = 8
+        dc, _ = c3_step_seconds(Bc, steps=1, threads=cores)
+        out["cpu_baseline"] = {"value": Bc / dc, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                               "sample": "the UPFlow step with the oracle's CPU ops (unfold correlation as "
+                                         "Corr_pyTorch), B=%d of the 32 pairs at 150x450: 1 timed step after one "
+                                         "warm-up, %.2f s/step" % (Bc, dc)}
+    return out
 
 
 def main():
@@ -416,6 +537,16 @@ def main():
                 log("PARITY FAILURE: GPU vs oracle: losses %.3e / step-2 loss %.3e relative, flow %.3e px" % (
                     w["rel"], w["loss_G_step2_rel"], w["flow_max_abs_diff_px"]))
                 rc = 3
+        if world == 1 and not args.no_configs and not ddp:
+            # the other single-GPU BASELINE configurations, driver-timed in the same run (extra keys; the top-level
+            # metric stays config 4's): C2 Flow-2D 160x224 B=16, C3 UPFlow 150x450 B=32 with census
+            model = imgs = gt = data = None
+            torch.cuda.empty_cache()
+            out["configs"] = {}
+            for name, fn in (("C2", config_c2), ("C3", config_c3)):
+                log("config %s" % name)
+                out["configs"][name] = fn(dev, args.config_steps, 5, not args.no_cpu_baseline)
+                torch.cuda.empty_cache()
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     else:

@@ -197,7 +197,8 @@ class _Warp2D(torch.autograd.Function):
         out = inp.new_empty((B, C, H, W))
         with torch.cuda.device(inp.device):
             _call("fs_warp2d_fwd", inp.data_ptr(), flow.data_ptr(), _ptr(start),
-                  out.data_ptr(), B, C, _in_hw(inp, flow), H, W, mode, int(with_mask), _stream(inp))
+                  out.data_ptr(), B, C, _in_hw(inp, flow), H, W, mode, int(with_mask), _stream(inp),
+                  algo_bytes=4 * flow.numel() + 8 * out.numel())  # flow 8 + per channel gather 4 + store 4
         ctx.save_for_backward(inp, flow, start)
         ctx.mode, ctx.with_mask = mode, int(with_mask)
         return out
@@ -216,7 +217,8 @@ class _Warp2D(torch.autograd.Function):
         with torch.cuda.device(inp.device):
             _call("fs_warp2d_bwd", inp.data_ptr(), flow.data_ptr(), _ptr(start),
                   gout.data_ptr(), _ptr(gin), _ptr(gflow), B, C, _in_hw(inp, flow), H, W, ctx.mode,
-                  ctx.with_mask, _stream(inp))
+                  ctx.with_mask, _stream(inp),
+                  algo_bytes=4 * flow.numel() * (2 if need_flow else 1) + 4 * gout.numel() * (3 if need_in else 2))
         return gin, gflow, None, None, None
 
 
@@ -303,7 +305,7 @@ def _pair_forward(img0, img1, flow, nd):
             H, W = flow.shape[2:]
             _call("fs_warp2d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
                   out0.data_ptr(), out1.data_ptr(), B, C, _in_hw(img0, flow), H, W,
-                  WARP2D_RIFE, _stream(flow))
+                  WARP2D_RIFE, _stream(flow), algo_bytes=4 * flow.numel() + 8 * out0.numel() * 2)
     return out0, out1
 
 
@@ -386,7 +388,8 @@ def _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow, gflow_add=None
             gflow = torch.empty_like(flow) if need_flow else None
             _call("fs_warp2d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
                   g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), _ptr(gflow), B, C,
-                  _in_hw(img0, flow), H, W, WARP2D_RIFE, _stream(flow))
+                  _in_hw(img0, flow), H, W, WARP2D_RIFE, _stream(flow),
+                  algo_bytes=4 * flow.numel() * (2 if need_flow else 1) + 8 * g0.numel() * (3 if need_img else 2))
             if gflow_add is not None and gflow is not None:
                 for g in (gflow_add if isinstance(gflow_add, (list, tuple)) else [gflow_add]):
                     if g is not None:
@@ -592,7 +595,8 @@ def corr2d_forward_into(input1, input2, output, max_displacement):
     output.resize_(B, nd * nd, H, W)
     with torch.cuda.device(input1.device):
         _call("fs_corr2d_fwd", input1.data_ptr(), input2.data_ptr(), output.data_ptr(), B, C, H, W,
-              int(max_displacement), _stream(input1))
+              int(max_displacement), _stream(input1), algo_bytes=4 * (2 * input1.numel() + output.numel()),
+              algo_flops=2 * output.numel() * C)
     return output
 
 
@@ -613,7 +617,9 @@ def corr2d_backward_into(input1, input2, grad_output, grad_input1, grad_input2, 
     with torch.cuda.device(input1.device):
         _call("fs_corr2d_bwd", input1.data_ptr(), input2.data_ptr(), grad_output.data_ptr(),
               _ptr(grad_input1), _ptr(grad_input2), B, C, H, W, int(max_displacement),
-              _stream(input1))
+              _stream(input1), algo_bytes=4 * (2 * input1.numel() + grad_output.numel()) + 4 * input1.numel() * sum(
+                  1 for g in (grad_input1, grad_input2) if g is not None),
+              algo_flops=2 * grad_output.numel() * C * sum(1 for g in (grad_input1, grad_input2) if g is not None))
 
 
 class _Corr2D(torch.autograd.Function):
@@ -891,7 +897,7 @@ class _CensusDist(torch.autograd.Function):
         dist = img1.new_empty(B, 1, H, W)
         with torch.cuda.device(img1.device):
             _call("fs_census_dist_fwd", img1.data_ptr(), img2.data_ptr(), dist.data_ptr(), B, H, W,
-                  int(max_distance), _stream(img1))
+                  int(max_distance), _stream(img1), algo_bytes=4 * (2 * img1.numel() + dist.numel()))
         ctx.save_for_backward(img1, img2)
         ctx.md = int(max_distance)
         return dist
@@ -908,7 +914,8 @@ class _CensusDist(torch.autograd.Function):
         g2 = torch.empty_like(img2) if n2 else None
         with torch.cuda.device(img1.device):
             _call("fs_census_dist_bwd", img1.data_ptr(), img2.data_ptr(), gdist.data_ptr(), _ptr(g1),
-                  _ptr(g2), B, H, W, ctx.md, _stream(img1))
+                  _ptr(g2), B, H, W, ctx.md, _stream(img1),
+                  algo_bytes=4 * (2 * img1.numel() + gdist.numel()) + 4 * img1.numel() * (int(n1) + int(n2)))
         return g1, g2, None
 
 

@@ -1,0 +1,94 @@
+"""Oracle (TEST INFRASTRUCTURE): the UPFlow train step on the CPU, for bench.py's `cpu_baseline` leg of BASELINE
+config C3 and for tests -- never for the product path.
+
+The product's UPFlow mirror (`opticalflowscivis_amd/upflow`) keeps the reference's network code on stock torch
+modules and calls seven hot-path ops through `opticalflowscivis_amd.ops`, which exist only as HIP kernels.  `cpu_ops()`
+swaps exactly those seven for this package's CPU restatements (each pinned to the reference's golden vectors by
+tests/test_oracle_golden.py), so that inside the `with` block the mirror computes what the reference's CPU PyTorch
+path computes with `if_use_cor_pytorch=True` (UPFlow/model/upflow.py:643-645: the unfold-based `Corr_pyTorch`).
+"""
+import contextlib
+
+import torch
+
+from . import corr as ocorr
+from . import losses as olosses
+from . import warps as owarps
+
+
+def _corr_fwd_into(input1, input2, output, max_displacement):
+    r = ocorr.corr2d_unfold_ref(input1, input2, max_displacement)  # UPFlow/utils/pytorch_correlation.py:27-50
+    output.resize_(r.shape).copy_(r)
+    return output
+
+
+def _corr_bwd_into(input1, input2, grad_output, grad_input1, grad_input2, max_displacement):
+    with torch.enable_grad():
+        a, b = input1.detach().requires_grad_(), input2.detach().requires_grad_()
+        ga, gb = torch.autograd.grad(ocorr.corr2d_unfold_ref(a, b, max_displacement), [a, b], grad_output)
+    for dst, src in ((grad_input1, ga), (grad_input2, gb)):
+        if dst is not None:
+            dst.resize_(src.shape).copy_(src)
+
+
+def _dilated(I, flow, start=None):
+    if start is not None:
+        start = start.reshape(-1, 2, 1, 1)
+    return owarps.warp2d_dilated_ref(I, flow, start)
+
+
+@contextlib.contextmanager
+def cpu_ops():
+    from opticalflowscivis_amd import ops
+    patch = {
+        "warp2d_pwc": lambda x, flow, with_mask: owarps.warp2d_pwc_ref(x, flow, with_mask),  # a5 / a6
+        "warp2d_dilated": _dilated,                                                          # a7
+        "occ_check2d": lambda ff, fb, a1, a2, scale=1, mode="obj": owarps.occ_check_ref(ff, fb, a1, a2, scale, mode),
+        "photo_loss_multi_type": olosses.photo_loss_multi_type,                               # a9
+        "photo_loss_function": olosses.photo_loss_function,                                   # a10
+        "census_loss": olosses.census_loss,                                                   # a8
+        "corr2d_forward_into": _corr_fwd_into,                                                # a3 / a4
+        "corr2d_backward_into": _corr_bwd_into,
+    }
+    saved = {k: getattr(ops, k) for k in patch}
+    try:
+        for k, v in patch.items():
+            setattr(ops, k, v)
+        yield
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+
+
+def c3_step_seconds(batch, steps=1, size=(150, 450), seed=0, threads=None):
+    """Seconds per UPFlow train step (forward with every loss incl. census, backward, Adam) on the host cores at
+    `batch` pairs of the C3 size; one untimed warm-up step first.  Returns (s_per_step, losses of the last step)."""
+    import time
+    from opticalflowscivis_amd.data import synthetic
+    from opticalflowscivis_amd.upflow.scripts.simple_train import Loss_manager, Trainer
+    if threads:
+        torch.set_num_threads(threads)
+    conf = Trainer.Config(exp_dir="/tmp/upflow_cpu_port")
+    conf.net_params = dict(conf.net_params, photo_loss_census_weight=1)
+    torch.manual_seed(0)
+    tr = Trainer(conf, device="cpu")
+    opt = torch.optim.Adam(tr.net.parameters(), lr=1e-4, weight_decay=1e-4, amsgrad=True)
+    pairs = synthetic.vortex2d_pairs(batch, size[0], size[1], seed=seed)
+    lm = Loss_manager()
+    last = {}
+
+    def step():
+        out = tr.net({'im1': pairs[:, 0], 'im2': pairs[:, 1], 'if_loss': True})
+        loss = lm.compute_loss(out['loss_dict'], batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        last.update({k: float(v.detach()) for k, v in out['loss_dict'].items() if v is not None})
+
+    with cpu_ops():
+        step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dt = (time.perf_counter() - t0) / steps
+    return dt, last

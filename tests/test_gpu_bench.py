@@ -15,7 +15,7 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def test_bench_json_contract():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "32", "--batch", "1", "--steps", "2",
-           "--warmup", "1", "--cpu-size", "32", "48"]
+           "--warmup", "1", "--cpu-size", "32", "48", "--no-configs"]
     r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
@@ -41,3 +41,28 @@ def test_bench_json_contract():
     assert pw["rel"] <= pw["tolerance_rel"] == 5e-4
     assert abs(pw["loss_gpu"] - pw["loss_oracle"]) <= 5e-4 * abs(pw["loss_oracle"])
     assert rf["measured"].startswith("HIP events on the launch stream inside the timed region")
+
+
+def test_bench_line_carries_the_other_single_gpu_configs():
+    """C2 (Flow-2D 160x224 B=16) and C3 (UPFlow 150x450 B=32, census on) are timed in the same
+    run, as extra keys; the top-level metric stays config 4's."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "32", "--batch", "1", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--config-steps", "3"]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("volume-pairs/sec") and d["unit"] == "volume-pairs/s"
+    c2, c3 = d["configs"]["C2"], d["configs"]["C3"]
+    for c, B in ((c2, 16), (c3, 32)):
+        assert c["unit"] == "frame-pairs/s" and c["ms_per_step"] > 0
+        assert abs(c["pairs_per_s"] - B * 1000.0 / c["ms_per_step"]) < 1e-6 * c["pairs_per_s"]
+        assert c["dominant_hot_path_kernel"] in c["hot_path_kernels"]
+        k = c["hot_path_kernels"][c["dominant_hot_path_kernel"]]
+        assert k["algo_GBps"] > 0 and 0 < k["frac_of_hbm_peak"] < 1
+    assert "fs_warp2d_pair_fwd" in c2["hot_path_kernels"] and "fs_robust_sum" in c2["hot_path_kernels"]
+    assert {"fs_corr2d_pair_fwd", "fs_corr2d_pair_bwd", "fs_census_dist_fwd", "fs_census_dist_bwd",
+            "fs_warp2d_fwd", "fs_warp2d_bwd"} <= set(c3["hot_path_kernels"])
+    # the launch-bound C2 step replayed from one HIP graph is not slower than eager
+    assert c2["graph_replay"]["ms_per_step"] < c2["ms_per_step"] * 1.05
