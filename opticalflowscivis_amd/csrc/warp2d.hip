@@ -111,15 +111,21 @@ __device__ __forceinline__ float w2_mask(const Samp2& s) {
   return (m >= 1.0f) ? 1.0f : 0.0f;
 }
 
-template <int MODE, bool MASK>
+// A workgroup is PX = 256 / SL pixels x SL channel slices (thread t: pixel t % PX, slice t / PX; lanes run along
+// x).  SL = 1 for images and fine pyramid levels; the coarse UPFlow levels have few pixels and many channels
+// ([32,196,3,8]: 768 pixels, 196 channels each) -- with one thread per pixel the launch was 3 workgroups walking
+// 196 channels (and 4 atomics per channel) one after the other, 157 us per backward launch; with SL = 16 it is 48
+// workgroups of 12-channel walks.
+template <int MODE, bool MASK, int SL>
 __global__ __launch_bounds__(256) void warp2d_fwd_kernel(W2Fwd io, const float* __restrict__ flow,
                                                          const float* __restrict__ start, W2P p) {
+  constexpr int PX = 256 / SL;
   const float* __restrict__ in = io.in[blockIdx.y];
   float* __restrict__ out = io.out[blockIdx.y];
   const int HW = p.H * p.W;
   const long long n = (long long)p.B * HW;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
+  const int px = threadIdx.x % PX, sl = threadIdx.x / PX;
+  for (long long i = (long long)blockIdx.x * PX + px; i < n; i += (long long)gridDim.x * PX) {
     const int b = (int)(i / HW);
     const int r = (int)(i - (long long)b * HW);
     const int y = r / p.W, x = r - y * p.W;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void warp2d_fwd_kernel(W2Fwd io, const float* 
     const float mk = MASK ? w2_mask(s) : 1.0f;
     const int o00 = s.y0 * p.Wi + s.x0, o10 = s.y0 * p.Wi + s.x1;
     const int o01 = s.y1 * p.Wi + s.x0, o11 = s.y1 * p.Wi + s.x1;
-    for (int c = 0; c < p.C; ++c) {
+    for (int c = sl; c < p.C; c += SL) {
 #pragma clang fp contract(off)
       const float* ic = in + ((size_t)b * p.C + c) * ((size_t)p.Hi * p.Wi);
       const float q00 = s.v00 ? ic[o00] : 0.f, q10 = s.v10 ? ic[o10] : 0.f;
@@ -147,46 +153,70 @@ __global__ __launch_bounds__(256) void warp2d_fwd_kernel(W2Fwd io, const float* 
   }
 }
 
-template <int MODE, bool MASK, bool WITH_GIN>
+// grad_flow sums over the channels: the SL slices of a pixel leave their partial sums in LDS and slice 0 adds them
+// in slice order (deterministic; with SL = 1 it is the plain per-thread running sum).  grad_in stays a scatter with
+// float atomics.
+template <int MODE, bool MASK, bool WITH_GIN, int SL>
 __global__ __launch_bounds__(256) void warp2d_bwd_kernel(W2Bwd io, const float* __restrict__ flow,
                                                          const float* __restrict__ start,
                                                          float* __restrict__ gflow, W2P p) {
+  constexpr int PX = 256 / SL;
+  __shared__ float red[SL > 1 ? 2 * 256 : 1];
   const float* __restrict__ in = io.in[blockIdx.y];
   const float* __restrict__ gout = io.gout[blockIdx.y];
   float* __restrict__ gin = io.gin[blockIdx.y];
   const int HW = p.H * p.W;
   const long long n = (long long)p.B * HW;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / HW);
-    const int r = (int)(i - (long long)b * HW);
-    const int y = r / p.W, x = r - y * p.W;
-    const float* fb = flow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
-    const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
-    const float mk = MASK ? w2_mask(s) : 1.0f;
-    const int o00 = s.y0 * p.Wi + s.x0, o10 = s.y0 * p.Wi + s.x1;
-    const int o01 = s.y1 * p.Wi + s.x0, o11 = s.y1 * p.Wi + s.x1;
-    float gx = 0.f, gy = 0.f;
-    for (int c = 0; c < p.C; ++c) {
-      const size_t pl = ((size_t)b * p.C + c) * ((size_t)p.Hi * p.Wi);
-      const float g = gout[((size_t)b * p.C + c) * HW + r] * mk;
-      const float* ic = in + pl;
-      const float q00 = s.v00 ? ic[o00] : 0.f, q10 = s.v10 ? ic[o10] : 0.f;
-      const float q01 = s.v01 ? ic[o01] : 0.f, q11 = s.v11 ? ic[o11] : 0.f;
-      gx += g * (s.by * (q10 - q00) + s.ay * (q11 - q01));
-      gy += g * (s.bx * (q01 - q00) + s.ax * (q11 - q10));
-      if (WITH_GIN) {
-        float* gc = gin + pl;
-        if (s.v00) atomicAdd(gc + o00, g * (s.bx * s.by));
-        if (s.v10) atomicAdd(gc + o10, g * (s.ax * s.by));
-        if (s.v01) atomicAdd(gc + o01, g * (s.bx * s.ay));
-        if (s.v11) atomicAdd(gc + o11, g * (s.ax * s.ay));
+  const int px = threadIdx.x % PX, sl = threadIdx.x / PX;
+  // every thread of the workgroup runs the same number of rounds (barriers inside)
+  for (long long base = (long long)blockIdx.x * PX; base < n; base += (long long)gridDim.x * PX) {
+    const long long i = base + px;
+    const bool live = i < n;
+    float gx = 0.f, gy = 0.f, mx = 0.f, my = 0.f;
+    int b = 0, r = 0;
+    if (live) {
+      b = (int)(i / HW);
+      r = (int)(i - (long long)b * HW);
+      const int y = r / p.W, x = r - y * p.W;
+      const float* fb = flow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
+      const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
+      const float mk = MASK ? w2_mask(s) : 1.0f;
+      const int o00 = s.y0 * p.Wi + s.x0, o10 = s.y0 * p.Wi + s.x1;
+      const int o01 = s.y1 * p.Wi + s.x0, o11 = s.y1 * p.Wi + s.x1;
+      mx = s.mx; my = s.my;
+      for (int c = sl; c < p.C; c += SL) {
+        const size_t pl = ((size_t)b * p.C + c) * ((size_t)p.Hi * p.Wi);
+        const float g = gout[((size_t)b * p.C + c) * HW + r] * mk;
+        const float* ic = in + pl;
+        const float q00 = s.v00 ? ic[o00] : 0.f, q10 = s.v10 ? ic[o10] : 0.f;
+        const float q01 = s.v01 ? ic[o01] : 0.f, q11 = s.v11 ? ic[o11] : 0.f;
+        gx += g * (s.by * (q10 - q00) + s.ay * (q11 - q01));
+        gy += g * (s.bx * (q01 - q00) + s.ax * (q11 - q10));
+        if (WITH_GIN) {
+          float* gc = gin + pl;
+          if (s.v00) atomicAdd(gc + o00, g * (s.bx * s.by));
+          if (s.v10) atomicAdd(gc + o10, g * (s.ax * s.by));
+          if (s.v01) atomicAdd(gc + o01, g * (s.bx * s.ay));
+          if (s.v11) atomicAdd(gc + o11, g * (s.ax * s.ay));
+        }
       }
     }
     if (gflow != nullptr) {
-      float* gb = gflow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
-      gb[r] = gx * s.mx;
-      gb[HW + r] = gy * s.my;
+      if (SL > 1) {
+        red[threadIdx.x] = gx;
+        red[256 + threadIdx.x] = gy;
+        __syncthreads();
+        if (sl == 0) {
+          gx = red[px]; gy = red[256 + px];
+          for (int k = 1; k < SL; ++k) { gx += red[k * PX + px]; gy += red[256 + k * PX + px]; }
+        }
+        __syncthreads();
+      }
+      if (live && sl == 0) {
+        float* gb = gflow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
+        gb[r] = gx * mx;
+        gb[HW + r] = gy * my;
+      }
     }
   }
 }
@@ -285,30 +315,46 @@ int make_params(W2P& p, int B, int C, int H, int W, int mode, const int* in_hw =
   return FS_OK;
 }
 
-unsigned grid_for(const W2P& p) {
+unsigned grid_for(const W2P& p, int slices = 1) {
   const long long n = (long long)p.B * p.H * p.W;
-  const long long g = (n + 255) / 256;
+  const int px = 256 / slices;
+  const long long g = (n + px - 1) / px;
   return (unsigned)(g < 16384 ? g : 16384);  // grid-stride above 64 blocks per CU
+}
+
+// channel slices per pixel: enough threads to fill the chip (>= 2 waves per SIMD) when the pixels alone do not
+int slices_for(const W2P& p) {
+  const long long n = (long long)p.B * p.H * p.W;
+  if (n >= 131072 || p.C < 4) return 1;
+  if (n * 4 >= 131072 || p.C < 16) return 4;
+  return 16;
 }
 
 template <int MODE, bool MASK>
 void launch_fwd(const W2Fwd& io, int npair, const float* flow, const float* start, W2P& p,
                 hipStream_t st) {
   p.flowC = 2 * npair;
-  hipLaunchKernelGGL((warp2d_fwd_kernel<MODE, MASK>), dim3(grid_for(p), npair), dim3(256), 0, st, io,
-                     flow, start, p);
+  const int sl = slices_for(p);
+  const dim3 g(grid_for(p, sl), npair);
+  if (sl == 1) hipLaunchKernelGGL((warp2d_fwd_kernel<MODE, MASK, 1>), g, dim3(256), 0, st, io, flow, start, p);
+  else if (sl == 4) hipLaunchKernelGGL((warp2d_fwd_kernel<MODE, MASK, 4>), g, dim3(256), 0, st, io, flow, start, p);
+  else hipLaunchKernelGGL((warp2d_fwd_kernel<MODE, MASK, 16>), g, dim3(256), 0, st, io, flow, start, p);
 }
 
 template <int MODE, bool MASK>
 void launch_bwd(const W2Bwd& io, int npair, const float* flow, const float* start, float* gflow,
                 W2P& p, hipStream_t st) {
   p.flowC = 2 * npair;
-  if (io.gin[0] != nullptr)
-    hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, true>), dim3(grid_for(p), npair), dim3(256), 0,
-                       st, io, flow, start, gflow, p);
-  else
-    hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, false>), dim3(grid_for(p), npair), dim3(256), 0,
-                       st, io, flow, start, gflow, p);
+  const int sl = slices_for(p);
+  const dim3 g(grid_for(p, sl), npair);
+#define FS_W2_BWD(GIN, SLN) \
+  hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, GIN, SLN>), g, dim3(256), 0, st, io, flow, start, gflow, p)
+  if (io.gin[0] != nullptr) {
+    if (sl == 1) FS_W2_BWD(true, 1); else if (sl == 4) FS_W2_BWD(true, 4); else FS_W2_BWD(true, 16);
+  } else {
+    if (sl == 1) FS_W2_BWD(false, 1); else if (sl == 4) FS_W2_BWD(false, 4); else FS_W2_BWD(false, 16);
+  }
+#undef FS_W2_BWD
 }
 
 int dispatch_fwd(const W2Fwd& io, int npair, const float* flow, const float* start, W2P& p, int mode,

@@ -31,16 +31,82 @@ class SyntheticTriplets(Dataset):
         return self.n
 
     def __getitem__(self, i):
+        return self.item(i, "cpu")
+
+    def item(self, i, device):
+        """Triplet i generated on `device`: the shape parameters come from the seeded CPU generator either way, the
+        volume itself is evaluated where it is asked for (same elementwise fp32 operations: same values)."""
         s = self.seed + 7919 * i
         if self.kind == "droplet3d":
-            return synthetic.droplet3d_batch(1, self.size[0], seed=s)[0]
+            return synthetic.droplet3d_batch(1, self.size[0], seed=s, device=device)[0]
         if self.kind == "5jets3d":
-            return synthetic.jets3d_batch(1, self.size[0], seed=s)[0]
+            return synthetic.jets3d_batch(1, self.size[0], seed=s, device=device)[0]
         if self.kind == "droplet2d":
             h, w = self.size
             r = (max(4, h // 8), max(8, h // 4))
-            return synthetic.droplet2d_batch(1, h, w, seed=s, radius=r)[0]
+            return synthetic.droplet2d_batch(1, h, w, seed=s, device=device, radius=r)[0]
         raise ValueError("no synthetic generator for dataset %r" % self.kind)
+
+
+class DeviceTripletLoader:
+    """DataLoader stand-in for synthetic data: the same batches (same sampler, same `drop_last` rule, same item
+    values) as `DataLoader(SyntheticTriplets(...))`, but every triplet is generated ON the GPU.  A 256^3 triplet is
+    201 MB: at the bench's 18.6 pairs/s one rank would need 3.7 GB/s of single-threaded host generation plus the
+    H2D copy (the reference feeds its 64^3 pickles with 8 worker processes, Flow-3D/train.py:84); generated on the
+    device it costs ~1 ms of HBM-bound elementwise kernels per sample and no PCIe traffic."""
+
+    def __init__(self, dataset, batch_size, device, sampler=None, shuffle=False, drop_last=False, seed=0):
+        self.dataset, self.batch_size, self.device = dataset, batch_size, device
+        self.sampler, self.shuffle, self.drop_last = sampler, shuffle, drop_last
+        self._gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None else len(self.dataset)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        if self.sampler is not None:
+            order = list(iter(self.sampler))
+        elif self.shuffle:
+            order = torch.randperm(len(self.dataset), generator=self._gen).tolist()
+        else:
+            order = list(range(len(self.dataset)))
+        for k in range(len(self)):
+            idx = order[k * self.batch_size:(k + 1) * self.batch_size]
+            yield torch.stack([self.dataset.item(i, self.device) for i in idx])
+
+
+class DevicePrefetcher:
+    """Host-resident data (any DataLoader with pin_memory=True): the H2D copy of batch k+1 runs on a side stream
+    while step k computes -- what UPFlow's `tools.data_prefetcher` does in the reference (UPFlow/utils/tools.py:
+    177-260); the Flow-2D / Flow-3D loops of the reference copy synchronously in front of every step
+    (Flow-3D/train.py:144)."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+        self.stream = torch.cuda.Stream(device=device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _load(self, it):
+        try:
+            host = next(it)
+        except StopIteration:
+            return None
+        with torch.cuda.stream(self.stream):
+            return host.to(self.device, non_blocking=True)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        nxt = self._load(it)
+        while nxt is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.stream)
+            batch = nxt
+            batch.record_stream(cur)  # its memory may not be reused by the side stream while the step reads it
+            nxt = self._load(it)
+            yield batch
 
 
 def get_learning_rate(step, total_steps):
@@ -96,9 +162,18 @@ def run(args, Model, nd):
     train_set = SyntheticTriplets(args.dataset, args.samples, size, seed)
     val_set = SyntheticTriplets(args.dataset, max(args.batch_size, args.samples // 8), size, seed + 10 ** 6)
     sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True) if distributed else None
-    train_data = DataLoader(train_set, batch_size=args.batch_size, num_workers=args.workers, pin_memory=True,
-                            drop_last=True, sampler=sampler, shuffle=(sampler is None))
-    val_data = DataLoader(val_set, batch_size=args.batch_size, num_workers=args.workers, pin_memory=True)
+    if args.host_data:
+        # the reference's arrangement (Flow-3D/train.py:84: DataLoader workers + pinned memory), with the H2D copy of
+        # the next batch overlapped with the current step
+        train_data = DevicePrefetcher(DataLoader(train_set, batch_size=args.batch_size, num_workers=args.workers,
+                                                 pin_memory=True, drop_last=True, sampler=sampler,
+                                                 shuffle=(sampler is None)), device)
+        val_data = DevicePrefetcher(DataLoader(val_set, batch_size=args.batch_size, num_workers=args.workers,
+                                               pin_memory=True), device)
+    else:
+        train_data = DeviceTripletLoader(train_set, args.batch_size, device, sampler=sampler, shuffle=True,
+                                         drop_last=True, seed=seed)
+        val_data = DeviceTripletLoader(val_set, args.batch_size, device)
     steps_per_epoch = len(train_data)
     log_path = args.log_path
     os.makedirs(log_path, exist_ok=True)
@@ -124,9 +199,9 @@ def run(args, Model, nd):
     for epoch in range(args.epoch):
         if sampler is not None:
             sampler.set_epoch(epoch)
-        t0 = time.time()
+        t0 = te = time.time()
         for i, data in enumerate(train_data):
-            data = data.to(device, non_blocking=True)
+            data = data.to(device, non_blocking=True)  # (already there on both data paths)
             imgs, gt = data[:, :2], data[:, 2:3]
             lr = get_learning_rate(step, max(total, 2001)) * world / 4  # train.py:167
             if nd == 3:
@@ -138,6 +213,12 @@ def run(args, Model, nd):
                     epoch, args.epoch, i, steps_per_epoch, time.time() - t0, float(info['loss_G'].detach())))
                 t0 = time.time()
             step += 1
+        torch.cuda.synchronize(device)
+        if rank == 0 and steps_per_epoch:
+            dt = time.time() - te
+            print("epoch %d train loop: %d steps in %.2f s = %.1f ms/step = %.2f pairs/s per rank (%s data)" % (
+                epoch, steps_per_epoch, dt, dt / steps_per_epoch * 1e3, steps_per_epoch * args.batch_size / dt,
+                "host" if args.host_data else "device-generated"))
         loss, p, pt = evaluate(model, val_data, nd, args.dataset, device)
         if rank == 0:
             print("eval epoch %d: loss_G %.4e  PSNR %.2f dB  (teacher %.2f dB)" % (epoch, loss, p, pt))
@@ -160,7 +241,10 @@ def add_common_args(parser, nd):
     # additions (synthetic data, no hard-coded checkpoint names)
     parser.add_argument('--size', type=int, nargs='+', default=[64] if nd == 3 else [160, 224])
     parser.add_argument('--samples', type=int, default=64, help='synthetic training triplets')
-    parser.add_argument('--workers', type=int, default=0)
+    parser.add_argument('--workers', type=int, default=0, help='DataLoader worker processes (with --host_data)')
+    parser.add_argument('--host_data', action='store_true',
+                        help='generate the synthetic triplets on the host and feed them through a DataLoader + '
+                             'pinned-memory prefetcher (the reference\'s arrangement) instead of on the GPU')
     parser.add_argument('--log_every', type=int, default=10)
     parser.add_argument('--log_path', default='train_log')
     parser.add_argument('--model_name', default='flownet.pkl')

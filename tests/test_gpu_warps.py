@@ -262,6 +262,47 @@ def test_wild_flows_do_not_fault(ops):
     assert torch.equal(o1[same], o2[same])
 
 
+@pytest.mark.parametrize("shape", [(32, 196, 3, 8), (32, 128, 5, 15), (2, 96, 10, 29), (3, 17, 7, 9), (2, 5, 6, 7),
+                                   (1, 64, 19, 57)])
+def test_warp2d_channel_sliced_launches_vs_oracle(ops, shape):
+    """The coarse UPFlow pyramid levels (few pixels, many channels: SURVEY Appendix B) run the 2-D warp with 4 or 16
+    channel slices per pixel; forward, grad_in (atomics) and grad_flow (LDS reduction over the slices) against the
+    oracle, masked (a5) and unmasked (a6), at the C3 level shapes and at shapes whose channel count does not divide
+    into the slices / whose pixel count does not fill the last workgroup."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C * 7 + H)
+    x = torch.rand(shape, generator=g)
+    f = 1.5 * torch.randn(B, 2, 1, 1, generator=g) + 0.6 * torch.randn(B, 2, H, W, generator=g)
+    G = torch.randn(shape, generator=g)
+    sure = ~owarps.pwc_mask_borderline(x, f)
+    for with_mask in (True, False):
+        Gs = G * sure if with_mask else G
+        xo, fo = x.clone().requires_grad_(), f.clone().requires_grad_()
+        ro = owarps.warp2d_pwc_ref(xo, fo, with_mask)
+        rgx, rgf = torch.autograd.grad((ro * Gs).sum(), [xo, fo])
+        xd, fd = x.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+        out = ops.warp2d_pwc(xd, fd, with_mask=with_mask)
+        gx, gf = torch.autograd.grad((out * Gs.to(DEV)).sum(), [xd, fd])
+        err = (out.detach().cpu() - ro.detach()).abs()
+        assert float((err * sure).max() if with_mask else err.max()) < OUT_ATOL
+        assert maxerr(gx, rgx) < GRAD_ATOL
+        assert float((gf.cpu() - rgf).abs().max()) < GRAD_ATOL * max(1.0, C / 8)  # a sum over C channels
+        # flow-only backward (no grad_in): the same grad_flow, bit for bit (same reduction order)
+        fd2 = f.to(DEV).requires_grad_()
+        (gf2,) = torch.autograd.grad((ops.warp2d_pwc(x.to(DEV), fd2, with_mask=with_mask) * Gs.to(DEV)).sum(), [fd2])
+        assert torch.equal(gf2, gf)
+    # the RIFE convention through the same sliced kernels
+    xo, fo = x.clone().requires_grad_(), f.clone().requires_grad_()
+    if H >= 2 and W >= 2:
+        ro = owarps.warp2d_rife_ref(xo, fo)
+        rgx, rgf = torch.autograd.grad((ro * G).sum(), [xo, fo])
+        xd, fd = x.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+        out = ops.warp2d(xd, fd)
+        gx, gf = torch.autograd.grad((out * G.to(DEV)).sum(), [xd, fd])
+        assert maxerr(out, ro) < OUT_ATOL and maxerr(gx, rgx) < GRAD_ATOL
+        assert frac_bad(gf, rgf, GRAD_ATOL * max(1.0, C / 8)) < 1e-3  # border-clamp kinks at tiny extents
+
+
 def _occ_compare(ops, ff, fb, a1, a2, scale, mode, eps=2e-4):
     """HIP masks vs oracle masks: identical except where the tested quantity is within `eps` of the
     threshold (the comparison is discontinuous; fp32 evaluation order decides those pixels)."""
