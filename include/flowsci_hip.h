@@ -37,8 +37,10 @@ enum {
  * written against -- a stale .so would otherwise run with shifted arguments instead of failing.
  *   100  round 1.
  *   300  round 2 inserted `const int* in_hw` into fs_warp2d_{fwd,bwd} and fs_warp2d_pair_{fwd,bwd} (without bumping
- *        the number: fixed in round 3) and added the f1-f4 / conv3d entry points. */
-#define FS_ABI_VERSION 300
+ *        the number: fixed in round 3) and added the f1-f4 / conv3d entry points.
+ *   310  round 3: fs_conv3d_fwd* / fs_conv3d_tr* accept w = NULL ("ws is prepared"), fs_conv3d_*_wprep_jobs,
+ *        fs_conv3d_wprep_batch. */
+#define FS_ABI_VERSION 310
 int fs_version(void);
 /* Static string for an FS_* code. */
 const char* fs_error_string(int code);
@@ -554,6 +556,31 @@ int fs_conv3d_fwd_prelu_ms(const float* const* src, const long long* batch_strid
 int fs_conv3d_wrw_ms(const float* g, const float* const* src, const long long* batch_strides, float* dw,
                      int B, int Cg, int Cs, int Do, int Ho, int Wo, int Di, int Hi, int Wi,
                      int kernel, int stride, int pad, fs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight preparation in one launch per optimiser step.  fs_conv3d_fwd* / fs_conv3d_tr* re-lay their weights into
+ * `ws` with a small launch in front of every convolution (~110 launches of ~5 us per 256^3 Flow-3D step).  A caller
+ * that keeps one `ws` per (layer, use) alive can instead (1) ask each entry point ONCE which re-layout it would run
+ * for its shape -- fs_conv3d_fwd_wprep_jobs / fs_conv3d_tr_wprep_jobs take the arguments of fs_conv3d_fwd /
+ * fs_conv3d_tr (the same dispatch code runs, nothing is launched) and write FsWprepJob records to a HOST array,
+ * returning their number (0: this shape reads `w` directly; < 0: -FS_ERR_*; more than `cap`: array too small);
+ * (2) after every weight update run all jobs with ONE fs_conv3d_wprep_batch launch (`jobs` in DEVICE memory);
+ * (3) call the convolutions with w = NULL: "`ws` is already prepared".  Passing w != NULL keeps the classic
+ * behaviour.  The fused variants (_add, _prelu, _prelu_ms, _dprelu) use the layout of their plain entry point
+ * (fs_conv3d_fwd_dprelu: wmode = kernel == 3).  `x` is only inspected for its alignment; `has_prelu_out`: the
+ * fs_conv3d_tr_prelu form (its two outputs rule out the all-parities kernel). */
+typedef struct FsWprepJob {
+  const float* w; /* source weights (device) */
+  float* ws;      /* destination slab (device) */
+  int kind;       /* layout, private to the library */
+  int total;      /* floats written */
+  int p[6];       /* layout parameters, private to the library */
+} FsWprepJob;
+int fs_conv3d_fwd_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* w, float* ws, int Cin, int Cout, int kernel,
+                             int wmode);
+int fs_conv3d_tr_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* x, const float* w, float* ws, int B, int Cin,
+                            int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout, int has_prelu_out);
+int fs_conv3d_wprep_batch(const FsWprepJob* jobs_dev, int njobs, fs_stream_t stream);
 
 #ifdef __cplusplus
 }

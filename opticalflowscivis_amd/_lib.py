@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libflowsci_hip.so")
-ABI_VERSION = 300  # FS_ABI_VERSION of the include/flowsci_hip.h the SIGNATURES below were written against
+ABI_VERSION = 310  # FS_ABI_VERSION of the include/flowsci_hip.h the SIGNATURES below were written against
 
 _f32p = ctypes.c_void_p  # device pointers travel as integers
 _int = ctypes.c_int
@@ -24,6 +24,14 @@ _intp = ctypes.POINTER(ctypes.c_int)  # host array of ints (or None)
 _i64p = ctypes.POINTER(ctypes.c_longlong)  # host out-parameter
 _i64 = ctypes.c_longlong
 _ptrv = ctypes.POINTER(ctypes.c_void_p)  # host array of device pointers
+
+class FsWprepJob(ctypes.Structure):
+    """include/flowsci_hip.h `FsWprepJob`: one weight re-layout of fs_conv3d_wprep_batch."""
+    _fields_ = [("w", ctypes.c_void_p), ("ws", ctypes.c_void_p), ("kind", ctypes.c_int), ("total", ctypes.c_int),
+                ("p", ctypes.c_int * 6)]
+
+
+_jobp = ctypes.POINTER(FsWprepJob)
 
 # name -> argtypes; restype is int unless listed in _RESTYPES
 SIGNATURES = {
@@ -95,6 +103,9 @@ SIGNATURES = {
     "fs_conv3d_wrw_ms": [_f32p, _ptrv, _i64p, _f32p] + [_int] * 12 + [_stream],
     "fs_wssim_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_wssim_bwd": [_f32p] * 6 + [_int] * 5 + [_stream],
+    "fs_conv3d_fwd_wprep_jobs": [_jobp, _int, _f32p, _f32p] + [_int] * 4,
+    "fs_conv3d_tr_wprep_jobs": [_jobp, _int, _f32p, _f32p, _f32p] + [_int] * 10,
+    "fs_conv3d_wprep_batch": [_f32p, _int, _stream],
     "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _intp, _int, _int, _int, _int, _stream],
     "fs_warp2d_bwd": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _intp, _int, _int, _int, _int,
                       _stream],

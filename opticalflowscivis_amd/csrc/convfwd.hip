@@ -63,22 +63,8 @@ struct FP {
   long long sbs[12];
 };
 
-// Wt[ci][tap][co] (ci < CinP, co < CoutP; zero outside the real channels)
-//   mode 0: W[co][ci][tap]                       (Conv3d forward; ConvTranspose3d input gradient)
-//   mode 1: W[ci][co][K3-1-tap]                  (stride-1 "same" Conv3d input gradient)
-__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
-                                                    int Cin, int K3, int CinP, int CoutP, int mode) {
-  const int total = CinP * K3 * CoutP;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const int co = e % CoutP;
-    const int t = e / CoutP;
-    const int tap = t % K3, ci = t / K3;
-    float v = 0.f;
-    if (co < Cout && ci < Cin)
-      v = mode ? w[((size_t)ci * Cout + co) * K3 + (K3 - 1 - tap)] : w[((size_t)co * Cin + ci) * K3 + tap];
-    wt[e] = v;
-  }
-}
+// the weight re-layout Wt[ci][tap][co] (FS_WPREP_FWD) lives in wprep.hpp
+#include "wprep.hpp"
 
 template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restrict__ X,
@@ -729,9 +715,11 @@ struct MultiSrc {  // the input as per-channel planes (FP::src / FP::sbs)
 static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
                            const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
                            int Ho, int Wo, int kernel, int stride, int pad, int wmode, fs_stream_t stream,
-                           const DPrelu* dp = nullptr, const MultiSrc* ms = nullptr) {
-  if (ms == nullptr) FS_REQUIRE_PTR(x);
-  FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y); FS_REQUIRE_PTR(ws);
+                           const DPrelu* dp = nullptr, const MultiSrc* ms = nullptr, WprepPlan* plan = nullptr) {
+  if (ms == nullptr && plan == nullptr) FS_REQUIRE_PTR(x);
+  // w == NULL: `ws` already holds the re-laid-out weights (fs_conv3d_wprep_batch)
+  if (plan == nullptr) FS_REQUIRE_PTR(y);
+  FS_REQUIRE_PTR(ws);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1 || Do < 1 || Ho < 1 || Wo < 1)
     return FS_ERR_SHAPE;
@@ -779,9 +767,8 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     return hipGetLastError() == hipSuccess ? FS_OK : FS_ERR_LAUNCH;
   };
   const int K3 = kernel * kernel * kernel;
-  const int total = cinp * K3 * p.CoutP;
-  hipLaunchKernelGGL(wprep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, ws, Cout, Cin, K3, cinp,
-                     p.CoutP, wmode);
+  wprep_do(wprep_job(FS_WPREP_FWD, w, ws, (long long)cinp * K3 * p.CoutP, Cout, Cin, K3, cinp, p.CoutP, wmode), plan, st);
+  if (plan != nullptr) return FS_OK;  // every kernel below reads the same slab
   // loader-wave kernels (k = 4: 100 / 129 TFLOP/s vs 92 / 120 for conv0a / conv0b at 256^3; k = 3: every 32-column
   // layer, see below): 16-byte
   // pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets inside one staged channel
@@ -871,6 +858,23 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   if (ws4) return launch_ws<4, 2, 2, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
   if (wide) return launch<4, 2, 2, 1, 1, 1, 4, 32>(x, ws, bias, y, p, st);
   return launch<4, 2, 2, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
+}
+
+// The re-layout job fs_conv3d_fwd* runs for this layer (it depends on the channel counts, the kernel size and wmode
+// only): conv3d_fwd_impl's own code with `plan` set -- nothing is launched.
+extern "C" int fs_conv3d_fwd_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* w, float* ws, int Cin, int Cout,
+                                        int kernel, int wmode) {
+  FS_ENTER();
+  if (jobs_host == nullptr || w == nullptr || ws == nullptr) return -FS_ERR_NULLPTR;
+  if (cap < 0) return -FS_ERR_ARG;
+  if (!(kernel == 3 || kernel == 4)) return -FS_ERR_ARG;
+  WprepPlan plan = {jobs_host, cap, 0};
+  const int stride = kernel == 3 ? 1 : 2, pad = 1, n = 8;  // any valid geometry: the layout does not depend on it
+  const int rc = conv3d_fwd_impl(nullptr, w, nullptr, nullptr, 0, nullptr, nullptr, nullptr, ws, 1, Cin, Cout, n, n, n,
+                                 (n + 2 * pad - kernel) / stride + 1, (n + 2 * pad - kernel) / stride + 1,
+                                 (n + 2 * pad - kernel) / stride + 1, kernel, stride, pad, wmode, nullptr, nullptr, nullptr,
+                                 &plan);
+  return rc == FS_OK ? plan.n : -rc;
 }
 
 extern "C" int fs_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B,

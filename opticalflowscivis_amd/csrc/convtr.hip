@@ -69,16 +69,8 @@ __device__ __forceinline__ void tr_slice(TP& p, const float*& Wt, const float*& 
 __device__ __forceinline__ constexpr int tap_d(int p, int a) { return p == 0 ? (a == 0 ? 0 : -1) : (a == 0 ? 1 : 0); }
 __device__ __forceinline__ constexpr int tap_k(int p, int a) { return p == 0 ? (a == 0 ? 1 : 3) : (a == 0 ? 0 : 2); }
 
-// Wt[ci][tap 0..63][co 0..31] <- W[ci][co][tap]  (zero for co >= Cout, ci >= Cin)
-// (`w` may point at a 32-channel slice of a [Cin][CoutT][64] tensor)
-__global__ __launch_bounds__(256) void wprep_tr_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin,
-                                                       int Cout, int CinP, int CoutT) {
-  const int total = CinP * 64 * 32;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const int co = e & 31, tap = (e >> 5) & 63, ci = e >> 11;
-    wt[e] = (co < Cout && ci < Cin) ? w[((size_t)ci * CoutT + co) * 64 + tap] : 0.f;
-  }
-}
+// the weight re-layouts (FS_WPREP_TR32 / TR16 / P8) live in wprep.hpp
+#include "wprep.hpp"
 
 // all 8 outputs of position q for channel co; float2 stores when the rows are 8-byte aligned.
 // zc / sl: the same channel's plane of the fused PReLU output and its slope (zc may be null).
@@ -289,15 +281,6 @@ __global__ __launch_bounds__(256, 2) void convtr_mfma_kernel(const float* __rest
 // four input channels of the chunk at one tap: a (class, tap) pair is ONE instruction per chunk and
 // column tile, an accumulator tile is 4 VGPRs.  A wave owns one brick row = two 16-position tiles.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256) void wprep_tr16_kernel(const float* __restrict__ w, float* __restrict__ wt,
-                                                         int Cin, int Cout, int CinP) {
-  const int total = CinP * 64 * 16;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const int co = e & 15, tap = (e >> 4) & 63, ci = e >> 10;
-    wt[e] = (co < Cout && ci < Cin) ? w[((size_t)ci * Cout + co) * 64 + tap] : 0.f;
-  }
-}
 
 template <int TZ, int TY>
 __global__ __launch_bounds__(256, 2) void convtr_mfma16_kernel(const float* __restrict__ X,
@@ -707,27 +690,6 @@ __global__ __launch_bounds__(512, 2) void convtr_mfma16_ws_kernel(const float* _
 constexpr int p8_ws_ci(int rt) { return 128 * rt + 16; }  // floats per input channel (+16: LDS bank spread)
 __host__ __device__ constexpr int p8_k(int par, int d) { return par == 0 ? (d == 0 ? 1 : 3) : (d == 0 ? 0 : 2); }
 
-__global__ __launch_bounds__(256) void wprep_p8_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin,
-                                                       int Cout, int CinP, int RT) {
-  const int wsci = 128 * RT + 16;
-  const int total = CinP * wsci;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const int ci = e / wsci, i = e - ci * wsci;
-    float v = 0.f;
-    if (i < 128 * RT && ci < Cin) {
-      const int d = i / (16 * RT), r2 = i - d * 16 * RT;
-      const int rt = r2 >> 4, row = r2 & 15;
-      const int px = row >> 3, item = 8 * rt + (row & 7);
-      if (item < 4 * Cout) {
-        const int pzy = item / Cout, co = item - pzy * Cout;
-        const int kz = p8_k(pzy >> 1, (d >> 2) & 1), ky = p8_k(pzy & 1, (d >> 1) & 1), kx = p8_k(px, d & 1);
-        v = w[((size_t)ci * Cout + co) * 64 + (kz * 4 + ky) * 4 + kx];
-      }
-    }
-    wt[e] = v;
-  }
-}
-
 #ifdef FS_TR_STAMPS
 __device__ unsigned long long fs_tr_dbg[4 * 8];
 #define TSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dt[i] += now_ - tprev; tprev = now_; } while (0)
@@ -1103,8 +1065,12 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
 
 static int conv3d_tr_slice(const float* x, const float* w, const float* bias, const float* slope, int nslope,
                           const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di,
-                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream, int CoutT = 0, int slices = 1) {
-  FS_REQUIRE_PTR(x); FS_REQUIRE_PTR(w); FS_REQUIRE_PTR(y);
+                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream, int CoutT = 0, int slices = 1,
+                          WprepPlan* plan = nullptr) {
+  // w == NULL: `ws` already holds the re-laid-out weights (fs_conv3d_wprep_batch); plan: record the re-layout this
+  // shape needs and launch nothing
+  FS_REQUIRE_PTR(x);
+  if (plan == nullptr) FS_REQUIRE_PTR(y);
   if (z != nullptr && (slope == nullptr || (nslope != 1 && nslope != Cout))) return FS_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1) return FS_ERR_SHAPE;
   if (Cout > 32) return FS_ERR_ARG;
@@ -1140,8 +1106,8 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
     p.tiles = (long long)B * p.tz * p.ty * p.tx;
     if (p.tiles >= 16 && p.tiles < (1ll << 31)) {
       const int cinp = (Cin + 3) / 4 * 4;
-      hipLaunchKernelGGL(wprep_p8_kernel, dim3((cinp * p8_ws_ci(rt) + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
-                         cinp, rt);
+      wprep_do(wprep_job(FS_WPREP_P8, w, ws, (long long)cinp * p8_ws_ci(rt), Cin, Cout, cinp, rt), plan, st);
+      if (plan != nullptr) return FS_OK;
       if (Cin > 32) {  // block0's heads (64 input channels): the weight table is twice as large
         if (rt == 1) { if (wide) launch_p8<1, 9, 64>(x, ws, bias, y, p, st); else launch_p8<1, 5, 64>(x, ws, bias, y, p, st); }
         else { if (wide) launch_p8<3, 9, 64>(x, ws, bias, y, p, st); else launch_p8<3, 5, 64>(x, ws, bias, y, p, st); }
@@ -1153,6 +1119,8 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
     }
   }
   if (Cout <= 6) {
+    if (plan != nullptr) return FS_OK;        // the vector-ALU kernels read `w` as stored: nothing to prepare
+    if (w == nullptr) return FS_ERR_NULLPTR;  // ... and therefore need it
     if (Cout == 1) launch_valu<1>(x, w, bias, y, p, st);
     else if (Cout <= 2) launch_valu<2>(x, w, bias, y, p, st);
     else if (Cout <= 4) launch_valu<4>(x, w, bias, y, p, st);
@@ -1172,8 +1140,8 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   const bool ws_ok = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && p.tiles * slices >= 128 &&
                      (long long)4 * Di * Hi * Wi * 4 < (1ll << 31);
   if (Cout <= 16) {
-    hipLaunchKernelGGL(wprep_tr16_kernel, dim3((cinp * 64 * 16 + 255) / 256), dim3(256), 0, st, w, ws, Cin, Cout,
-                       cinp);
+    wprep_do(wprep_job(FS_WPREP_TR16, w, ws, (long long)cinp * 64 * 16, Cin, Cout, cinp), plan, st);
+    if (plan != nullptr) return FS_OK;
     if (ws_ok)
       hipLaunchKernelGGL((convtr_mfma16_ws_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(512), 0, st, x, ws, bias, y, p);
     else
@@ -1181,8 +1149,9 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   } else {
     p.wslice = (long long)cinp * 64 * 32;
     for (int sl = 0; sl < slices; ++sl)
-      hipLaunchKernelGGL(wprep_tr_kernel, dim3((cinp * 64 * 32 + 255) / 256), dim3(256), 0, st, w + (size_t)sl * 32 * 64,
-                         ws + (size_t)sl * p.wslice, Cin, Cout, cinp, p.CoutT);
+      wprep_do(wprep_job(FS_WPREP_TR32, w ? w + (size_t)sl * 32 * 64 : nullptr, ws + (size_t)sl * p.wslice, p.wslice, Cin,
+                         Cout, cinp, p.CoutT), plan, st);
+    if (plan != nullptr) return FS_OK;
     if (ws_ok)
       hipLaunchKernelGGL((convtr_mfma_ws_kernel<2, 2>), dim3((unsigned)p.tiles, slices), dim3(512), 0, st, x, ws, bias, y, p);
     else
@@ -1197,13 +1166,29 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
 // and the kernels stride batches by the whole tensor's channel count.
 static int conv3d_tr_impl(const float* x, const float* w, const float* bias, const float* slope, int nslope,
                           const float* addend, float* y, float* z, float* ws, int B, int Cin, int Cout, int Di,
-                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream) {
+                          int Hi, int Wi, int Dout, int Hout, int Wout, fs_stream_t stream, WprepPlan* plan = nullptr) {
   if (Cout <= 32) return conv3d_tr_slice(x, w, bias, slope, nslope, addend, y, z, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout,
-                                         Wout, stream);
+                                         Wout, stream, 0, 1, plan);
   if (Cout % 32 != 0 || Cout > 128 || Dout < 1 || Hout < 1 || Wout < 1) return FS_ERR_ARG;
   // all 32-channel slices in one launch (grid.y): pointers of slice 0, the kernels step to theirs
   return conv3d_tr_slice(x, w, bias, slope, nslope == 1 ? 1 : (nslope ? 32 : 0), addend, y, z, ws, B, Cin, 32, Di, Hi, Wi, Dout,
-                         Hout, Wout, stream, Cout, Cout / 32);
+                         Hout, Wout, stream, Cout, Cout / 32, plan);
+}
+
+// The re-layout job(s) fs_conv3d_tr{,_add} (has_prelu_out = 0) / fs_conv3d_tr_prelu (1) would run for this shape: the
+// dispatch above with `plan` set -- nothing is launched.  Returns the number of jobs (0: the kernel reads `w` as stored).
+extern "C" int fs_conv3d_tr_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* x, const float* w, float* ws, int B,
+                                       int Cin, int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout,
+                                       int has_prelu_out) {
+  FS_ENTER();
+  if (jobs_host == nullptr || w == nullptr) return -FS_ERR_NULLPTR;
+  if (cap < 0) return -FS_ERR_ARG;
+  WprepPlan plan = {jobs_host, cap, 0};
+  static const float one = 1.f;
+  float* zdummy = has_prelu_out ? ws : nullptr;  // only tested against NULL
+  const int rc = conv3d_tr_impl(x, w, nullptr, has_prelu_out ? &one : nullptr, has_prelu_out ? 1 : 0, nullptr, nullptr,
+                                zdummy, ws, B, Cin, Cout, Di, Hi, Wi, Dout, Hout, Wout, nullptr, &plan);
+  return rc == FS_OK ? plan.n : -rc;
 }
 
 extern "C" int fs_conv3d_tr(const float* x, const float* w, const float* bias, float* y, float* ws, int B,

@@ -1,0 +1,87 @@
+// wprep.hpp -- re-layout of convolution weights into the slabs the implicit-GEMM kernels stage into LDS, as JOBS:
+// one element function per layout, used by the per-launch preparation (one job per kernel launch, as before) and by
+// fs_conv3d_wprep_batch (all layers of a model in ONE launch per optimiser step: the 256^3 step spent ~110 launches
+// of ~5 us + their dispatch gaps on these).  Include inside the anonymous namespace of the .hip file that uses it.
+#pragma once
+
+// kinds / parameters (FsWprepJob::p), see the kernels that consume each slab:
+//   FS_WPREP_FWD  p = {Cout, Cin, K3, CinP, CoutP, mode}   Wt[ci][tap][co]      (convfwd.hip)
+//       mode 0: W[co][ci][tap] (Conv3d forward; ConvTranspose3d input gradient)
+//       mode 1: W[ci][co][K3-1-tap] (stride-1 "same" Conv3d input gradient)
+//   FS_WPREP_TR32 p = {Cin, Cout, CinP, CoutT}              Wt[ci][tap 0..63][co 0..31] <- W[ci][co][tap]
+//       (`w` may point at a 32-channel slice of a [Cin][CoutT][64] tensor)            (convtr.hip)
+//   FS_WPREP_TR16 p = {Cin, Cout, CinP}                     Wt[ci][tap][co 0..15]
+//   FS_WPREP_P8   p = {Cin, Cout, CinP, RT}                 W'[ci][neighbour][row] (+16 pad) of the all-parities kernel
+enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3 };
+
+__host__ __device__ constexpr int wprep_p8_k(int par, int d) { return par == 0 ? (d == 0 ? 1 : 3) : (d == 0 ? 0 : 2); }
+
+__device__ __forceinline__ float wprep_elem(const FsWprepJob& j, int e) {
+  const float* __restrict__ w = j.w;
+  switch (j.kind) {
+    case FS_WPREP_FWD: {
+      const int Cout = j.p[0], Cin = j.p[1], K3 = j.p[2], CoutP = j.p[4], mode = j.p[5];
+      const int co = e % CoutP;
+      const int t = e / CoutP;
+      const int tap = t % K3, ci = t / K3;
+      if (co >= Cout || ci >= Cin) return 0.f;
+      return mode ? w[((size_t)ci * Cout + co) * K3 + (K3 - 1 - tap)] : w[((size_t)co * Cin + ci) * K3 + tap];
+    }
+    case FS_WPREP_TR32: {
+      const int Cin = j.p[0], Cout = j.p[1], CoutT = j.p[3];
+      const int co = e & 31, tap = (e >> 5) & 63, ci = e >> 11;
+      return (co < Cout && ci < Cin) ? w[((size_t)ci * CoutT + co) * 64 + tap] : 0.f;
+    }
+    case FS_WPREP_TR16: {
+      const int Cin = j.p[0], Cout = j.p[1];
+      const int co = e & 15, tap = (e >> 4) & 63, ci = e >> 10;
+      return (co < Cout && ci < Cin) ? w[((size_t)ci * Cout + co) * 64 + tap] : 0.f;
+    }
+    default: {  // FS_WPREP_P8
+      const int Cin = j.p[0], Cout = j.p[1], RT = j.p[3];
+      const int wsci = 128 * RT + 16;
+      const int ci = e / wsci, i = e - ci * wsci;
+      if (i >= 128 * RT || ci >= Cin) return 0.f;
+      const int d = i / (16 * RT), r2 = i - d * 16 * RT;
+      const int rt = r2 >> 4, row = r2 & 15;
+      const int px = row >> 3, item = 8 * rt + (row & 7);
+      if (item >= 4 * Cout) return 0.f;
+      const int pzy = item / Cout, co = item - pzy * Cout;
+      const int kz = wprep_p8_k(pzy >> 1, (d >> 2) & 1), ky = wprep_p8_k(pzy & 1, (d >> 1) & 1), kx = wprep_p8_k(px, d & 1);
+      return w[((size_t)ci * Cout + co) * 64 + (kz * 4 + ky) * 4 + kx];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wprep_one_kernel(FsWprepJob j) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256) j.ws[e] = wprep_elem(j, e);
+}
+
+// blockIdx.y = job, blockIdx.x strides over its elements
+__global__ __launch_bounds__(256) void wprep_batch_kernel(const FsWprepJob* __restrict__ jobs) {
+  const FsWprepJob j = jobs[blockIdx.y];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256) j.ws[e] = wprep_elem(j, e);
+}
+
+inline FsWprepJob wprep_job(int kind, const float* w, float* ws, long long total, int p0, int p1, int p2 = 0, int p3 = 0,
+                            int p4 = 0, int p5 = 0) {
+  FsWprepJob j;
+  j.w = w; j.ws = ws; j.kind = kind; j.total = (int)total;
+  j.p[0] = p0; j.p[1] = p1; j.p[2] = p2; j.p[3] = p3; j.p[4] = p4; j.p[5] = p5;
+  return j;
+}
+
+// What a convolution entry point does with the re-layout its kernel needs:
+//   plan != nullptr  -> record the job and launch nothing (fs_conv3d_*_wprep_jobs: the caller batches it)
+//   w == nullptr     -> `ws` already holds the slab (prepared by fs_conv3d_wprep_batch), nothing to do
+//   otherwise        -> prepare it now, one small launch in front of the convolution (the classic path)
+struct WprepPlan { FsWprepJob* jobs; int cap; int n; };
+inline void wprep_do(const FsWprepJob& j, WprepPlan* plan, hipStream_t st) {
+  if (plan != nullptr) {
+    if (plan->n < plan->cap) plan->jobs[plan->n] = j;
+    plan->n++;
+    return;
+  }
+  if (j.w == nullptr) return;
+  hipLaunchKernelGGL(wprep_one_kernel, dim3((j.total + 255) / 256), dim3(256), 0, st, j);
+}

@@ -1455,6 +1455,95 @@ def corr3d(f1, f2, max_displacement=4):
 # --------------------------------------------------------------------------------------------
 # IFNet-3D convolution weight gradient: implicit GEMM on the fp32 matrix cores
 # --------------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------------
+# Prepared convolution weights: one re-layout launch per optimiser step instead of one per convolution
+# --------------------------------------------------------------------------------------------
+# fs_conv3d_fwd* / fs_conv3d_tr* re-lay their weights into a slab (`ws`) with a ~5 us launch in front of every
+# convolution: ~110 launches + dispatch gaps per 256^3 Flow-3D step.  For weights that are autograd LEAVES (a model's
+# parameters) the slab is kept, keyed by (storage address, layer geometry); a slab is current while the weight's
+# version counter (bumped by every in-place update: optimiser steps, load_state_dict) and the epoch below are
+# unchanged, and the first convolution that meets a stale slab re-lays ALL registered weights of the device with ONE
+# fs_conv3d_wprep_batch launch.  Anything that changes weights behind autograd's back (HIP-graph replays, writes
+# through `.data`) must call invalidate_prepared_weights().  FLOWSCI_WPREP_PER_LAUNCH=1 restores the per-launch path.
+import os as _os
+import weakref as _weakref
+
+_PREP_ON = _os.environ.get("FLOWSCI_WPREP_PER_LAUNCH") != "1"
+_prep_epoch = 0
+_prep_tables = {}
+
+
+def invalidate_prepared_weights():
+    """Every cached weight slab is stale from now on (call after updating weights outside autograd's view)."""
+    global _prep_epoch
+    _prep_epoch += 1
+
+
+class _PrepEntry:
+    __slots__ = ("wref", "ws", "jobs", "stamp")
+
+
+class _PrepTable:
+    def __init__(self):
+        self.entries, self.dirty, self.dev_jobs, self.njobs = {}, False, None, 0
+
+    def refresh(self, device):
+        live = []
+        for k, e in list(self.entries.items()):
+            w = e.wref()
+            if w is None:  # the weight is gone (its address may be reused): forget the slab
+                del self.entries[k]
+                self.dirty = True
+            elif e.jobs:
+                live.append((e, w))
+        if not live:
+            return
+        if self.dirty or self.dev_jobs is None:
+            jobs = [j for e, _ in live for j in e.jobs]
+            arr = (_lib.FsWprepJob * len(jobs))(*jobs)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
+            self.dev_jobs, self.njobs, self.dirty = host.to(device, non_blocking=True), len(jobs), False
+        with torch.cuda.device(device):
+            _call("fs_conv3d_wprep_batch", self.dev_jobs.data_ptr(), self.njobs,
+                  torch.cuda.current_stream(device).cuda_stream,
+                  algo_bytes=8 * sum(j.total for e, _ in live for j in e.jobs))
+        for e, w in live:
+            e.stamp = (w._version, _prep_epoch)
+
+
+def _prepared(w, nfloats, key, plan):
+    """(pointer to pass as `w`, slab tensor to pass as `ws`).  plan(jobs, cap, ws) -> number of FsWprepJob records
+    written (the library's own dispatch decides the layout).  0 as the pointer means "the slab is prepared"."""
+    if not (_PREP_ON and w.is_leaf and w.requires_grad):
+        return w.data_ptr(), w.new_empty(max(int(nfloats), 1))
+    tab = _prep_tables.setdefault((w.device.type, w.device.index), _PrepTable())
+    k = (w.data_ptr(), tuple(w.shape)) + key
+    e = tab.entries.get(k)
+    if e is None or e.wref() is None:
+        e = _PrepEntry()
+        e.wref, e.stamp = _weakref.ref(w), None
+        e.ws = torch.empty(max(int(nfloats), 1), device=w.device, dtype=torch.float32)
+        buf = (_lib.FsWprepJob * 4)()
+        n = int(plan(buf, 4, e.ws))
+        if n < 0 or n > 4:
+            raise _lib.FlowsciKernelError("weight re-layout plan failed (%d)" % n)
+        e.jobs = [_lib.FsWprepJob.from_buffer_copy(buf[i]) for i in range(n)]
+        tab.entries[k] = e
+        tab.dirty = True
+    if not e.jobs:  # this shape's kernel reads the weights as stored
+        return w.data_ptr(), e.ws
+    if e.stamp != (w._version, _prep_epoch):
+        tab.refresh(w.device)
+    return 0, e.ws
+
+
+def _prepared_fwd(w, Cin, Cout, k, wmode):
+    L = _lib.lib()
+    return _prepared(w, L.fs_conv3d_fwd_ws_floats(Cin, Cout, int(k)), ("fwd", Cin, Cout, int(k), int(wmode)),
+                     lambda jobs, cap, ws: L.fs_conv3d_fwd_wprep_jobs(jobs, cap, w.data_ptr(), ws.data_ptr(), Cin, Cout,
+                                                                     int(k), int(wmode)))
+
+
 def conv3d_wrw_supported(k, stride, padding):
     return (len(k) == 3 and k[0] == k[1] == k[2] and stride[0] == stride[1] == stride[2] and
             padding[0] == padding[1] == padding[2] and (k[0], stride[0]) in ((3, 1), (4, 2)) and
@@ -1545,10 +1634,10 @@ def conv3d_fwd_prelu_ms(pieces, w, bias, prelu_weight, k, stride, pad):
         return None
     y = x0.new_empty((B, Cout, Do, Ho, Wo))
     z = torch.empty_like(y)
-    ws = x0.new_empty(int(_lib.lib().fs_conv3d_fwd_ws_floats(Cin, Cout, int(k))))
+    wp, ws = _prepared_fwd(w, Cin, Cout, k, 0)
     xbytes = 4 * B * Cin * Di * Hi * Wi
     with torch.cuda.device(x0.device):
-        rc = _call_rc("fs_conv3d_fwd_prelu_ms", pv, sv, w.data_ptr(), _ptr(bias), a.data_ptr(), y.data_ptr(), z.data_ptr(),
+        rc = _call_rc("fs_conv3d_fwd_prelu_ms", pv, sv, wp, _ptr(bias), a.data_ptr(), y.data_ptr(), z.data_ptr(),
                    ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(a.numel()),
                       _stream(x0), algo_bytes=xbytes + 8 * y.numel(), algo_flops=2 * y.numel() * Cin * int(k) ** 3,
                       record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
@@ -1602,11 +1691,11 @@ def conv3d_deconv_grad_input_dprelu(gy, w, act_y, prelu_weight):
     out = torch.empty_like(act_y)
     ga, gb = torch.empty_like(a), act_y.new_empty(Cin_t)
     part = act_y.new_empty(npart)
-    ws = act_y.new_empty(int(L.fs_conv3d_fwd_ws_floats(Cg, Cin_t, 4)))
+    wp, ws = _prepared_fwd(w, Cg, Cin_t, 4, 0)
     nb = 4 * (gy.numel() + 2 * out.numel())
     fl = 2 * out.numel() * Cg * 64
     with torch.cuda.device(gy.device):
-        args = (gy.data_ptr(), w.data_ptr(), act_y.data_ptr(), a.data_ptr(), a.numel(), out.data_ptr(), ga.data_ptr(),
+        args = (gy.data_ptr(), wp, act_y.data_ptr(), a.data_ptr(), a.numel(), out.data_ptr(), ga.data_ptr(),
                 gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, Cg, Cin_t, Di, Hi, Wi, Do, Ho, Wo, 4, 2, 1, _stream(gy))
         if _timing is None or (_timing_only is not None and "fs_conv3d_fwd" not in _timing_only):
             rc = L.fs_conv3d_fwd_dprelu(*args)
@@ -1646,9 +1735,9 @@ def conv3d_k3_grad_input_dprelu(gy, w, act_y, prelu_weight):
     out = torch.empty_like(act_y)
     ga, gb = torch.empty_like(a), act_y.new_empty(Cx)
     part = act_y.new_empty(npart)
-    ws = act_y.new_empty(int(L.fs_conv3d_fwd_ws_floats(Cg, Cx, 3)))
+    wp, ws = _prepared_fwd(w, Cg, Cx, 3, 1)
     with torch.cuda.device(gy.device):
-        rc = _call_rc("fs_conv3d_fwd_dprelu", gy.data_ptr(), w.data_ptr(), act_y.data_ptr(), a.data_ptr(), a.numel(),
+        rc = _call_rc("fs_conv3d_fwd_dprelu", gy.data_ptr(), wp, act_y.data_ptr(), a.data_ptr(), a.numel(),
                       out.data_ptr(), ga.data_ptr(), gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, Cg, Cx, D, H, W,
                       D, H, W, 3, 1, 1, _stream(gy), algo_bytes=4 * (gy.numel() + 2 * out.numel()),
                       algo_flops=2 * out.numel() * Cg * 27, record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
@@ -1700,7 +1789,7 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
     if min(Do, Ho, Wo) < 1:
         raise ValueError("convolution output is empty for input %s" % (tuple(x.shape),))
     y = x.new_empty((B, Cout, Do, Ho, Wo))
-    ws = x.new_empty(int(_lib.lib().fs_conv3d_fwd_ws_floats(Cin, Cout, int(k))))
+    wp, ws = _prepared_fwd(w, Cin, Cout, k, wmode)
     nb, fl = 4 * (x.numel() + y.numel()), 2 * y.numel() * Cin * int(k) ** 3
     if addend is not None:
         addend = _need_cuda_f32("addend", addend, 5)
@@ -1709,12 +1798,12 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
         nb += 4 * y.numel()
     with torch.cuda.device(x.device):
         if prelu_weight is None and addend is not None:
-            _call("fs_conv3d_fwd_add", x.data_ptr(), w.data_ptr(), _ptr(bias), addend.data_ptr(), y.data_ptr(),
+            _call("fs_conv3d_fwd_add", x.data_ptr(), wp, _ptr(bias), addend.data_ptr(), y.data_ptr(),
                   ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode),
                   _stream(x), algo_bytes=nb, algo_flops=fl, record_as="fs_conv3d_fwd")
             return y
         if prelu_weight is None:
-            _call("fs_conv3d_fwd", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
+            _call("fs_conv3d_fwd", x.data_ptr(), wp, _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
                   Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode), _stream(x),
                   algo_bytes=nb, algo_flops=fl)
             return y
@@ -1724,7 +1813,7 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
         if a.numel() not in (1, Cout):
             raise ValueError("prelu_weight must have 1 or %d elements" % Cout)
         z = torch.empty_like(y)
-        _call("fs_conv3d_fwd_prelu", x.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), _ptr(addend),
+        _call("fs_conv3d_fwd_prelu", x.data_ptr(), wp, _ptr(bias), a.data_ptr(), _ptr(addend),
               y.data_ptr(), z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride),
               int(pad),
               a.numel(), _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_fwd")
@@ -1757,7 +1846,12 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
     nws = int(_lib.lib().fs_conv3d_tr_ws_floats(Cin, Cout))
     if nws < 0:
         raise ValueError("fs_conv3d_tr supports up to 32 output channels or 64 / 96 / 128, got %d" % Cout)
-    ws = x.new_empty(max(nws, 1))
+    L = _lib.lib()
+    has_z = int(prelu_weight is not None)
+    wp, ws = _prepared(w, nws, ("tr", B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, has_z, x.data_ptr() % 16),
+                       lambda jobs, cap, slab: L.fs_conv3d_tr_wprep_jobs(jobs, cap, x.data_ptr(), w.data_ptr(),
+                                                                        slab.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho,
+                                                                        Wo, has_z))
     nb, fl = 4 * (x.numel() + y.numel()), 2 * x.numel() * Cout * 64
     with torch.cuda.device(x.device):
         if addend is not None:
@@ -1766,19 +1860,19 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
             addend = _need_cuda_f32("addend", addend, 5)
             if addend.shape != y.shape:
                 raise ValueError("addend %s must have the output shape %s" % (tuple(addend.shape), tuple(y.shape)))
-            _call("fs_conv3d_tr_add", x.data_ptr(), w.data_ptr(), _ptr(bias), addend.data_ptr(), y.data_ptr(),
+            _call("fs_conv3d_tr_add", x.data_ptr(), wp, _ptr(bias), addend.data_ptr(), y.data_ptr(),
                   ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb + 4 * y.numel(),
                   algo_flops=fl, record_as="fs_conv3d_tr")
             return y
         if prelu_weight is None:
-            _call("fs_conv3d_tr", x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
+            _call("fs_conv3d_tr", x.data_ptr(), wp, _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
                   Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb, algo_flops=fl)
             return y
         a = _need_cuda_f32("prelu_weight", prelu_weight, 1)
         if a.numel() not in (1, Cout):
             raise ValueError("prelu_weight must have 1 or %d elements" % Cout)
         z = torch.empty_like(y)
-        _call("fs_conv3d_tr_prelu", x.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), y.data_ptr(),
+        _call("fs_conv3d_tr_prelu", x.data_ptr(), wp, _ptr(bias), a.data_ptr(), y.data_ptr(),
               z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, a.numel(), _stream(x),
               algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_tr")
     return y, z

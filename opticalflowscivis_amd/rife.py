@@ -154,6 +154,9 @@ class ModelBase:
             s_gt.copy_(gt)
             self._set_lr(learning_rate)
             graph.replay()
+            # the replay moved the weights without autograd's version counters noticing: a later EAGER step must not
+            # trust the convolution weight slabs the graph's own re-layout launch left behind
+            ops.invalidate_prepared_weights()
             return out
         step.graph = graph
         return step

@@ -41,7 +41,7 @@ def census_dist(img1, img1_warp, max_distance=3):
         oc = patch * patch
         # :59-63 identity convolution = gather of the patch x patch neighbourhood, zero padded
         w = np.eye(oc).reshape((patch, patch, 1, oc))
-        weight = torch.from_numpy(np.transpose(w, (3, 2, 0, 1))).float()
+        weight = torch.from_numpy(np.transpose(w, (3, 2, 0, 1))).float().to(image.device)
         patches = torch.conv2d(gray, weight, None, [1, 1], [max_distance, max_distance])
         t = patches - gray  # :65
         return t / torch.sqrt(0.81 + t ** 2)  # :66
@@ -58,7 +58,7 @@ def census_loss(img1, img1_warp, mask, q, charbonnier_or_abs_robust, if_use_occ,
     # [p00, p01] on the LAST dim and [p10, p11] on dim 2; symmetric here, so it is a border mask.
     B, c, H, W = mask.shape
     m = max_distance
-    inner = torch.ones(B, c, H - 2 * m, W - 2 * m, dtype=mask.dtype)
+    inner = torch.ones(B, c, H - 2 * m, W - 2 * m, dtype=mask.dtype, device=mask.device)
     tmask = F.pad(inner, [m, m, m, m])
     return photo_loss_function(dist, mask * tmask, q, charbonnier_or_abs_robust, if_use_occ, averge)
 

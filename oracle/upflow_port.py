@@ -31,6 +31,15 @@ def _corr_bwd_into(input1, input2, grad_output, grad_input1, grad_input2, max_di
             dst.resize_(src.shape).copy_(src)
 
 
+def _corr_pair(f1a, f2a, f1b, f2b, max_displacement=4, normalize=False):
+    """ops.corr2d_pair (the mirror takes it for CUDA tensors): both directions of a level, with the per-plane
+    `normalize_features` of the C3 configuration in front (UPFlow/model/upflow.py:635-645)."""
+    if normalize:
+        f1a, f2a = ocorr.normalize_features((f1a, f2a), True, True, False, False)
+        f1b, f2b = ocorr.normalize_features((f1b, f2b), True, True, False, False)
+    return ocorr.corr2d_unfold_ref(f1a, f2a, max_displacement), ocorr.corr2d_unfold_ref(f1b, f2b, max_displacement)
+
+
 def _dilated(I, flow, start=None):
     if start is not None:
         start = start.reshape(-1, 2, 1, 1)
@@ -49,6 +58,7 @@ def cpu_ops():
         "census_loss": olosses.census_loss,                                                   # a8
         "corr2d_forward_into": _corr_fwd_into,                                                # a3 / a4
         "corr2d_backward_into": _corr_bwd_into,
+        "corr2d_pair": _corr_pair,
     }
     saved = {k: getattr(ops, k) for k in patch}
     try:
@@ -58,6 +68,12 @@ def cpu_ops():
     finally:
         for k, v in saved.items():
             setattr(ops, k, v)
+
+
+# The restatements are plain torch code and follow their operands' device: on CUDA tensors the same swap gives "the
+# reference's stock torch ops on this GPU" (grid_sample, unfold correlation, 49-channel census), the comparator of
+# the UPFlow end-to-end band in tests/test_gpu_e2e.py.
+stock_ops = cpu_ops
 
 
 def c3_step_seconds(batch, steps=1, size=(150, 450), seed=0, threads=None):

@@ -110,8 +110,10 @@ def warp3d_closed(tenInput, tenFlow):
 # --------------------------------------------------------------------------------------------
 def _pwc_vgrid(flow):
     B, _, H, W = flow.shape
-    xx = torch.arange(0, W).view(1, -1).repeat(H, 1).view(1, 1, H, W).repeat(B, 1, 1, 1)
-    yy = torch.arange(0, H).view(-1, 1).repeat(1, W).view(1, 1, H, W).repeat(B, 1, 1, 1)
+    # (device=...: these restatements also run as "the reference's stock torch ops on this GPU" -- the comparator
+    # of tests/test_gpu_e2e.py's UPFlow band; on the CPU nothing changes)
+    xx = torch.arange(0, W, device=flow.device).view(1, -1).repeat(H, 1).view(1, 1, H, W).repeat(B, 1, 1, 1)
+    yy = torch.arange(0, H, device=flow.device).view(-1, 1).repeat(1, W).view(1, 1, H, W).repeat(B, 1, 1, 1)
     vgrid = torch.cat((xx, yy), 1).float() + flow  # pwc_modules.py:193-197
     # :199-200 scale to [-1, 1] with (W-1), (H-1); out-of-place so autograd stays simple
     vx = 2.0 * vgrid[:, 0] / max(W - 1, 1) - 1.0
@@ -178,10 +180,10 @@ def warp2d_photo_closed(frame, flow):
 def warp2d_dilated_ref(I, flow, start=None):
     B, C, H, W = I.shape
     _, _, ph, pw = flow.shape
-    xs = torch.arange(pw, dtype=flow.dtype).view(1, 1, pw)
-    ys = torch.arange(ph, dtype=flow.dtype).view(1, ph, 1)
+    xs = torch.arange(pw, dtype=flow.dtype, device=flow.device).view(1, 1, pw)
+    ys = torch.arange(ph, dtype=flow.dtype, device=flow.device).view(1, ph, 1)
     if start is None:
-        start = torch.zeros(B, 2, 1, 1, dtype=flow.dtype)
+        start = torch.zeros(B, 2, 1, 1, dtype=flow.dtype, device=flow.device)
     # get_grid :396-410 adds the patch offset, warp_im :538 adds the flow
     x = (xs + start[:, 0]) + flow[:, 0]
     y = (ys + start[:, 1]) + flow[:, 1]
@@ -225,8 +227,8 @@ def occ_fb_lhs_thresh(flow_fw, flow_bw, alpha1, alpha2, scale=1):
 def occ_outgoing_ref(flow):
     """tools.py:683-709."""
     B, C, H, W = flow.size()
-    xx = torch.arange(0, W).view(1, -1).repeat(H, 1).view(1, 1, H, W).repeat(B, 1, 1, 1).float()
-    yy = torch.arange(0, H).view(-1, 1).repeat(1, W).view(1, 1, H, W).repeat(B, 1, 1, 1).float()
+    xx = torch.arange(0, W, device=flow.device).view(1, -1).repeat(H, 1).view(1, 1, H, W).repeat(B, 1, 1, 1).float()
+    yy = torch.arange(0, H, device=flow.device).view(-1, 1).repeat(1, W).view(1, 1, H, W).repeat(B, 1, 1, 1).float()
     pos_x, pos_y = xx + flow[:, 0:1], yy + flow[:, 1:2]
     m = torch.ones_like(pos_x)
     m[pos_x > W - 1] = 0

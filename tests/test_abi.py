@@ -88,3 +88,32 @@ def test_model_requires_gpu():
     from opticalflowscivis_amd.flow3d.model.RIFE import Model
     with pytest.raises(RuntimeError, match="no CPU"):
         Model(local_rank=-1)
+
+
+def test_weight_relayout_plans_without_gpu():
+    """fs_conv3d_{fwd,tr}_wprep_jobs run the entry points' own dispatch with nothing launched: host-only, so the
+    layouts they pick for the IFNet-3D layer shapes are checkable here (slab sizes == fs_conv3d_*_ws_floats)."""
+    from opticalflowscivis_amd import _lib
+    L = _lib.lib()
+    buf = (_lib.FsWprepJob * 4)()
+    assert ctypes.sizeof(_lib.FsWprepJob) == 48
+    n = L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000, 0x2000, 64, 64, 3, 1)
+    assert n == 1 and buf[0].w == 0x1000 and buf[0].ws == 0x2000 and buf[0].total == L.fs_conv3d_fwd_ws_floats(64, 64, 3)
+    n = L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000, 0x2000, 11, 32, 4, 0)
+    assert n == 1 and buf[0].total == L.fs_conv3d_fwd_ws_floats(11, 32, 4) == 12 * 64 * 32
+    assert L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000, 0x2000, 8, 8, 5, 0) == -3          # -FS_ERR_ARG
+    assert L.fs_conv3d_fwd_wprep_jobs(buf, 4, None, 0x2000, 8, 8, 3, 0) == -1            # -FS_ERR_NULLPTR
+    kinds = {}
+    for cin, cout, di, z in ((64, 32, 64, 0), (32, 6, 128, 0), (32, 1, 128, 0), (32, 11, 128, 0), (128, 64, 16, 0),
+                             (32, 6, 128, 1), (5, 3, 9, 0)):
+        n = L.fs_conv3d_tr_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 2, cin, cout, di, di, di, 2 * di, 2 * di, 2 * di, z)
+        assert n >= 0
+        assert sum(buf[i].total for i in range(n)) <= L.fs_conv3d_tr_ws_floats(cin, cout)
+        kinds[(cin, cout, di, z)] = [buf[i].kind for i in range(n)]
+    assert kinds[(64, 32, 64, 0)] == [1] and kinds[(128, 64, 16, 0)] == [1, 1]           # 32-channel slices
+    assert kinds[(32, 11, 128, 0)] == [2] and kinds[(32, 6, 128, 0)] == [3] and kinds[(32, 1, 128, 0)] == [3]
+    assert kinds[(32, 6, 128, 1)] == [] and kinds[(5, 3, 9, 0)] == []                      # kernels that read w as stored
+    # a misaligned input rules out the loader-wave / all-parities kernels: another layout (or none) is planned
+    n = L.fs_conv3d_tr_wprep_jobs(buf, 4, 0x4004, 0x1000, 0x2000, 2, 32, 6, 128, 128, 128, 256, 256, 256, 0)
+    assert n == 0
+    assert L.fs_conv3d_wprep_batch(None, 1, None) == 1 and L.fs_conv3d_wprep_batch(0x10, 0, None) == 2

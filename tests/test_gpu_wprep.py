@@ -1,0 +1,114 @@
+"""-m gpu: convolution weights re-laid-out once per optimiser step (fs_conv3d_wprep_batch + w = NULL calls) instead of
+in front of every convolution -- same numbers as the per-launch path, one launch per step, and no stale slab after any
+way the weights can change."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(seed=11):
+    from opticalflowscivis_amd.flow3d.model.RIFE import Model
+    torch.manual_seed(seed)
+    return Model(local_rank=-1, device=DEV)
+
+
+def _batch(seed, S=32, B=1):
+    from opticalflowscivis_amd.data import synthetic
+    d = synthetic.droplet3d_batch(B, S, seed=seed, device=DEV)
+    return d[:, :2].contiguous(), d[:, 2:3].contiguous()
+
+
+def _infer(m, imgs):
+    m.eval()
+    with torch.no_grad():
+        merged, flows, mask = m.inference(imgs[:, :1], imgs[:, 1:2])
+    return merged, flows[2]
+
+
+@pytest.mark.parametrize("S", [32, 48])
+def test_prepared_weights_equal_the_per_launch_path(monkeypatch, S):
+    from opticalflowscivis_amd import ops
+    imgs, gt = _batch(3, S)
+    m = _model()
+    a = _infer(m, imgs)
+    monkeypatch.setattr(ops, "_PREP_ON", False)
+    b = _infer(m, imgs)
+    monkeypatch.setattr(ops, "_PREP_ON", True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])  # same kernels, same slabs: bit for bit
+    # training: the loss trajectories agree step by step (the weight-gradient atomics make them differ in the last
+    # digits only), i.e. every step saw the weights the previous optimiser step produced
+    state = copy.deepcopy(m.flownet.state_dict())
+    on = [float(m.update(imgs, gt, learning_rate=3e-4, training=True)[1]["loss_G"].detach()) for _ in range(4)]
+    m2 = _model()
+    m2.flownet.load_state_dict(state)
+    monkeypatch.setattr(ops, "_PREP_ON", False)
+    off = [float(m2.update(imgs, gt, learning_rate=3e-4, training=True)[1]["loss_G"].detach()) for _ in range(4)]
+    for x, y in zip(on, off):
+        assert abs(x - y) <= 2e-4 * abs(y), (on, off)
+    assert abs(on[0] - on[3]) > 1e-4 * abs(on[0])  # the weights did move
+
+
+def test_one_relayout_launch_per_step():
+    from opticalflowscivis_amd import ops
+    imgs, gt = _batch(4)
+    m = _model()
+    m.update(imgs, gt, learning_rate=1e-4, training=True)  # registers every layer (one growing batch per new layer)
+    ops.enable_kernel_timing(True)
+    for _ in range(3):
+        m.update(imgs, gt, learning_rate=1e-4, training=True)
+    rec = ops.kernel_timings()
+    ops.enable_kernel_timing(False)
+    assert len(rec["fs_conv3d_wprep_batch"]) == 3
+    # inference with unchanged weights: no re-layout at all
+    ops.enable_kernel_timing(True)
+    _infer(m, imgs)
+    _infer(m, imgs)
+    rec = ops.kernel_timings()
+    ops.enable_kernel_timing(False)
+    assert len(rec.get("fs_conv3d_wprep_batch", [])) <= 1
+
+
+def test_no_stale_slab_after_any_weight_change(monkeypatch):
+    from opticalflowscivis_amd import ops
+    imgs, gt = _batch(5)
+    m = _model()
+    ref = _model()
+
+    def same():
+        ref.flownet.load_state_dict(m.flownet.state_dict())
+        monkeypatch.setattr(ops, "_PREP_ON", False)
+        want = _infer(ref, imgs)
+        monkeypatch.setattr(ops, "_PREP_ON", True)
+        got = _infer(m, imgs)
+        return torch.equal(got[1], want[1])
+
+    assert same()
+    m.update(imgs, gt, learning_rate=1e-3, training=True)               # optimiser step (in-place, version bump)
+    assert same()
+    other = _model(seed=99)
+    m.flownet.load_state_dict(other.flownet.state_dict())               # load_state_dict (copy_)
+    assert same()
+    with torch.no_grad():
+        for p in m.flownet.parameters():
+            p.mul_(1.01)                                                # in-place under no_grad
+    assert same()
+    for p in m.flownet.parameters():
+        p.data.mul_(0.99)                                               # behind autograd's back ...
+    ops.invalidate_prepared_weights()                                   # ... needs the explicit call
+    assert same()
+    # HIP-graph replays move the weights without version bumps: the step wrapper invalidates
+    m.train()
+    step = m.graphed_update(imgs, gt)
+    step(imgs, gt, 1e-3)
+    step(imgs, gt, 1e-3)
+    assert same()
+    eager = float(m.update(imgs, gt, learning_rate=1e-3, training=True)[1]["loss_G"].detach())
+    ref.train()
+    monkeypatch.setattr(ops, "_PREP_ON", False)
+    ref.flownet.load_state_dict(m.flownet.state_dict())
+    assert same()
+    assert eager == eager  # finite
