@@ -1459,24 +1459,40 @@ def corr3d(f1, f2, max_displacement=4):
 # Prepared convolution weights: one re-layout launch per optimiser step instead of one per convolution
 # --------------------------------------------------------------------------------------------
 # fs_conv3d_fwd* / fs_conv3d_tr* re-lay their weights into a slab (`ws`) with a ~5 us launch in front of every
-# convolution: ~110 launches + dispatch gaps per 256^3 Flow-3D step.  For weights that are autograd LEAVES (a model's
-# parameters) the slab is kept, keyed by (storage address, layer geometry); a slab is current while the weight's
-# version counter (bumped by every in-place update: optimiser steps, load_state_dict) and the epoch below are
-# unchanged, and the first convolution that meets a stale slab re-lays ALL registered weights of the device with ONE
-# fs_conv3d_wprep_batch launch.  Anything that changes weights behind autograd's back (HIP-graph replays, writes
-# through `.data`) must call invalidate_prepared_weights().  FLOWSCI_WPREP_PER_LAUNCH=1 restores the per-launch path.
+# convolution: ~110 launches + dispatch gaps per 256^3 Flow-3D step.  Inside a `with prepared_weights():` block the
+# slabs of weights that are autograd LEAVES (a model's parameters) are kept, keyed by (storage address, layer
+# geometry), and the first convolution that meets a stale slab re-lays ALL registered weights of the device with ONE
+# fs_conv3d_wprep_batch launch.  The block is a promise by its owner -- `Model.update` / `Model.inference` -- that the
+# weights change only at its end (the optimiser step): leaving it makes every slab stale.  That explicit epoch is the
+# rule; tensor version counters are checked as well, but they cannot be the rule: torch's fused AdamW updates
+# parameters without bumping them.  Outside such a block (a bare IFNet, the convgrad modules in someone else's
+# model) every convolution prepares its weights itself, as before.  FLOWSCI_WPREP_PER_LAUNCH=1: never keep slabs.
+import contextlib as _contextlib
 import os as _os
 import weakref as _weakref
 
 _PREP_ON = _os.environ.get("FLOWSCI_WPREP_PER_LAUNCH") != "1"
 _prep_epoch = 0
+_prep_depth = 0
 _prep_tables = {}
 
 
 def invalidate_prepared_weights():
-    """Every cached weight slab is stale from now on (call after updating weights outside autograd's view)."""
+    """Every cached weight slab is stale from now on."""
     global _prep_epoch
     _prep_epoch += 1
+
+
+@_contextlib.contextmanager
+def prepared_weights():
+    """Weights are constant inside this block except for an optimiser step at its very end."""
+    global _prep_depth
+    _prep_depth += 1
+    try:
+        yield
+    finally:
+        _prep_depth -= 1
+        invalidate_prepared_weights()
 
 
 class _PrepEntry:
@@ -1514,7 +1530,7 @@ class _PrepTable:
 def _prepared(w, nfloats, key, plan):
     """(pointer to pass as `w`, slab tensor to pass as `ws`).  plan(jobs, cap, ws) -> number of FsWprepJob records
     written (the library's own dispatch decides the layout).  0 as the pointer means "the slab is prepared"."""
-    if not (_PREP_ON and w.is_leaf and w.requires_grad):
+    if not (_PREP_ON and _prep_depth > 0 and w.is_leaf and w.requires_grad):
         return w.data_ptr(), w.new_empty(max(int(nfloats), 1))
     tab = _prep_tables.setdefault((w.device.type, w.device.index), _PrepTable())
     k = (w.data_ptr(), tuple(w.shape)) + key

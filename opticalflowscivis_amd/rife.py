@@ -172,7 +172,8 @@ class Model3D(ModelBase):
 
     def inference(self, img0, img1, scale_list=(4, 2, 1), TTA=False, timestep=0.5):
         imgs = torch.cat((img0, img1), 1)
-        flow, mask, merged, _, _, _ = self.flownet(imgs, scale_list, timestep=timestep)
+        with ops.prepared_weights():  # the convolution weights are re-laid-out once per call, not once per layer
+            flow, mask, merged, _, _, _ = self.flownet(imgs, scale_list, timestep=timestep)
         if TTA:
             raise NotImplementedError("TTA is 'not implemented' in the reference too (RIFE.py:76)")
         return merged[2], flow, mask
@@ -181,6 +182,12 @@ class Model3D(ModelBase):
         """`lap_loss=True` swaps the two L1 terms for the Laplacian-pyramid loss the reference has commented
         out (RIFE.py:126, 133: `(self.lap(merged[2], gt)).mean()`), computed by the 3-D pyramid kernels; the
         default is the reference's active path."""
+        # forward, backward and the optimiser step see ONE set of weights: their re-laid-out slabs are built by one
+        # launch at the first convolution and dropped when the step ends (ops.prepared_weights)
+        with ops.prepared_weights():
+            return self._update(imgs, gt, learning_rate, training, lap_loss)
+
+    def _update(self, imgs, gt, learning_rate, training, lap_loss):
         self._set_lr(learning_rate)
         if training:
             self.train()

@@ -120,9 +120,67 @@ def test_upflow_matches_reference_golden(golden):
     sum(out['loss_dict'][k] for k in keys).backward()
     gsum = np.array([float(p.grad.detach().double().abs().sum()) if p.grad is not None else 0.0
                      for p in net.parameters()])
-    # gradient magnitude per parameter tensor: same band (these sums move with every flipped mask pixel)
+    # gradient magnitude per parameter tensor: these sums move with every flipped mask / occlusion pixel, so the bound
+    # is tied to the fraction of occlusion-mask pixels that differ from the reference's (measured: 0.3-0.6 % of the
+    # pixels, median deviation 0.3-0.9 %, worst tensor 1.9-3.5 %; the stock torch ops on this GPU: 0.4-0.6 % / 1.4-2.5 %)
+    occ_diff = float((out['occ_fw'].cpu() != occ_ref).float().mean())
     rel = np.abs(gsum - g["grad_abs_sums"]) / (np.abs(g["grad_abs_sums"]) + 1e-3)
-    assert np.median(rel) < 0.05 and rel.max() < 0.5
+    assert np.median(rel) < 0.02 + 3 * occ_diff and rel.max() < 0.03 + 10 * occ_diff, (np.median(rel), rel.max(), occ_diff)
+
+
+def _upflow_deviation(g, stock):
+    """One forward + backward of the UPFlow mirror on this GPU against the reference's CPU golden: with the HIP ops, or
+    (stock=True) with every hot-path op swapped for the reference's own formulation in stock torch ops on the GPU
+    (grid_sample, unfold correlation, 49-channel census: oracle/upflow_port.py::stock_ops)."""
+    import contextlib
+    from opticalflowscivis_amd.upflow.model.upflow import UPFlow_net
+    from oracle.upflow_port import stock_ops
+    conf = UPFlow_net.config()
+    conf.update({'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+                 'norm_moments_across_images': False, 'photo_loss_census_weight': 1,
+                 'multi_scale_distillation_weight': 1})
+    torch.manual_seed(0)
+    net = conf().to(DEV)
+    keys = [str(k) for k in g["loss_keys"]]
+    with (stock_ops() if stock else contextlib.nullcontext()):
+        out = net({'im1': torch.from_numpy(g["im1"]), 'im2': torch.from_numpy(g["im2"]), 'if_loss': True})
+        got = np.array([float(out['loss_dict'][k].detach()) for k in keys])
+        sum(out['loss_dict'][k] for k in keys).backward()
+    ref_f = torch.from_numpy(g["flow_f_out"])
+    scale = float(ref_f.abs().max())
+    err = (out['flow_f_out'].detach().cpu() - ref_f).abs()
+    gsum = np.array([float(p.grad.detach().double().abs().sum()) if p.grad is not None else 0.0
+                     for p in net.parameters()])
+    rel = np.abs(gsum - g["grad_abs_sums"]) / (np.abs(g["grad_abs_sums"]) + 1e-3)
+    return dict(flow_median=float(err.median()) / scale, flow_p99=float(err.flatten().quantile(0.99)) / scale,
+                loss=float(np.max(np.abs(got - g["losses"]) / np.abs(g["losses"]))),
+                occ=float((out['occ_fw'].cpu() != torch.from_numpy(g["occ_fw"])).float().mean()),
+                grad_median=float(np.median(rel)), grad_max=float(rel.max()))
+
+
+def test_upflow_hip_path_is_no_further_from_the_reference_than_its_own_torch_ops(golden):
+    """the comparator of the UPFlow end-to-end band, measured in the test instead of quoted in a
+    comment.  The reference's own op formulations, run as stock torch ops on THIS GPU, do not reproduce its CPU
+    result either (MIOpen's 2-D convolutions are not reproducible from call to call; fp32-borderline validity masks
+    flip): three runs of each side, and for every metric the HIP path's best run must be within 1.5 x the stock path's
+    worst -- the HIP kernels add no deviation of their own beyond what the platform's noise already gives the
+    reference's ops.  (Measured, 4 runs each: flow median 0.28-0.45 % vs 0.30-0.60 % of the flow scale, 99th
+    percentile 1.7-3.8 % vs 1.6-3.8 %, losses 0.05-0.42 % vs 0.07-0.29 %, gradient sums worst tensor 1.9-3.5 % vs
+    1.4-2.5 %.  `torch.backends.cudnn.deterministic = True` is not an option: MIOpen answers
+    miopenStatusUnknownError for one of the PWC shapes in that mode on this image.)  The epsilon-level statement about
+    the same network lives on the CPU: tests/test_oracle_e2e.py::test_upflow_mirror_on_oracle_ops_matches_reference
+    (the mirror on the oracle's ops equals the reference bit for bit), and op by op in test_gpu_warps / test_gpu_losses
+    / test_gpu_c3_batch."""
+    g = golden("upflow_e2e")
+    stock = [_upflow_deviation(g, True) for _ in range(3)]
+    hip = [_upflow_deviation(g, False) for _ in range(3)]
+    for k in stock[0]:
+        s_worst, h_best = max(r[k] for r in stock), min(r[k] for r in hip)
+        print("%-12s stock %s | hip %s" % (k, " ".join("%.2e" % r[k] for r in stock), " ".join("%.2e" % r[k] for r in hip)))
+        assert h_best <= 1.5 * s_worst + 1e-4, (k, stock, hip)
+    # and every HIP run stays inside the absolute band of test_upflow_matches_reference_golden
+    for r in hip:
+        assert r["flow_median"] < 0.02 and r["flow_p99"] < 0.08 and r["loss"] < 1.5e-2 and r["occ"] < 2e-2
 
 
 def _proj(t, seed):

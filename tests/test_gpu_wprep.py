@@ -69,7 +69,7 @@ def test_one_relayout_launch_per_step():
     _infer(m, imgs)
     rec = ops.kernel_timings()
     ops.enable_kernel_timing(False)
-    assert len(rec.get("fs_conv3d_wprep_batch", [])) <= 1
+    assert len(rec.get("fs_conv3d_wprep_batch", [])) == 2  # one per Model.inference call
 
 
 def test_no_stale_slab_after_any_weight_change(monkeypatch):
@@ -97,9 +97,15 @@ def test_no_stale_slab_after_any_weight_change(monkeypatch):
             p.mul_(1.01)                                                # in-place under no_grad
     assert same()
     for p in m.flownet.parameters():
-        p.data.mul_(0.99)                                               # behind autograd's back ...
-    ops.invalidate_prepared_weights()                                   # ... needs the explicit call
+        p.data.mul_(0.99)                                               # behind autograd's back, between calls
     assert same()
+    # outside Model.update / Model.inference nothing is kept: a bare IFNet prepares per launch
+    ops.enable_kernel_timing(True)
+    with torch.no_grad():
+        m.flownet(torch.cat((imgs[:, :1], imgs[:, 1:2]), 1), [4, 2, 1])
+    rec = ops.kernel_timings()
+    ops.enable_kernel_timing(False)
+    assert "fs_conv3d_wprep_batch" not in rec
     # HIP-graph replays move the weights without version bumps: the step wrapper invalidates
     m.train()
     step = m.graphed_update(imgs, gt)
