@@ -420,8 +420,9 @@ class Conv3d(nn.Conv3d):
             if x.dim() == 5 and self.padding_mode == "zeros" and self.groups == 1 and _tuple(self.dilation, 3) == (1, 1, 1) \
                     and _hip_fwd_ok(x, self.weight.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
                                                               zip(x.shape[2:], k, st, pd)], k, st, pd):
-                from . import ops  # inference: same kernel, no autograd node
-                return ops.conv3d_fwd(x, self.weight.detach(), None if self.bias is None else self.bias.detach(),
+                from . import ops  # inference (grad mode off: nothing is recorded): same kernel, no autograd node; the
+                # parameter itself is passed so that its re-laid-out slab can be kept (ops.prepared_weights)
+                return ops.conv3d_fwd(x, self.weight, None if self.bias is None else self.bias.detach(),
                                       k[0], st[0], pd[0], 0)
             return super().forward(x)
         return _ConvFn.apply(x, self.weight, self.bias, _tuple(self.stride, 3), _tuple(self.padding, 3), False)
@@ -443,13 +444,13 @@ class ConvTranspose3d(nn.ConvTranspose3d):
                 if _hip_autograd(x):
                     return _ConvTrAddFn.apply(x, self.weight, self.bias, addend, st, pd)
                 from . import ops
-                return ops.conv3d_tr(x, self.weight.detach(), None if self.bias is None else self.bias.detach(),
+                return ops.conv3d_tr(x, self.weight, None if self.bias is None else self.bias.detach(),
                                      None, None, addend)
             return self.forward(x) + addend
         if not _hip_autograd(x):
             if hip:
                 from . import ops  # inference: same kernel, no autograd node
-                return ops.conv3d_tr(x, self.weight.detach(), None if self.bias is None else self.bias.detach())
+                return ops.conv3d_tr(x, self.weight, None if self.bias is None else self.bias.detach())
             return super().forward(x)
         return _ConvFn.apply(x, self.weight, self.bias, st, pd, True)
 
