@@ -53,27 +53,50 @@ def roofline(dom, k, S, B):
     """Roofline record of the dominant hand-written kernel: the fp32 implicit-GEMM convolutions (forward /
     input gradient, weight gradient, transposed) are priced against the dense fp32 MFMA peak, every
     other kernel against HBM."""
+    traffic, src = pmc_traffic(dom, S, B)
     if "TFLOPps" in k and dom in ("fs_conv3d_wrw", "fs_conv3d_fwd", "fs_conv3d_tr"):
         return {"bound": "mfma", "kernel": dom, "achieved": k["TFLOPps"], "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(k["TFLOPps"] / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(dom, S, B)}
+                "traffic": traffic, "traffic_source": src}
     return {"bound": "hbm", "kernel": dom, "achieved": k["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(k["algo_GBps"] / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, S, B)}
+            "frac": round(k["algo_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src}
+
+
+def kernel_sources_sha256():
+    """Hash of every kernel source + the C-ABI header (the same function as scripts/pmc_traffic.py's)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "opticalflowscivis_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    for path in files + [os.path.join(ROOT, "include", "flowsci_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
 
 
 def pmc_traffic(kernel, S, B):
-    """HBM bytes per launch (averaged over the entry point's launches of one step) from the committed
-    rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE x1, as MI355X_MICROARCH.md prescribes);
-    only valid for the workload they were taken on."""
-    for name in ("r02_pmc_traffic.json", "r01_warp3d_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                d = json.load(f)
-            if S == 256 and B == 2 and kernel in d["kernels"]:
-                return d["kernels"][kernel]["hbm_bytes_corrected"]
-        except (OSError, KeyError, ValueError):
-            pass
-    return None
+    """HBM bytes per launch (averaged over the entry point's launches of one step) from the committed rocprofv3 --pmc
+    passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950, as
+    MI355X_MICROARCH.md prescribes; scripts/final_profile.sh).  PMC counters cannot be read from inside the timed
+    run, so this is a recorded figure -- valid only for the workload AND the kernels it was taken on: the file carries
+    the hash of the kernel sources, and a file taken on other sources yields null (with the reason in
+    `roofline.traffic_source`), never a stale number."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/%s not found" % PMC_TRAFFIC_FILE
+    if not (S == 256 and B == 2):
+        return None, "recorded for 2 x 256^3 only"
+    if d.get("kernel_sources_sha256") != kernel_sources_sha256():
+        return None, "profiles/%s was taken on other kernel sources (stale): rerun scripts/final_profile.sh" % PMC_TRAFFIC_FILE
+    if kernel not in d.get("kernels", {}):
+        return None, "no record for %s" % kernel
+    return d["kernels"][kernel]["hbm_bytes_corrected"], "profiles/%s (rocprofv3 --pmc, same kernel sources)" % PMC_TRAFFIC_FILE
 
 
 def parse():

@@ -29,6 +29,26 @@ def _tuple(v, nd):
     return tuple(v) if isinstance(v, (tuple, list)) else (v,) * nd
 
 
+_stock_seen = set()
+
+
+def _note_stock_path(what, x, w, stride, padding):
+    """A 3-D fp32 GPU layer that leaves this package's kernels for ATen / MIOpen (a (kernel, stride, padding) outside
+    k3 s1 p1 / k4 s2 p1, or a volume beyond the kernels' 32-bit offsets -- 512^3 activations): correct, but on ROCm
+    7.2's untuned MIOpen it is the 6 s/step class of run, so say so ONCE per layer shape instead of silently."""
+    if x.dim() != 5 or not x.is_cuda or x.dtype != torch.float32:
+        return  # 2-D layers and CPU tensors are MIOpen's / ATen's by design
+    key = (what, tuple(x.shape[1:]), tuple(w.shape), tuple(stride), tuple(padding))
+    if key in _stock_seen:
+        return
+    _stock_seen.add(key)
+    import warnings
+    warnings.warn("opticalflowscivis_amd: %s of a 3-D convolution runs on stock ATen / MIOpen kernels, not on the HIP "
+                  "implicit-GEMM kernels (input %s, weight %s, stride %s, padding %s: unsupported geometry or beyond "
+                  "32-bit offsets)" % (what, tuple(x.shape), tuple(w.shape), tuple(stride), tuple(padding)),
+                  RuntimeWarning, stacklevel=3)
+
+
 _MIN_WORKGROUPS = int(os.environ.get("FLOWSCI_CONV_FWD_MIN_WG", "0"))
 _MIN_TR_POSITIONS = int(os.environ.get("FLOWSCI_CONV_TR_MIN_POS", "0"))  # input voxels (all samples)
 
@@ -70,6 +90,7 @@ def _conv_forward(x, w, b, stride, padding, transposed, prelu_weight=None):
         from . import ops
         y = ops.conv3d_tr(x, w, b, None, prelu_weight)
     elif transposed:
+        _note_stock_path("the forward", x, w, stride, padding)
         y = (F.conv_transpose3d if nd == 3 else F.conv_transpose2d)(x, w, b, stride, padding)
     elif nd == 3 and _hip_fwd_ok(x, w.shape[0], [_conv_out(n, kk, s, p) for n, kk, s, p in
                                                  zip(x.shape[2:], w.shape[2:], stride, padding)],
@@ -77,6 +98,7 @@ def _conv_forward(x, w, b, stride, padding, transposed, prelu_weight=None):
         from . import ops
         y = ops.conv3d_fwd(x, w, b, w.shape[2], stride[0], padding[0], 0, prelu_weight)
     else:
+        _note_stock_path("the forward", x, w, stride, padding)
         y = (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, padding)
     if prelu_weight is None or isinstance(y, tuple):
         return y
@@ -92,6 +114,7 @@ def _conv_grad_input(x, w, gy, stride, padding, transposed):
         if nd == 3 and _hip_fwd_ok(gy, w.shape[1], x.shape[2:], k, stride, padding):
             from . import ops  # flip + transpose happen in the kernel's weight re-layout
             return ops.conv3d_fwd(gy, w, None, k[0], 1, padding[0], 1)
+        _note_stock_path("the input gradient", gy, w, stride, padding)
         wf = w.transpose(0, 1).flip(*range(2, 2 + nd)).contiguous()
         return (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, stride, padding)
     if (transposed and nd == 3 and _hip_fwd_ok(gy, w.shape[0], x.shape[2:], k, stride, padding) and
@@ -107,6 +130,7 @@ def _conv_grad_input(x, w, gy, stride, padding, transposed):
         # weight [Cout][Cin][64] read as [in][out][64]
         from . import ops
         return ops.conv3d_tr(gy, w, None, x.shape[2:])
+    _note_stock_path("the input gradient", gy, w, stride, padding)
     return torch.ops.aten.convolution_backward(  # MIOpen backward-data
         gy, x, w, None, list(stride), list(padding), [1] * nd, transposed, [0] * nd, 1,
         [True, False, False])[0]
@@ -123,6 +147,7 @@ def _conv_grad_weight(x, w, gy, stride, padding, transposed):
         from . import ops
         if ops.conv3d_wrw_supported(k, stride, padding) and ops.conv3d_wrw_fits(src.shape[2:], g.shape[2:]):
             return ops.conv3d_wrw(g, src, k[0], stride[0], padding[0])
+    _note_stock_path("the weight gradient", x, w, stride, padding)
     return torch.ops.aten.convolution_backward(
         gy, x, w, None, list(stride), list(padding), [1] * nd, transposed, [0] * nd, 1,
         [False, True, False])[1]

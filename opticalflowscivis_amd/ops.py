@@ -1606,7 +1606,8 @@ FS_ERR_UNSUPPORTED = 5
 
 
 def _channel_planes(pieces):
-    """(pointer array, batch-stride array, Cin, keep-alive list) for fs_*_ms: every channel of every piece as the
+    """(pointer array, batch-stride array, Cin) for fs_*_ms -- two ctypes HOST arrays of Cin entries, read by the entry
+    point at launch (the caller keeps `pieces` alive across the launch) -- every channel of every piece as the
     plane it already is.  A piece is a [B, Ci, D,H,W] tensor, contiguous or a channel slice of a wider contiguous
     one; None when a piece has other strides / alignment (the caller concatenates instead)."""
     B, dhw = pieces[0].shape[0], tuple(pieces[0].shape[2:])

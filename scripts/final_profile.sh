@@ -6,7 +6,7 @@
 # Results land in gpurun_out/final/; copy what is to be judged into profiles/.
 set -e
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/final
 rm -rf $O && mkdir -p $O
 python bench.py --no-cpu-baseline > $O/bench_events.json 2> $O/bench_events.log

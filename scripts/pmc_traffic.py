@@ -14,14 +14,30 @@ kernel and are told apart by their order inside a step: teacher warp, block 2 (t
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sources_sha256():
+    """Hash of every kernel source + the C-ABI header: bench.py recomputes it and refuses a traffic file taken on
+    other kernels (the same function lives there)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "opticalflowscivis_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    for path in files + [os.path.join(ROOT, "include", "flowsci_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
 
 RULES = [  # (substring of the kernel name, entry point, counts as a launch of the entry point)
     ("conv3d_fwd_kernel", "fs_conv3d_fwd", True), ("conv3d_fwd_ws_kernel", "fs_conv3d_fwd", True),
-    ("wprep_kernel", "fs_conv3d_fwd", False),
+    ("wprep_one_kernel", "fs_conv3d_fwd", False), ("wprep_batch_kernel", "fs_conv3d_wprep_batch", True),
     ("conv3d_wrw_", "fs_conv3d_wrw", True),
-    ("convtr_", "fs_conv3d_tr", True), ("wprep_tr", "fs_conv3d_tr", False),
+    ("convtr_", "fs_conv3d_tr", True),
     ("warp3d_fwd_kernel<512, true, true>", "fs_upsample_warp3d_pair_fwd", True),
     ("warp3d_fwd_kernel<512, true, false>", "fs_warp3d_pair_fwd", True),
     ("prelu_bwd_kernel", "fs_prelu_bwd", True), ("prelu_ga_kernel", "fs_prelu_bwd", False),
@@ -78,6 +94,7 @@ def main():
     json.dump({"workload": "bench.py default: %s; per launch of the entry point, last step of each pass"
                % bench["config"]["workload"],
                "correction": "FETCH_SIZE x2 (gfx950 half-count of wide coalesced reads), WRITE_SIZE x1, KB units",
+               "kernel_sources_sha256": kernel_sources_sha256(),
                "kernels": kern}, sys.stdout, indent=1)
 
 

@@ -27,7 +27,8 @@ def test_bench_json_contract():
     assert d["value"] > 0 and abs(d["value"] - 1 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"] + 1e-9
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] in ("hbm", "mfma")
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"} <= set(rf) and rf["bound"] in ("hbm", "mfma")
+    assert rf["traffic"] is None and "256^3" in rf["traffic_source"]  # PMC traffic is recorded for the BASELINE size only
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     rh = d["roofline_hbm"]
     assert rh["bound"] == "hbm" and rh["kernel"] == "fs_warp3d_pair_bwd" and 0 < rh["frac"] < 1
