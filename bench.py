@@ -85,13 +85,13 @@ def pmc_traffic(kernel, S, B):
     run, so this is a recorded figure -- valid only for the workload AND the kernels it was taken on: the file carries
     the hash of the kernel sources, and a file taken on other sources yields null (with the reason in
     `roofline.traffic_source`), never a stale number."""
+    if not (S == 256 and B == 2):
+        return None, "recorded for 2 x 256^3 only"
     try:
         with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return None, "profiles/%s not found" % PMC_TRAFFIC_FILE
-    if not (S == 256 and B == 2):
-        return None, "recorded for 2 x 256^3 only"
     if d.get("kernel_sources_sha256") != kernel_sources_sha256():
         return None, "profiles/%s was taken on other kernel sources (stale): rerun scripts/final_profile.sh" % PMC_TRAFFIC_FILE
     if kernel not in d.get("kernels", {}):
