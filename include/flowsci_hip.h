@@ -576,8 +576,9 @@ typedef struct FsWprepJob {
   int total;      /* floats written */
   int p[6];       /* layout parameters, private to the library */
 } FsWprepJob;
-int fs_conv3d_fwd_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* w, float* ws, int Cin, int Cout, int kernel,
-                             int wmode);
+int fs_conv3d_fwd_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* x, const float* w, float* ws,
+                             int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                             int kernel, int stride, int pad, int wmode);
 int fs_conv3d_tr_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* x, const float* w, float* ws, int B, int Cin,
                             int Cout, int Di, int Hi, int Wi, int Dout, int Hout, int Wout, int has_prelu_out);
 int fs_conv3d_wprep_batch(const FsWprepJob* jobs_dev, int njobs, fs_stream_t stream);

@@ -103,7 +103,7 @@ SIGNATURES = {
     "fs_conv3d_wrw_ms": [_f32p, _ptrv, _i64p, _f32p] + [_int] * 12 + [_stream],
     "fs_wssim_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
     "fs_wssim_bwd": [_f32p] * 6 + [_int] * 5 + [_stream],
-    "fs_conv3d_fwd_wprep_jobs": [_jobp, _int, _f32p, _f32p] + [_int] * 4,
+    "fs_conv3d_fwd_wprep_jobs": [_jobp, _int, _f32p, _f32p, _f32p] + [_int] * 13,
     "fs_conv3d_tr_wprep_jobs": [_jobp, _int, _f32p, _f32p, _f32p] + [_int] * 10,
     "fs_conv3d_wprep_batch": [_f32p, _int, _stream],
     "fs_warp2d_fwd": [_f32p, _f32p, _f32p, _f32p, _int, _int, _intp, _int, _int, _int, _int, _stream],

@@ -611,6 +611,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
   }
 }
 
+#include "convwino.hpp"
+
 template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
 int launch_ws(const float* X, const float* Wt, const float* bias, float* Y, FP& p, hipStream_t st) {
   constexpr int TYR = TY * (32 / TW);
@@ -695,7 +697,9 @@ extern "C" long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel) {
   if (Cin < 1 || Cout < 1 || (kernel != 3 && kernel != 4)) return -1;
   int cinp, coutp;
   wt_dims(Cin, Cout, kernel, &cinp, &coutp);
-  return (long long)cinp * kernel * kernel * kernel * coutp;
+  const long long direct = (long long)cinp * kernel * kernel * kernel * coutp;
+  const long long wino = (kernel == 3 && coutp == 64) ? (long long)cinp * FS_WINO_UCH : 0;  // the F(2,3) slab is 4/3 larger
+  return direct > wino ? direct : wino;
 }
 
 struct DPrelu {  // fused PReLU backward of the layer that produced this convolution's (gradient) output
@@ -767,6 +771,16 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     return hipGetLastError() == hipSuccess ? FS_OK : FS_ERR_LAUNCH;
   };
   const int K3 = kernel * kernel * kernel;
+  // the 64-channel k3 layers of the 64^3 trunk: 1-D Winograd F(2,3) along x (convwino.hpp), its own filter slab
+  p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+  if (wino_ok(p, x, ws, Cin, Cout, kernel, stride, ms != nullptr) &&
+      (dp == nullptr || (bias == nullptr && z == nullptr && addend == nullptr))) {
+    wprep_do(wprep_job(FS_WPREP_WINO, w, ws, (long long)cinp * FS_WINO_UCH, Cout, Cin, cinp, wmode), plan, st);
+    if (plan != nullptr) return FS_OK;
+    const int rc = launch_wino(x, ws, bias, y, p, st);
+    if (rc != FS_OK || dp == nullptr) return rc;
+    return dp_finish(64);
+  }
   wprep_do(wprep_job(FS_WPREP_FWD, w, ws, (long long)cinp * K3 * p.CoutP, Cout, Cin, K3, cinp, p.CoutP, wmode), plan, st);
   if (plan != nullptr) return FS_OK;  // every kernel below reads the same slab
   // loader-wave kernels (k = 4: 100 / 129 TFLOP/s vs 92 / 120 for conv0a / conv0b at 256^3; k = 3: every 32-column
@@ -860,20 +874,17 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   return launch<4, 2, 2, 1, 1, 1, 4, 16>(x, ws, bias, y, p, st);
 }
 
-// The re-layout job fs_conv3d_fwd* runs for this layer (it depends on the channel counts, the kernel size and wmode
-// only): conv3d_fwd_impl's own code with `plan` set -- nothing is launched.
-extern "C" int fs_conv3d_fwd_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* w, float* ws, int Cin, int Cout,
-                                        int kernel, int wmode) {
+// The re-layout job fs_conv3d_fwd* runs for this call (the arguments of fs_conv3d_fwd; `x` is only inspected for its
+// alignment): conv3d_fwd_impl's own dispatch with `plan` set -- nothing is launched.
+extern "C" int fs_conv3d_fwd_wprep_jobs(FsWprepJob* jobs_host, int cap, const float* x, const float* w, float* ws, int B,
+                                        int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kernel,
+                                        int stride, int pad, int wmode) {
   FS_ENTER();
   if (jobs_host == nullptr || w == nullptr || ws == nullptr) return -FS_ERR_NULLPTR;
   if (cap < 0) return -FS_ERR_ARG;
-  if (!(kernel == 3 || kernel == 4)) return -FS_ERR_ARG;
   WprepPlan plan = {jobs_host, cap, 0};
-  const int stride = kernel == 3 ? 1 : 2, pad = 1, n = 8;  // any valid geometry: the layout does not depend on it
-  const int rc = conv3d_fwd_impl(nullptr, w, nullptr, nullptr, 0, nullptr, nullptr, nullptr, ws, 1, Cin, Cout, n, n, n,
-                                 (n + 2 * pad - kernel) / stride + 1, (n + 2 * pad - kernel) / stride + 1,
-                                 (n + 2 * pad - kernel) / stride + 1, kernel, stride, pad, wmode, nullptr, nullptr, nullptr,
-                                 &plan);
+  const int rc = conv3d_fwd_impl(x, w, nullptr, nullptr, 0, nullptr, nullptr, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho,
+                                 Wo, kernel, stride, pad, wmode, nullptr, nullptr, nullptr, &plan);
   return rc == FS_OK ? plan.n : -rc;
 }
 
@@ -936,7 +947,10 @@ extern "C" long long fs_conv3d_fwd_dprelu_part_floats_k3(int B, int Cout, int Do
   const long long mg64 = coutp / 64;
   const long long big = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, wide ? 8 : 16) * fs::cdiv(Wo, wide ? 32 : 16);
   const long long small = (long long)B * Do * fs::cdiv(Ho, wide ? 4 : 8) * fs::cdiv(Wo, wide ? 32 : 16);
-  const long long tiles = big * mg64 >= 512 ? big : small;  // bricks per channel group
+  long long tiles = big * mg64 >= 512 ? big : small;  // bricks per channel group
+  // the Winograd kernel's bricks (2 x 2 x 64) where it applies: twice as many as the direct kernel's big bricks
+  const long long wino = (long long)B * fs::cdiv(Do, 2) * fs::cdiv(Ho, 2) * fs::cdiv(Wo, 64);
+  if (coutp == 64 && wino > tiles) tiles = wino;
   // rows = 4 per brick and channel group; a row holds the group's channels x 2: coutp x 2 floats per brick row in total
   return tiles * 4 * coutp * 2 + 2 + (long long)kFinishBlocks * coutp * 2 * 2;
 }

@@ -12,7 +12,10 @@
 //       (`w` may point at a 32-channel slice of a [Cin][CoutT][64] tensor)            (convtr.hip)
 //   FS_WPREP_TR16 p = {Cin, Cout, CinP}                     Wt[ci][tap][co 0..15]
 //   FS_WPREP_P8   p = {Cin, Cout, CinP, RT}                 W'[ci][neighbour][row] (+16 pad) of the all-parities kernel
-enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3 };
+//   FS_WPREP_WINO p = {Cout, Cin, CinP, mode}              Ut[ci][kz*3+ky][t 0..3][co 0..63] (+16 pad per ci): the F(2,3)
+//       filter transform along kx of the taps FS_WPREP_FWD would deliver (same two modes)          (convwino.hpp)
+enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4 };
+constexpr int FS_WINO_UCH = 9 * 4 * 64 + 16;  // floats per input channel of the Winograd slab (== WN_UCH)
 
 __host__ __device__ constexpr int wprep_p8_k(int par, int d) { return par == 0 ? (d == 0 ? 1 : 3) : (d == 0 ? 0 : 2); }
 
@@ -36,6 +39,18 @@ __device__ __forceinline__ float wprep_elem(const FsWprepJob& j, int e) {
       const int Cin = j.p[0], Cout = j.p[1];
       const int co = e & 15, tap = (e >> 4) & 63, ci = e >> 10;
       return (co < Cout && ci < Cin) ? w[((size_t)ci * Cout + co) * 64 + tap] : 0.f;
+    }
+    case FS_WPREP_WINO: {
+      const int Cout = j.p[0], Cin = j.p[1], mode = j.p[3];
+      const int ci = e / FS_WINO_UCH, i = e - ci * FS_WINO_UCH;
+      if (i >= 9 * 4 * 64 || ci >= Cin) return 0.f;
+      const int kk = i >> 8, tt = (i >> 6) & 3, co = i & 63;
+      if (co >= Cout) return 0.f;
+      float g[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        g[kx] = mode ? w[((size_t)ci * Cout + co) * 27 + (26 - (kk * 3 + kx))] : w[((size_t)co * Cin + ci) * 27 + kk * 3 + kx];
+      return tt == 0 ? g[0] : tt == 1 ? 0.5f * ((g[0] + g[1]) + g[2]) : tt == 2 ? 0.5f * ((g[0] - g[1]) + g[2]) : g[2];
     }
     default: {  // FS_WPREP_P8
       const int Cin = j.p[0], Cout = j.p[1], RT = j.p[3];

@@ -1553,11 +1553,14 @@ def _prepared(w, nfloats, key, plan):
     return 0, e.ws
 
 
-def _prepared_fwd(w, Cin, Cout, k, wmode):
+def _prepared_fwd(w, xptr, B, Cin, Cout, in_dhw, out_dhw, k, stride, pad, wmode):
+    """Slab of fs_conv3d_fwd* for this call: which layout (direct taps, or the Winograd-transformed filter of the
+    64-channel k3 trunk layers) is the library's decision for the call's geometry."""
     L = _lib.lib()
-    return _prepared(w, L.fs_conv3d_fwd_ws_floats(Cin, Cout, int(k)), ("fwd", Cin, Cout, int(k), int(wmode)),
-                     lambda jobs, cap, ws: L.fs_conv3d_fwd_wprep_jobs(jobs, cap, w.data_ptr(), ws.data_ptr(), Cin, Cout,
-                                                                     int(k), int(wmode)))
+    geo = (B, Cin, Cout) + tuple(int(v) for v in in_dhw) + tuple(int(v) for v in out_dhw) + (int(k), int(stride), int(pad),
+                                                                                          int(wmode))
+    return _prepared(w, L.fs_conv3d_fwd_ws_floats(Cin, Cout, int(k)), ("fwd", xptr % 16) + geo,
+                     lambda jobs, cap, ws: L.fs_conv3d_fwd_wprep_jobs(jobs, cap, xptr, w.data_ptr(), ws.data_ptr(), *geo))
 
 
 def conv3d_wrw_supported(k, stride, padding):
@@ -1651,7 +1654,7 @@ def conv3d_fwd_prelu_ms(pieces, w, bias, prelu_weight, k, stride, pad):
         return None
     y = x0.new_empty((B, Cout, Do, Ho, Wo))
     z = torch.empty_like(y)
-    wp, ws = _prepared_fwd(w, Cin, Cout, k, 0)
+    wp, ws = _prepared_fwd(w, x0.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), (Do, Ho, Wo), k, stride, pad, 0)
     xbytes = 4 * B * Cin * Di * Hi * Wi
     with torch.cuda.device(x0.device):
         rc = _call_rc("fs_conv3d_fwd_prelu_ms", pv, sv, wp, _ptr(bias), a.data_ptr(), y.data_ptr(), z.data_ptr(),
@@ -1708,7 +1711,7 @@ def conv3d_deconv_grad_input_dprelu(gy, w, act_y, prelu_weight):
     out = torch.empty_like(act_y)
     ga, gb = torch.empty_like(a), act_y.new_empty(Cin_t)
     part = act_y.new_empty(npart)
-    wp, ws = _prepared_fwd(w, Cg, Cin_t, 4, 0)
+    wp, ws = _prepared_fwd(w, gy.data_ptr(), B, Cg, Cin_t, (Di, Hi, Wi), (Do, Ho, Wo), 4, 2, 1, 0)
     nb = 4 * (gy.numel() + 2 * out.numel())
     fl = 2 * out.numel() * Cg * 64
     with torch.cuda.device(gy.device):
@@ -1752,7 +1755,7 @@ def conv3d_k3_grad_input_dprelu(gy, w, act_y, prelu_weight):
     out = torch.empty_like(act_y)
     ga, gb = torch.empty_like(a), act_y.new_empty(Cx)
     part = act_y.new_empty(npart)
-    wp, ws = _prepared_fwd(w, Cg, Cx, 3, 1)
+    wp, ws = _prepared_fwd(w, gy.data_ptr(), B, Cg, Cx, (D, H, W), (D, H, W), 3, 1, 1, 1)
     with torch.cuda.device(gy.device):
         rc = _call_rc("fs_conv3d_fwd_dprelu", gy.data_ptr(), wp, act_y.data_ptr(), a.data_ptr(), a.numel(),
                       out.data_ptr(), ga.data_ptr(), gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, Cg, Cx, D, H, W,
@@ -1806,7 +1809,7 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
     if min(Do, Ho, Wo) < 1:
         raise ValueError("convolution output is empty for input %s" % (tuple(x.shape),))
     y = x.new_empty((B, Cout, Do, Ho, Wo))
-    wp, ws = _prepared_fwd(w, Cin, Cout, k, wmode)
+    wp, ws = _prepared_fwd(w, x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), (Do, Ho, Wo), k, stride, pad, wmode)
     nb, fl = 4 * (x.numel() + y.numel()), 2 * y.numel() * Cin * int(k) ** 3
     if addend is not None:
         addend = _need_cuda_f32("addend", addend, 5)

@@ -97,12 +97,19 @@ def test_weight_relayout_plans_without_gpu():
     L = _lib.lib()
     buf = (_lib.FsWprepJob * 4)()
     assert ctypes.sizeof(_lib.FsWprepJob) == 48
-    n = L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000, 0x2000, 64, 64, 3, 1)
-    assert n == 1 and buf[0].w == 0x1000 and buf[0].ws == 0x2000 and buf[0].total == L.fs_conv3d_fwd_ws_floats(64, 64, 3)
-    n = L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000, 0x2000, 11, 32, 4, 0)
-    assert n == 1 and buf[0].total == L.fs_conv3d_fwd_ws_floats(11, 32, 4) == 12 * 64 * 32
-    assert L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000, 0x2000, 8, 8, 5, 0) == -3          # -FS_ERR_ARG
-    assert L.fs_conv3d_fwd_wprep_jobs(buf, 4, None, 0x2000, 8, 8, 3, 0) == -1            # -FS_ERR_NULLPTR
+    fwd = lambda cin, cout, n, k, wmode, x=0x4000, w=0x1000: L.fs_conv3d_fwd_wprep_jobs(
+        buf, 4, x, w, 0x2000, 2, cin, cout, n, n, n, n if k == 3 else n // 2, n if k == 3 else n // 2,
+        n if k == 3 else n // 2, k, 1 if k == 3 else 2, 1, wmode)
+    # the 64-channel k3 layers of the 64^3 trunk take the Winograd-transformed filter (kind 4), in both weight modes
+    for wmode in (0, 1):
+        assert fwd(64, 64, 64, 3, wmode) == 1 and buf[0].kind == 4 and buf[0].w == 0x1000 and buf[0].ws == 0x2000
+        assert buf[0].total == 64 * (9 * 4 * 64 + 16) == L.fs_conv3d_fwd_ws_floats(64, 64, 3)
+    # ... not at 32^3 (rows of 32), not from a misaligned input: the direct taps (kind 0)
+    assert fwd(64, 64, 32, 3, 0) == 1 and buf[0].kind == 0 and buf[0].total == 64 * 27 * 64
+    assert fwd(64, 64, 64, 3, 0, x=0x4004) == 1 and buf[0].kind == 0
+    assert fwd(11, 32, 64, 4, 0) == 1 and buf[0].kind == 0 and buf[0].total == L.fs_conv3d_fwd_ws_floats(11, 32, 4) == 12 * 64 * 32
+    assert L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 1, 8, 8, 8, 8, 8, 4, 4, 4, 5, 1, 2, 0) == -3   # -FS_ERR_ARG
+    assert fwd(8, 8, 8, 3, 0, w=None) == -1                                                                          # -FS_ERR_NULLPTR
     kinds = {}
     for cin, cout, di, z in ((64, 32, 64, 0), (32, 6, 128, 0), (32, 1, 128, 0), (32, 11, 128, 0), (128, 64, 16, 0),
                              (32, 6, 128, 1), (5, 3, 9, 0)):

@@ -1,0 +1,99 @@
+"""-m gpu: the 1-D Winograd F(2,3) form of the 64-channel k3 trunk convolutions (csrc/convwino.hpp) against fp64:
+every fused epilogue (bias, PReLU output + residual addend, plain addend, the PReLU-backward form), both weight modes
+(forward taps / flipped + transposed for the input gradient), volume edges that are not multiples of the 2 x 2 brick,
+channel counts below the 64-row tile.  The transform's coefficients are +-1 and 1/2: the error against fp64 stays
+within 2x the direct kernel's bound (3e-5 of the output's magnitude)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 6e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from opticalflowscivis_amd import ops as o
+    return o
+
+
+def _is_wino(ops, x, w, cin, cout, size, wmode):
+    """The library's own dispatch: does this call take the Winograd slab (FsWprepJob kind 4)?"""
+    from opticalflowscivis_amd import _lib
+    L = _lib.lib()
+    buf = (_lib.FsWprepJob * 4)()
+    ws = torch.empty(int(L.fs_conv3d_fwd_ws_floats(cin, cout, 3)), device=DEV)
+    n = L.fs_conv3d_fwd_wprep_jobs(buf, 4, x.data_ptr(), w.data_ptr(), ws.data_ptr(), x.shape[0], cin, cout, *size, *size,
+                                   3, 1, 1, wmode)
+    return n == 1 and buf[0].kind == 4
+
+
+@pytest.mark.parametrize("B,cin,cout,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (33, 31, 64)), (2, 8, 20, (32, 32, 64)),
+                                             (1, 64, 64, (16, 32, 128)), (2, 12, 64, (64, 64, 64))])
+def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
+    g = torch.Generator().manual_seed(cin * 100 + size[0])
+    x = torch.randn((B, cin) + size, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    assert _is_wino(ops, xd, wd, cin, cout, size, 0)
+    ref = F.conv3d(x.double(), w.double(), b.double(), 1, 1)
+    scale = float(ref.abs().max())
+    got = ops.conv3d_fwd(xd, wd, bd, 3, 1, 1, 0)
+    assert float((got.cpu().double() - ref).abs().max()) < TOL * scale
+    # no bias
+    got = ops.conv3d_fwd(xd, wd, None, 3, 1, 1, 0)
+    assert float((got.cpu().double() - (ref - b.double().view(1, -1, 1, 1, 1))).abs().max()) < TOL * scale
+    # PReLU output + residual addend (conv2 of a residual unit), per-channel and shared slope
+    add = torch.randn(ref.shape, generator=g)
+    for slope in (torch.rand(cout, generator=g) - 0.3, torch.tensor([0.2])):
+        y, z = ops.conv3d_fwd(xd, wd, bd, 3, 1, 1, 0, prelu_weight=slope.to(DEV), addend=add.to(DEV))
+        zr = F.prelu(ref, slope.double()) + add.double()
+        assert float((y.cpu().double() - ref).abs().max()) < TOL * scale
+        assert float((z.cpu().double() - zr).abs().max()) < TOL * max(scale, float(zr.abs().max()))
+    # plain addend (the skip gradient of conv1's input gradient)
+    got = ops.conv3d_fwd(xd, wd, bd, 3, 1, 1, 0, addend=add.to(DEV))
+    assert float((got.cpu().double() - (ref + add.double())).abs().max()) < TOL * max(scale, float((ref + add.double()).abs().max()))
+
+
+@pytest.mark.parametrize("B,cg,cx,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (21, 34, 64)), (2, 64, 32, (32, 32, 64))])
+def test_wino_input_gradient_and_prelu_backward_vs_fp64(ops, B, cg, cx, size):
+    """wmode 1: the layer weight [Cout_layer = cg][Cin_layer = cx] read flipped + transposed; and the same convolution
+    with the PReLU backward as its epilogue (fs_conv3d_fwd_dprelu, kernel 3)."""
+    g = torch.Generator().manual_seed(cg + cx + size[1])
+    gy = torch.randn((B, cg) + size, generator=g)
+    w = torch.randn(cg, cx, 3, 3, 3, generator=g) / (cg * 27) ** 0.5
+    gyd, wd = gy.to(DEV), w.to(DEV)
+    assert _is_wino(ops, gyd, wd, cg, cx, size, 1)
+    ref = F.conv3d(gy.double(), w.transpose(0, 1).flip(2, 3, 4).double(), None, 1, 1)
+    scale = float(ref.abs().max())
+    got = ops.conv3d_fwd(gyd, wd, None, 3, 1, 1, 1)
+    assert float((got.cpu().double() - ref).abs().max()) < TOL * scale
+    act = torch.randn(ref.shape, generator=g)
+    for slope in (torch.rand(cx, generator=g) - 0.3, torch.tensor([0.25])):
+        fused = ops.conv3d_k3_grad_input_dprelu(gyd, wd, act.to(DEV), slope.to(DEV))
+        assert fused is not None
+        sl = slope.double().view(1, -1, 1, 1, 1) if slope.numel() > 1 else slope.double()
+        neg = act.double() <= 0
+        gx = torch.where(neg, sl * ref, ref)
+        ga = torch.where(neg, act.double() * ref, torch.zeros_like(ref))
+        ga = ga.sum((0, 2, 3, 4)) if slope.numel() > 1 else ga.sum().view(1)
+        gb = gx.sum((0, 2, 3, 4))
+        assert torch.equal(fused[0], torch.where(act.to(DEV) > 0, got, slope.to(DEV).view(1, -1, 1, 1, 1) * got)
+                           if slope.numel() > 1 else torch.where(act.to(DEV) > 0, got, slope.to(DEV) * got))
+        assert float((fused[0].cpu().double() - gx).abs().max()) < TOL * scale
+        n = float(ref.numel() / cx) ** 0.5
+        assert float((fused[1].cpu().double() - ga).abs().max()) < 2e-5 * max(1.0, float(ga.abs().max())) + 1e-5 * n * scale
+        assert float((fused[2].cpu().double() - gb).abs().max()) < 2e-5 * max(1.0, float(gb.abs().max())) + 1e-5 * n * scale
+
+
+def test_wino_is_not_taken_where_it_does_not_apply(ops):
+    x = torch.randn(2, 64, 32, 32, 32, device=DEV)   # rows of 32
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV)
+    assert not _is_wino(ops, x, w, 64, 64, (32, 32, 32), 0)
+    x = torch.randn(1, 64, 8, 8, 64, device=DEV)     # too few bricks to fill the chip
+    assert not _is_wino(ops, x, w, 64, 64, (8, 8, 64), 0)
+    w = torch.randn(128, 64, 3, 3, 3, device=DEV)    # more than one 64-channel group
+    x = torch.randn(2, 64, 32, 32, 64, device=DEV)
+    assert not _is_wino(ops, x, w, 64, 128, (32, 32, 64), 0)
