@@ -454,7 +454,7 @@ def main():
         if rank == 0:
             log("warm-up step %d done" % i)
     wt = ops.kernel_timings()
-    dom_guess = max(wt, key=lambda k: sum(r[0] for r in wt[k])) if wt else None
+    dom_guess = max(wt, key=lambda k: sum(r[0] for r in wt[k])) if wt else None  # (a convolution entry point)
     barrier()
     # timed region: only the dominant entry point's launches carry events (~90 of ~600 launches per step), so
     # the headline time is free of profiling overhead while `roofline` is still measured inside the region

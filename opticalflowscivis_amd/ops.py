@@ -1546,6 +1546,10 @@ def _prepared(w, nfloats, key, plan):
         e.jobs = [_lib.FsWprepJob.from_buffer_copy(buf[i]) for i in range(n)]
         tab.entries[k] = e
         tab.dirty = True
+        # first use: the convolution re-lays the weights into the (now persistent) slab itself, as the classic path does;
+        # from the next stale epoch on the slab is part of the device's one batch launch
+        e.stamp = (w._version, _prep_epoch)
+        return w.data_ptr(), e.ws
     if not e.jobs:  # this shape's kernel reads the weights as stored
         return w.data_ptr(), e.ws
     if e.stamp != (w._version, _prep_epoch):
