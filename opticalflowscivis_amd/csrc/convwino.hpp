@@ -30,7 +30,7 @@ constexpr int WN_VCH = 16 * WN_ROWF + 16;       // channel pitch of V (4 x 4 sta
 constexpr int WN_UCH = 9 * 4 * 64 + 16;         // channel pitch of U ([kz*3+ky][t][co], + the same pad)
 
 template <int CI>
-__global__ __launch_bounds__(512, 1) void conv3d_wino_ws_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(const float* __restrict__ X,
                                                                const float* __restrict__ Ut,
                                                                const float* __restrict__ bias,
                                                                float* __restrict__ Y, FP p) {
@@ -296,7 +296,11 @@ inline int launch_wino(const float* X, const float* Ut, const float* bias, float
   p.tz = fs::cdiv(p.Do, 2); p.ty = fs::cdiv(p.Ho, 2); p.tx = p.Wo / 64;
   p.tiles = (long long)p.B * p.tz * p.ty * p.tx;
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
-  hipLaunchKernelGGL((conv3d_wino_ws_kernel<4>), dim3((unsigned)p.tiles, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
+  // FLOWSCI_WINO_CI=2: 2-channel chunks, 70 KB of LDS, two workgroups per CU (A/B switch; 4-channel chunks with one
+  // workgroup per CU are the default)
+  static const bool ci2 = getenv("FLOWSCI_WINO_CI") != nullptr && atoi(getenv("FLOWSCI_WINO_CI")) == 2;
+  if (ci2) hipLaunchKernelGGL((conv3d_wino_ws_kernel<2>), dim3((unsigned)p.tiles, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
+  else hipLaunchKernelGGL((conv3d_wino_ws_kernel<4>), dim3((unsigned)p.tiles, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -30,7 +30,7 @@ def _is_wino(ops, x, w, cin, cout, size, wmode):
 
 
 @pytest.mark.parametrize("B,cin,cout,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (33, 31, 64)), (2, 8, 20, (32, 32, 64)),
-                                             (1, 64, 64, (16, 32, 128)), (2, 12, 64, (64, 64, 64))])
+                                             (2, 64, 64, (16, 32, 128)), (2, 12, 64, (64, 64, 64))])
 def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
     g = torch.Generator().manual_seed(cin * 100 + size[0])
     x = torch.randn((B, cin) + size, generator=g)
