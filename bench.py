@@ -55,9 +55,15 @@ def roofline(dom, k, S, B):
     other kernel against HBM."""
     traffic, src = pmc_traffic(dom, S, B)
     if "TFLOPps" in k and dom in ("fs_conv3d_wrw", "fs_conv3d_fwd", "fs_conv3d_tr"):
-        return {"bound": "mfma", "kernel": dom, "achieved": k["TFLOPps"], "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(k["TFLOPps"] / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": src}
+        rec = {"bound": "mfma", "kernel": dom, "achieved": k["TFLOPps"], "peak": MFMA_F32_PEAK_TFLOPS,
+               "unit": "TFLOP/s", "frac": round(k["TFLOPps"] / MFMA_F32_PEAK_TFLOPS, 4),
+               "traffic": traffic, "traffic_source": src}
+        if "TFLOPps_direct_equivalent" in k:
+            # `achieved` counts the multiply-adds the matrix cores EXECUTE; the 64-channel k3 layers run a Winograd
+            # F(2,3) form with 2/3 of the direct convolution's multiply-adds, so the useful (direct-equivalent) rate
+            # is higher than the executed one
+            rec["direct_equivalent_TFLOPps"] = k["TFLOPps_direct_equivalent"]
+        return rec
     return {"bound": "hbm", "kernel": dom, "achieved": k["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(k["algo_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src}
 
@@ -513,24 +519,31 @@ def main():
         for name, recs in ktimes.items():
             tot_ms = sum(r[0] for r in recs)
             tot_b = sum(r[1] for r in recs)
-            tot_f = sum(r[2] for r in recs)
+            tot_f, tot_q = sum(r[2] for r in recs), sum(r[3] for r in recs)
             kern[name] = {"launches": len(recs), "avg_ms": round(tot_ms / len(recs), 4),
                           "ms_per_step": round(tot_ms / ksteps, 3),
                           "algo_GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
             if tot_f:
+                # TFLOPps: matrix-core flops EXECUTED per second (what the MFMA roofline is about); the Winograd
+                # convolutions execute 2/3 of the direct formulation's flops -- the direct-equivalent rate is the
+                # useful work per second and may exceed the MFMA peak
                 kern[name]["TFLOPps"] = round(tot_f / (tot_ms * 1e-3) / 1e12, 2)
+                if tot_q != tot_f:
+                    kern[name]["TFLOPps_direct_equivalent"] = round(tot_q / (tot_ms * 1e-3) / 1e12, 2)
         # dominant hand-written kernel = the one with the largest total time; its roofline record comes from
         # the events recorded inside the timed region when it is the entry point that was followed there
         dom = max(ktimes, key=lambda k: sum(r[0] for r in ktimes[k]))
         dom_rec, dom_src = kern[dom], "HIP events, separate pass of %d steps after the timed region" % ksteps
         if dom in timed and timed[dom]:
             recs = timed[dom]
-            tot_ms, tot_b, tot_f = (sum(r[i] for r in recs) for i in range(3))
+            tot_ms, tot_b, tot_f, tot_q = (sum(r[i] for r in recs) for i in range(4))
             dom_rec = {"launches": len(recs), "avg_ms": round(tot_ms / len(recs), 4),
                        "ms_per_step": round(tot_ms / args.steps, 3),
                        "algo_GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
             if tot_f:
                 dom_rec["TFLOPps"] = round(tot_f / (tot_ms * 1e-3) / 1e12, 2)
+                if tot_q != tot_f:
+                    dom_rec["TFLOPps_direct_equivalent"] = round(tot_q / (tot_ms * 1e-3) / 1e12, 2)
             dom_src = "HIP events on the launch stream inside the timed region (%d launches)" % len(recs)
         out = {
             "metric": "volume-pairs/sec, Flow-3D unsupervised train step (fwd+loss+bwd+AdamW)",

@@ -68,14 +68,15 @@ def enable_kernel_timing(on=True, only=None):
 
 
 def kernel_timings():
-    """{entry point: [(ms, algorithmic HBM bytes, flops) per launch]} recorded so far (synchronises)."""
+    """{entry point: [(ms, algorithmic HBM bytes, matrix-core flops EXECUTED, flops of the direct formulation) per
+    launch]} recorded so far (synchronises).  The two flop counts differ for the Winograd convolutions only (2/3)."""
     if _timing is None:
         return {}
     torch.cuda.synchronize()
-    return {k: [(a.elapsed_time(b), nb, fl) for a, b, nb, fl in v] for k, v in _timing.items()}
+    return {k: [(a.elapsed_time(b), nb, fl, fe) for a, b, nb, fl, fe in v] for k, v in _timing.items()}
 
 
-def _call(name, *args, algo_bytes=0, algo_flops=0, record_as=None):
+def _call(name, *args, algo_bytes=0, algo_flops=0, record_as=None, equiv_flops=None):
     """Launch a C-ABI entry point.  `algo_bytes` / `algo_flops` = compulsory HBM bytes / useful flops of
     this launch, only used by the optional timing records (`record_as`: file the record
     under another entry point's name -- the *_prelu variants are the same kernels with one more store)."""
@@ -89,10 +90,11 @@ def _call(name, *args, algo_bytes=0, algo_flops=0, record_as=None):
     code = fn(*args)
     e1.record()
     _lib.check(code, name)
-    _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops))
+    _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops,
+                                                      algo_flops if equiv_flops is None else equiv_flops))
 
 
-def _call_rc(name, *args, algo_bytes=0, algo_flops=0, record_as=None, allow=()):
+def _call_rc(name, *args, algo_bytes=0, algo_flops=0, record_as=None, allow=(), equiv_flops=None):
     """_call for entry points that may answer with a status in `allow` (FS_ERR_UNSUPPORTED: "no such kernel for
     this shape, take the unfused path"): returns the status instead of raising on those."""
     fn = getattr(_lib.lib(), name)
@@ -104,7 +106,8 @@ def _call_rc(name, *args, algo_bytes=0, algo_flops=0, record_as=None, allow=()):
     if timed:
         e1.record()
         if rc == 0:
-            _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops))
+            _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops,
+                                                              algo_flops if equiv_flops is None else equiv_flops))
     if rc not in allow:
         _lib.check(rc, name)
     return rc
@@ -1557,6 +1560,22 @@ def _prepared(w, nfloats, key, plan):
     return 0, e.ws
 
 
+_wino_seen = {}
+
+
+def _fwd_takes_winograd(xptr, B, Cin, Cout, dhw, wmode):
+    """Does fs_conv3d_fwd* run this k3 s1 p1 call as the 1-D Winograd F(2,3) kernel (csrc/convwino.hpp)?  Asked of
+    the library's own dispatch (its re-layout plan), cached per geometry; only the flop accounting of the timing
+    records depends on it: that kernel EXECUTES 2/3 of the direct formulation's multiply-adds."""
+    key = (xptr % 16, B, Cin, Cout) + tuple(int(v) for v in dhw) + (int(wmode),)
+    if key not in _wino_seen:
+        buf = (_lib.FsWprepJob * 4)()
+        n = _lib.lib().fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000 + xptr % 16, 0x1000, 0x1000, B, Cin, Cout, *key[4:7],
+                                                *key[4:7], 3, 1, 1, int(wmode))
+        _wino_seen[key] = (n == 1 and buf[0].kind == 4)
+    return _wino_seen[key]
+
+
 def _prepared_fwd(w, xptr, B, Cin, Cout, in_dhw, out_dhw, k, stride, pad, wmode):
     """Slab of fs_conv3d_fwd* for this call: which layout (direct taps, or the Winograd-transformed filter of the
     64-channel k3 trunk layers) is the library's decision for the call's geometry."""
@@ -1729,7 +1748,7 @@ def conv3d_deconv_grad_input_dprelu(gy, w, act_y, prelu_weight):
             rc = L.fs_conv3d_fwd_dprelu(*args)
             e1.record()
             if rc == 0:
-                _timing.setdefault("fs_conv3d_fwd", []).append((e0, e1, nb, fl))
+                _timing.setdefault("fs_conv3d_fwd", []).append((e0, e1, nb, fl, fl))
     if rc == FS_ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "fs_conv3d_fwd_dprelu")
@@ -1764,7 +1783,8 @@ def conv3d_k3_grad_input_dprelu(gy, w, act_y, prelu_weight):
         rc = _call_rc("fs_conv3d_fwd_dprelu", gy.data_ptr(), wp, act_y.data_ptr(), a.data_ptr(), a.numel(),
                       out.data_ptr(), ga.data_ptr(), gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, Cg, Cx, D, H, W,
                       D, H, W, 3, 1, 1, _stream(gy), algo_bytes=4 * (gy.numel() + 2 * out.numel()),
-                      algo_flops=2 * out.numel() * Cg * 27, record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
+                      algo_flops=2 * out.numel() * Cg * (18 if _fwd_takes_winograd(gy.data_ptr(), B, Cg, Cx, (D, H, W), 1) else 27),
+                      equiv_flops=2 * out.numel() * Cg * 27, record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
     if rc == FS_ERR_UNSUPPORTED:
         return None
     return out, ga, gb
@@ -1814,7 +1834,9 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
         raise ValueError("convolution output is empty for input %s" % (tuple(x.shape),))
     y = x.new_empty((B, Cout, Do, Ho, Wo))
     wp, ws = _prepared_fwd(w, x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), (Do, Ho, Wo), k, stride, pad, wmode)
-    nb, fl = 4 * (x.numel() + y.numel()), 2 * y.numel() * Cin * int(k) ** 3
+    nb, fq = 4 * (x.numel() + y.numel()), 2 * y.numel() * Cin * int(k) ** 3
+    fl = fq * 2 // 3 if (int(k) == 3 and int(stride) == 1 and int(pad) == 1 and
+                         _fwd_takes_winograd(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), wmode)) else fq
     if addend is not None:
         addend = _need_cuda_f32("addend", addend, 5)
         if addend.shape != y.shape:
@@ -1824,12 +1846,12 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
         if prelu_weight is None and addend is not None:
             _call("fs_conv3d_fwd_add", x.data_ptr(), wp, _ptr(bias), addend.data_ptr(), y.data_ptr(),
                   ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode),
-                  _stream(x), algo_bytes=nb, algo_flops=fl, record_as="fs_conv3d_fwd")
+                  _stream(x), algo_bytes=nb, algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_fwd")
             return y
         if prelu_weight is None:
             _call("fs_conv3d_fwd", x.data_ptr(), wp, _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
                   Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode), _stream(x),
-                  algo_bytes=nb, algo_flops=fl)
+                  algo_bytes=nb, algo_flops=fl, equiv_flops=fq)
             return y
         if wmode:
             raise ValueError("the fused PReLU epilogue is forward-only (wmode 0)")
@@ -1840,7 +1862,7 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
         _call("fs_conv3d_fwd_prelu", x.data_ptr(), wp, _ptr(bias), a.data_ptr(), _ptr(addend),
               y.data_ptr(), z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride),
               int(pad),
-              a.numel(), _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_fwd")
+              a.numel(), _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_fwd")
     return y, z
 
 
