@@ -21,6 +21,9 @@
 //     LDS as V[ci][staged row][t][x-tile]: wave w stages staged-z row w of every channel (4 y rows x 16 lanes).
 //   matrix waves 0-3: one output row each (4 transformed accumulator sets x 2 channel tiles = 8 MFMA tiles, as
 //     many as the direct kernel holds); both MFMA operands are "lane base + immediate" LDS reads.
+//   Workgroups are persistent: 256 of them (one per CU, contiguous brick ranges per XCD) walk their bricks, and the
+//     loaders run one chunk ahead ACROSS brick boundaries, so a brick's first loads fly under the previous brick's
+//     last MFMA phase and its epilogue.
 //   epilogue: output transform in registers, one DPP swap between neighbouring x-tiles so that a lane holds 4
 //     consecutive x of one channel, then the same fused epilogues as the direct kernel (bias, PReLU output, residual
 //     addend; or the PReLU-backward form with its per-wave partial sums).
@@ -45,27 +48,23 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wv = wave & 3;
 
-  long long tile = blockIdx.x;
-  {
-    const long long per = p.tiles / 8;
-    if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);  // contiguous brick ranges per XCD
-  }
-  const int txi = (int)(tile % p.tx); tile /= p.tx;
-  const int tyi = (int)(tile % p.ty); tile /= p.ty;
-  const int tzi = (int)(tile % p.tz);
-  const int b = (int)(tile / p.tz);
-  const int oz0 = tzi * 2, oy0 = tyi * 2, ox0 = txi * 64;
+  // this workgroup's bricks: a contiguous range, and consecutive ranges on one XCD (workgroups are dealt to the 8
+  // XCDs round-robin): neighbouring bricks share halo rows in that XCD's L2
+  const int nwg = gridDim.x;
+  const long long ord = (long long)(blockIdx.x & 7) * (nwg / 8) + (blockIdx.x >> 3);
+  const long long br0 = ord * p.tiles / nwg, br1 = (ord + 1) * p.tiles / nwg;
+  auto decode = [&](long long tile, int& b, int& oz0, int& oy0, int& ox0) {
+    const int txi = (int)(tile % p.tx); tile /= p.tx;
+    const int tyi = (int)(tile % p.ty); tile /= p.ty;
+    const int tzi = (int)(tile % p.tz);
+    b = (int)(tile / p.tz);
+    oz0 = tzi * 2; oy0 = tyi * 2; ox0 = txi * 64;
+  };
   const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
 
   if (wave >= 4) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int yr = lane >> 4, q = lane & 15;
-    const int gz = oz0 - 1 + wv, gy = oy0 - 1 + yr, gx = ox0 + 4 * q;
-    const bool rowok = gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
-    const unsigned rbase = ((unsigned)(rowok ? gz : 0) * p.Hi + (rowok ? gy : 0)) * p.Wi;
-    const unsigned voff = (rowok && gx < p.Wi) ? (rbase + gx) * 4u : DMA_OOB;   // Wi % 64 == 0: a float4 is in or out whole
-    const int hx = q == 0 ? ox0 - 1 : ox0 + 64;
-    const unsigned hoff = (rowok && (q == 0 || q == 15) && hx >= 0 && hx < p.Wi) ? (rbase + hx) * 4u : DMA_OOB;
     unsigned uoff[NUW];
 #pragma unroll
     for (int k = 0; k < NUW; ++k) {
@@ -73,6 +72,18 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
       uoff[k] = piece < NU / 4 ? (unsigned)piece * 16u : DMA_OOB;
     }
     const int vdst = (wv * 4 + yr) * WN_ROWF + 2 * q;
+    int b = 0;
+    unsigned voff = DMA_OOB, hoff = DMA_OOB;
+    auto place = [&](long long brick) {  // this lane's row of the brick: offsets inside a channel volume
+      int oz0, oy0, ox0;
+      decode(brick, b, oz0, oy0, ox0);
+      const int gz = oz0 - 1 + wv, gy = oy0 - 1 + yr, gx = ox0 + 4 * q;
+      const bool rowok = gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
+      const unsigned rbase = ((unsigned)(rowok ? gz : 0) * p.Hi + (rowok ? gy : 0)) * p.Wi;
+      voff = (rowok && gx < p.Wi) ? (rbase + gx) * 4u : DMA_OOB;   // Wi % 64 == 0: a float4 is in or out whole
+      const int hx = q == 0 ? ox0 - 1 : ox0 + 64;
+      hoff = (rowok && (q == 0 || q == 15) && hx >= 0 && hx < p.Wi) ? (rbase + hx) * 4u : DMA_OOB;
+    };
     float xa[CI], xb[CI], xc[CI], xd[CI], xh[CI];
     auto fetch = [&](int c0) {
 #pragma unroll
@@ -109,24 +120,31 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
         *reinterpret_cast<float2*>(dst + 3 * 32) = make_float2(xa[c] - xc[c], xc[c] - Rr);
       }
     };
-    fetch(0);
-    dma_u(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    put(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto stage = [&](int c0, int buf) {
+      fetch(c0);
+      dma_u(c0, buf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      put(buf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if (br0 < br1) {
+      place(br0);
+      stage(0, 0);
+    }
     __builtin_amdgcn_s_barrier();
     int buf = 0;
-    for (int c0 = 0; c0 < p.Cin; c0 += CI) {
-      if (c0 + CI < p.Cin) {
-        fetch(c0 + CI);
-        dma_u(c0 + CI, buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        put(buf ^ 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (long long brick = br0; brick < br1; ++brick)
+      for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+        // the chunk after this one: the same brick's next channels, or the next brick's first
+        if (c0 + CI < p.Cin) {
+          stage(c0 + CI, buf ^ 1);
+        } else if (brick + 1 < br1) {
+          place(brick + 1);
+          stage(0, buf ^ 1);
+        }
+        __builtin_amdgcn_s_barrier();  // that chunk is in LDS; the matrix waves are done reading `buf`
+        buf ^= 1;
       }
-      __builtin_amdgcn_s_barrier();  // the next chunk is in LDS; the matrix waves are done reading `buf`
-      buf ^= 1;
-    }
 #else
     (void)xvol; (void)NUW;
 #endif
@@ -140,6 +158,9 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
   const int aBo = NV + kh * (CI / 2) * WN_UCH + col;
   constexpr int NP = (CI / 2) * 36;  // reduction steps per chunk: channel pair x (kz, ky) x t
 
+  __builtin_amdgcn_s_barrier();  // the first chunk has landed
+  int buf = 0;
+  for (long long brick = br0; brick < br1; ++brick) {
   f32x16 acc[4][2];
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt)
@@ -148,8 +169,6 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tt][m][r] = 0.f;
 
-  __builtin_amdgcn_s_barrier();  // chunk 0 has landed
-  int buf = 0;
   for (int c0 = 0; c0 < p.Cin; c0 += CI) {
     const float* bB = lds + buf * BUF + bBo;
     const float* aB = lds + buf * BUF + aBo;
@@ -175,10 +194,12 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
         acc[(j + 1) & 3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b1, acc[(j + 1) & 3][1], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();  // the loaders may refill `buf`; the next chunk (this brick's or the next one's) is in
     buf ^= 1;
   }
 
+  int b, oz0, oy0, ox0;
+  decode(brick, b, oz0, oy0, ox0);
   // ---- epilogue: output transform, pair exchange, fused epilogues
   const int oz = oz0 + wz, oy = oy0 + wy;
   const bool odd = (col & 1) != 0;
@@ -259,7 +280,7 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
   if (dy != nullptr) {
     // the 16 lanes with equal (col & 1, kh) hold the same channels: butterfly over them, lanes col < 2 write the wave's
     // row [channel][slope-gradient term, bias-gradient term]
-    float* __restrict__ prow = p.dpart + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 64 * 2;
+    float* __restrict__ prow = p.dpart + ((size_t)brick * 4 + wv) * 64 * 2;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -279,6 +300,7 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
           }
         }
   }
+  }  // bricks
 }
 
 inline bool wino_ok(const FP& p, const float* x, const float* ws, int Cin, int Cout, int kernel, int stride, bool has_ms) {
@@ -298,9 +320,10 @@ inline int launch_wino(const float* X, const float* Ut, const float* bias, float
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
   // FLOWSCI_WINO_CI=2: 2-channel chunks, 70 KB of LDS, two workgroups per CU (A/B switch; 4-channel chunks with one
   // workgroup per CU are the default)
+  const unsigned nwg = 256;  // one persistent workgroup per CU (wino_ok: >= 512 bricks)
   static const bool ci2 = getenv("FLOWSCI_WINO_CI") != nullptr && atoi(getenv("FLOWSCI_WINO_CI")) == 2;
-  if (ci2) hipLaunchKernelGGL((conv3d_wino_ws_kernel<2>), dim3((unsigned)p.tiles, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
-  else hipLaunchKernelGGL((conv3d_wino_ws_kernel<4>), dim3((unsigned)p.tiles, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
+  if (ci2) hipLaunchKernelGGL((conv3d_wino_ws_kernel<2>), dim3(nwg, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
+  else hipLaunchKernelGGL((conv3d_wino_ws_kernel<4>), dim3(nwg, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

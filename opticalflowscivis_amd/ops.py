@@ -1496,6 +1496,10 @@ def prepared_weights():
     finally:
         _prep_depth -= 1
         invalidate_prepared_weights()
+        if _prep_depth == 0 and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            for tab in _prep_tables.values():  # layers met for the first time in this block join the batch table
+                if tab.dirty:
+                    tab.upload()
 
 
 class _PrepEntry:
@@ -1503,10 +1507,10 @@ class _PrepEntry:
 
 
 class _PrepTable:
-    def __init__(self):
-        self.entries, self.dirty, self.dev_jobs, self.njobs = {}, False, None, 0
+    def __init__(self, device):
+        self.device, self.entries, self.dirty, self.dev_jobs, self.njobs = device, {}, False, None, 0
 
-    def refresh(self, device):
+    def _live(self):
         live = []
         for k, e in list(self.entries.items()):
             w = e.wref()
@@ -1515,19 +1519,39 @@ class _PrepTable:
                 self.dirty = True
             elif e.jobs:
                 live.append((e, w))
-        if not live:
-            return
-        if self.dirty or self.dev_jobs is None:
-            jobs = [j for e, _ in live for j in e.jobs]
+        return live
+
+    def upload(self):
+        """(Re)build the device copy of the job table -- a pinned host buffer and an H2D copy: not capturable, so
+        prepared_weights() does it when a block ends, never inside a HIP-graph capture."""
+        live = self._live()
+        jobs = [j for e, _ in live for j in e.jobs]
+        if jobs:
             arr = (_lib.FsWprepJob * len(jobs))(*jobs)
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
-            self.dev_jobs, self.njobs, self.dirty = host.to(device, non_blocking=True), len(jobs), False
-        with torch.cuda.device(device):
-            _call("fs_conv3d_wprep_batch", self.dev_jobs.data_ptr(), self.njobs,
-                  torch.cuda.current_stream(device).cuda_stream,
-                  algo_bytes=8 * sum(j.total for e, _ in live for j in e.jobs))
+            self.dev_jobs, self.njobs = host.to(self.device, non_blocking=True), len(jobs)
+        else:
+            self.dev_jobs, self.njobs = None, 0
+        self.dirty = False
+
+    def refresh(self):
+        """Re-lay every registered weight with one launch.  False when that is not possible right now (the table
+        changed and the stream is capturing): the caller prepares its own weights, as the classic path does."""
+        if self.dirty or self.dev_jobs is None:
+            if torch.cuda.is_current_stream_capturing():
+                return False
+            self.upload()
+        live = self._live()
+        if self.dirty:  # an entry died between the upload and now
+            return False
+        if self.njobs:
+            with torch.cuda.device(self.device):
+                _call("fs_conv3d_wprep_batch", self.dev_jobs.data_ptr(), self.njobs,
+                      torch.cuda.current_stream(self.device).cuda_stream,
+                      algo_bytes=8 * sum(j.total for e, _ in live for j in e.jobs))
         for e, w in live:
             e.stamp = (w._version, _prep_epoch)
+        return True
 
 
 def _prepared(w, nfloats, key, plan):
@@ -1535,7 +1559,9 @@ def _prepared(w, nfloats, key, plan):
     written (the library's own dispatch decides the layout).  0 as the pointer means "the slab is prepared"."""
     if not (_PREP_ON and _prep_depth > 0 and w.is_leaf and w.requires_grad):
         return w.data_ptr(), w.new_empty(max(int(nfloats), 1))
-    tab = _prep_tables.setdefault((w.device.type, w.device.index), _PrepTable())
+    tab = _prep_tables.get((w.device.type, w.device.index))
+    if tab is None:
+        tab = _prep_tables[(w.device.type, w.device.index)] = _PrepTable(w.device)
     k = (w.data_ptr(), tuple(w.shape)) + key
     e = tab.entries.get(k)
     if e is None or e.wref() is None:
@@ -1555,8 +1581,9 @@ def _prepared(w, nfloats, key, plan):
         return w.data_ptr(), e.ws
     if not e.jobs:  # this shape's kernel reads the weights as stored
         return w.data_ptr(), e.ws
-    if e.stamp != (w._version, _prep_epoch):
-        tab.refresh(w.device)
+    if e.stamp != (w._version, _prep_epoch) and not tab.refresh():
+        e.stamp = (w._version, _prep_epoch)
+        return w.data_ptr(), e.ws
     return 0, e.ws
 
 
