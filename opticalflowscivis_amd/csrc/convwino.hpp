@@ -172,27 +172,36 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
   for (int c0 = 0; c0 < p.Cin; c0 += CI) {
     const float* bB = lds + buf * BUF + bBo;
     const float* aB = lds + buf * BUF + aBo;
-    auto lds_ops = [&](int j, float (&a)[2], float& bq) {
-      const int cl = j / 36, r = j - cl * 36;
-      const int kk = r >> 2, tt = r & 3;
-      a[0] = aB[cl * WN_UCH + kk * 256 + tt * 64];
-      a[1] = aB[cl * WN_UCH + kk * 256 + tt * 64 + 32];
-      bq = bB[cl * WN_VCH + ((kk / 3) * 4 + (kk % 3)) * WN_ROWF + tt * 32];
-    };
-    float a0[2], a1[2], b0, b1;
-    lds_ops(0, a0, b0);
+    // operands of the four transformed components t = 0..3 of one (channel pair, kz, ky): 12 LDS reads, issued a whole
+    // group (8 MFMAs = 512 matrix-pipe cycles) ahead of their use -- with two MFMAs per reduction step, reading one
+    // STEP ahead (as the direct kernel does with its eight) leaves the LDS latency uncovered
+    auto lds_group = [&](int g, float (&a)[4][2], float (&bq)[4]) {
+      const int cl = g / 9, kk = g - cl * 9;
 #pragma unroll
-    for (int j = 0; j < NP; j += 2) {
-      if (j + 1 < NP) lds_ops(j + 1, a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[j & 3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0, acc[j & 3][0], 0, 0, 0);
-      acc[j & 3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0, acc[j & 3][1], 0, 0, 0);
-      if (j + 2 < NP) lds_ops(j + 2, a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (j + 1 < NP) {
-        acc[(j + 1) & 3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b1, acc[(j + 1) & 3][0], 0, 0, 0);
-        acc[(j + 1) & 3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b1, acc[(j + 1) & 3][1], 0, 0, 0);
+      for (int tt = 0; tt < 4; ++tt) {
+        a[tt][0] = aB[cl * WN_UCH + kk * 256 + tt * 64];
+        a[tt][1] = aB[cl * WN_UCH + kk * 256 + tt * 64 + 32];
+        bq[tt] = bB[cl * WN_VCH + ((kk / 3) * 4 + (kk % 3)) * WN_ROWF + tt * 32];
       }
+    };
+    auto mma_group = [&](const float (&a)[4][2], const float (&bq)[4]) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        acc[tt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt][0], bq[tt], acc[tt][0], 0, 0, 0);
+        acc[tt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt][1], bq[tt], acc[tt][1], 0, 0, 0);
+      }
+    };
+    constexpr int NG = NP / 4;
+    float ga0[4][2], gb0[4], ga1[4][2], gb1[4];
+    lds_group(0, ga0, gb0);
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+      if (g + 1 < NG) lds_group(g + 1, ga1, gb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group(ga0, gb0);
+      if (g + 2 < NG) lds_group(g + 2, ga0, gb0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < NG) mma_group(ga1, gb1);
     }
     __builtin_amdgcn_s_barrier();  // the loaders may refill `buf`; the next chunk (this brick's or the next one's) is in
     buf ^= 1;
