@@ -25,6 +25,7 @@
 // into a forward convolution.
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 

@@ -84,8 +84,11 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
       const int hx = q == 0 ? ox0 - 1 : ox0 + 64;
       hoff = (rowok && (q == 0 || q == 15) && hx >= 0 && hx < p.Wi) ? (rbase + hx) * 4u : DMA_OOB;
     };
-    float xa[CI], xb[CI], xc[CI], xd[CI], xh[CI];
-    auto fetch = [&](int c0) {
+    // two register sets: the rows of chunk k + 2 are requested while those of chunk k + 1 are transformed -- with a
+    // 9 K-cycle MFMA phase per chunk a request issued only one chunk ahead lands too late under load
+    float xa[2][CI], xb[2][CI], xc[2][CI], xd[2][CI], xh[2][CI];
+    auto fetch = [&](auto P, int c0) {
+      constexpr int s_ = decltype(P)::value;
 #pragma unroll
       for (int c = 0; c < CI; ++c) {
         const int ch = c0 + c;
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
         const float* base = X + ((size_t)b * p.Cin + (live ? ch : 0)) * xvol;
         __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, live ? (int)((unsigned)xvol * 4u) : 0, 0x00020000);
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
-        xa[c] = __uint_as_float(v[0]); xb[c] = __uint_as_float(v[1]); xc[c] = __uint_as_float(v[2]); xd[c] = __uint_as_float(v[3]);
-        xh[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, hoff, 0, 0));
+        xa[s_][c] = __uint_as_float(v[0]); xb[s_][c] = __uint_as_float(v[1]); xc[s_][c] = __uint_as_float(v[2]); xd[s_][c] = __uint_as_float(v[3]);
+        xh[s_][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, hoff, 0, 0));
       }
     };
     auto dma_u = [&](int c0, int buf) {
@@ -105,46 +108,63 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
         if (wv + 4 * k < NUP)  // wave-uniform
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + 256 * (wv + 4 * k)), 16, uoff[k], 0, 0, 0);
     };
-    auto put = [&](int buf) {
+    auto put = [&](auto P, int buf) {
+      constexpr int s_ = decltype(P)::value;
       float* base = lds + buf * BUF + vdst;
 #pragma unroll
       for (int c = 0; c < CI; ++c) {
         // left neighbour's d (x = 4q - 1) and right neighbour's a (x = 4q + 4); lanes 0 / 15 of a row keep the halo
-        const float L = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(xh[c]), __float_as_uint(xd[c]), 0x111, 0xF, 0xF, false));
-        const float Rr = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(xh[c]), __float_as_uint(xa[c]), 0x101, 0xF, 0xF, false));
+        const float L = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(xh[s_][c]), __float_as_uint(xd[s_][c]), 0x111, 0xF, 0xF, false));
+        const float Rr = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(xh[s_][c]), __float_as_uint(xa[s_][c]), 0x101, 0xF, 0xF, false));
         float* dst = base + c * WN_VCH;
         // tile 2q: d = (L, a, b, c); tile 2q + 1: d = (b, c, d, Rr)
-        *reinterpret_cast<float2*>(dst + 0 * 32) = make_float2(L - xb[c], xb[c] - xd[c]);
-        *reinterpret_cast<float2*>(dst + 1 * 32) = make_float2(xa[c] + xb[c], xc[c] + xd[c]);
-        *reinterpret_cast<float2*>(dst + 2 * 32) = make_float2(xb[c] - xa[c], xd[c] - xc[c]);
-        *reinterpret_cast<float2*>(dst + 3 * 32) = make_float2(xa[c] - xc[c], xc[c] - Rr);
+        *reinterpret_cast<float2*>(dst + 0 * 32) = make_float2(L - xb[s_][c], xb[s_][c] - xd[s_][c]);
+        *reinterpret_cast<float2*>(dst + 1 * 32) = make_float2(xa[s_][c] + xb[s_][c], xc[s_][c] + xd[s_][c]);
+        *reinterpret_cast<float2*>(dst + 2 * 32) = make_float2(xb[s_][c] - xa[s_][c], xd[s_][c] - xc[s_][c]);
+        *reinterpret_cast<float2*>(dst + 3 * 32) = make_float2(xa[s_][c] - xc[s_][c], xc[s_][c] - Rr);
       }
     };
-    auto stage = [&](int c0, int buf) {
-      fetch(c0);
-      dma_u(c0, buf);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      put(buf);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the chunk sequence of this workgroup: (brick, c0), c0 fastest.  `n2` = the chunk whose rows are requested next
+    long long n2b = br0;
+    int n2c = 0;
+    long long placed = -1;
+    auto n2_valid = [&]() { return n2b < br1; };
+    auto n2_advance = [&]() { n2c += CI; if (n2c >= p.Cin) { n2c = 0; ++n2b; } };
+    auto request = [&](auto P) {  // rows of chunk n2 -> register set P (nothing when the sequence is over)
+      if (!n2_valid()) return false;
+      if (placed != n2b) { place(n2b); placed = n2b; }
+      fetch(P, n2c);
+      n2_advance();
+      return true;
     };
-    if (br0 < br1) {
-      place(br0);
-      stage(0, 0);
+    // per chunk k (its MFMA phase runs on buffer k & 1): U slab of chunk k + 1 by DMA, rows of chunk k + 2 requested,
+    // rows of chunk k + 1 (requested one phase ago, set P) transformed into buffer (k + 1) & 1
+    long long n1b = br0;  // chunk k + 1 of the loop below, starting with chunk 0 for the prologue
+    int n1c = 0;
+    auto n1_advance = [&]() { n1c += CI; if (n1c >= p.Cin) { n1c = 0; ++n1b; } };
+    auto fill = [&](auto P, auto Q, int buf) {  // chunk n1: set P holds its rows; request the following chunk into Q
+      dma_u(n1c, buf);
+      if (request(Q)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CI) : "memory");  // all but the newest requests
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      put(P, buf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      n1_advance();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    const long long nchunks = (br1 - br0) * ((p.Cin + CI - 1) / CI);
+    if (nchunks > 0) {
+      request(I0{});
+      fill(I0{}, I1{}, 0);
     }
     __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    for (long long brick = br0; brick < br1; ++brick)
-      for (int c0 = 0; c0 < p.Cin; c0 += CI) {
-        // the chunk after this one: the same brick's next channels, or the next brick's first
-        if (c0 + CI < p.Cin) {
-          stage(c0 + CI, buf ^ 1);
-        } else if (brick + 1 < br1) {
-          place(brick + 1);
-          stage(0, buf ^ 1);
-        }
-        __builtin_amdgcn_s_barrier();  // that chunk is in LDS; the matrix waves are done reading `buf`
-        buf ^= 1;
-      }
+    for (long long k = 0; k < nchunks; k += 2) {
+      if (k + 1 < nchunks) fill(I1{}, I0{}, 1);  // chunk k + 1 -> buffer 1 while chunk k computes on buffer 0
+      __builtin_amdgcn_s_barrier();
+      if (k + 1 >= nchunks) break;
+      if (k + 2 < nchunks) fill(I0{}, I1{}, 0);  // chunk k + 2 -> buffer 0 while chunk k + 1 computes on buffer 1
+      __builtin_amdgcn_s_barrier();
+    }
 #else
     (void)xvol; (void)NUW;
 #endif
