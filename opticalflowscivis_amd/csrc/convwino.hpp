@@ -21,9 +21,6 @@
 //     LDS as V[ci][staged row][t][x-tile]: wave w stages staged-z row w of every channel (4 y rows x 16 lanes).
 //   matrix waves 0-3: one output row each (4 transformed accumulator sets x 2 channel tiles = 8 MFMA tiles, as
 //     many as the direct kernel holds); both MFMA operands are "lane base + immediate" LDS reads.
-//   Workgroups are persistent: 256 of them (one per CU, contiguous brick ranges per XCD) walk their bricks, and the
-//     loaders run one chunk ahead ACROSS brick boundaries, so a brick's first loads fly under the previous brick's
-//     last MFMA phase and its epilogue.
 //   epilogue: output transform in registers, one DPP swap between neighbouring x-tiles so that a lane holds 4
 //     consecutive x of one channel, then the same fused epilogues as the direct kernel (bias, PReLU output, residual
 //     addend; or the PReLU-backward form with its per-wave partial sums).
@@ -33,7 +30,7 @@ constexpr int WN_VCH = 16 * WN_ROWF + 16;       // channel pitch of V (4 x 4 sta
 constexpr int WN_UCH = 9 * 4 * 64 + 16;         // channel pitch of U ([kz*3+ky][t][co], + the same pad)
 
 template <int CI>
-__global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(512, 1) void conv3d_wino_ws_kernel(const float* __restrict__ X,
                                                                const float* __restrict__ Ut,
                                                                const float* __restrict__ bias,
                                                                float* __restrict__ Y, FP p) {
@@ -48,23 +45,27 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wv = wave & 3;
 
-  // this workgroup's bricks: a contiguous range, and consecutive ranges on one XCD (workgroups are dealt to the 8
-  // XCDs round-robin): neighbouring bricks share halo rows in that XCD's L2
-  const int nwg = gridDim.x;
-  const long long ord = (long long)(blockIdx.x & 7) * (nwg / 8) + (blockIdx.x >> 3);
-  const long long br0 = ord * p.tiles / nwg, br1 = (ord + 1) * p.tiles / nwg;
-  auto decode = [&](long long tile, int& b, int& oz0, int& oy0, int& ox0) {
-    const int txi = (int)(tile % p.tx); tile /= p.tx;
-    const int tyi = (int)(tile % p.ty); tile /= p.ty;
-    const int tzi = (int)(tile % p.tz);
-    b = (int)(tile / p.tz);
-    oz0 = tzi * 2; oy0 = tyi * 2; ox0 = txi * 64;
-  };
+  long long tile = blockIdx.x;
+  {
+    const long long per = p.tiles / 8;
+    if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);  // contiguous brick ranges per XCD
+  }
+  const int txi = (int)(tile % p.tx); tile /= p.tx;
+  const int tyi = (int)(tile % p.ty); tile /= p.ty;
+  const int tzi = (int)(tile % p.tz);
+  const int b = (int)(tile / p.tz);
+  const int oz0 = tzi * 2, oy0 = tyi * 2, ox0 = txi * 64;
   const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
 
   if (wave >= 4) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int yr = lane >> 4, q = lane & 15;
+    const int gz = oz0 - 1 + wv, gy = oy0 - 1 + yr, gx = ox0 + 4 * q;
+    const bool rowok = gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
+    const unsigned rbase = ((unsigned)(rowok ? gz : 0) * p.Hi + (rowok ? gy : 0)) * p.Wi;
+    const unsigned voff = (rowok && gx < p.Wi) ? (rbase + gx) * 4u : DMA_OOB;   // Wi % 64 == 0: a float4 is in or out whole
+    const int hx = q == 0 ? ox0 - 1 : ox0 + 64;
+    const unsigned hoff = (rowok && (q == 0 || q == 15) && hx >= 0 && hx < p.Wi) ? (rbase + hx) * 4u : DMA_OOB;
     unsigned uoff[NUW];
 #pragma unroll
     for (int k = 0; k < NUW; ++k) {
@@ -72,23 +73,8 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
       uoff[k] = piece < NU / 4 ? (unsigned)piece * 16u : DMA_OOB;
     }
     const int vdst = (wv * 4 + yr) * WN_ROWF + 2 * q;
-    int b = 0;
-    unsigned voff = DMA_OOB, hoff = DMA_OOB;
-    auto place = [&](long long brick) {  // this lane's row of the brick: offsets inside a channel volume
-      int oz0, oy0, ox0;
-      decode(brick, b, oz0, oy0, ox0);
-      const int gz = oz0 - 1 + wv, gy = oy0 - 1 + yr, gx = ox0 + 4 * q;
-      const bool rowok = gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
-      const unsigned rbase = ((unsigned)(rowok ? gz : 0) * p.Hi + (rowok ? gy : 0)) * p.Wi;
-      voff = (rowok && gx < p.Wi) ? (rbase + gx) * 4u : DMA_OOB;   // Wi % 64 == 0: a float4 is in or out whole
-      const int hx = q == 0 ? ox0 - 1 : ox0 + 64;
-      hoff = (rowok && (q == 0 || q == 15) && hx >= 0 && hx < p.Wi) ? (rbase + hx) * 4u : DMA_OOB;
-    };
-    // two register sets: the rows of chunk k + 2 are requested while those of chunk k + 1 are transformed -- with a
-    // 9 K-cycle MFMA phase per chunk a request issued only one chunk ahead lands too late under load
-    float xa[2][CI], xb[2][CI], xc[2][CI], xd[2][CI], xh[2][CI];
-    auto fetch = [&](auto P, int c0) {
-      constexpr int s_ = decltype(P)::value;
+    float xa[CI], xb[CI], xc[CI], xd[CI], xh[CI];
+    auto fetch = [&](int c0) {
 #pragma unroll
       for (int c = 0; c < CI; ++c) {
         const int ch = c0 + c;
@@ -96,8 +82,8 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
         const float* base = X + ((size_t)b * p.Cin + (live ? ch : 0)) * xvol;
         __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, live ? (int)((unsigned)xvol * 4u) : 0, 0x00020000);
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
-        xa[s_][c] = __uint_as_float(v[0]); xb[s_][c] = __uint_as_float(v[1]); xc[s_][c] = __uint_as_float(v[2]); xd[s_][c] = __uint_as_float(v[3]);
-        xh[s_][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, hoff, 0, 0));
+        xa[c] = __uint_as_float(v[0]); xb[c] = __uint_as_float(v[1]); xc[c] = __uint_as_float(v[2]); xd[c] = __uint_as_float(v[3]);
+        xh[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, hoff, 0, 0));
       }
     };
     auto dma_u = [&](int c0, int buf) {
@@ -108,62 +94,38 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
         if (wv + 4 * k < NUP)  // wave-uniform
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + 256 * (wv + 4 * k)), 16, uoff[k], 0, 0, 0);
     };
-    auto put = [&](auto P, int buf) {
-      constexpr int s_ = decltype(P)::value;
+    auto put = [&](int buf) {
       float* base = lds + buf * BUF + vdst;
 #pragma unroll
       for (int c = 0; c < CI; ++c) {
         // left neighbour's d (x = 4q - 1) and right neighbour's a (x = 4q + 4); lanes 0 / 15 of a row keep the halo
-        const float L = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(xh[s_][c]), __float_as_uint(xd[s_][c]), 0x111, 0xF, 0xF, false));
-        const float Rr = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(xh[s_][c]), __float_as_uint(xa[s_][c]), 0x101, 0xF, 0xF, false));
+        const float L = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(xh[c]), __float_as_uint(xd[c]), 0x111, 0xF, 0xF, false));
+        const float Rr = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(xh[c]), __float_as_uint(xa[c]), 0x101, 0xF, 0xF, false));
         float* dst = base + c * WN_VCH;
         // tile 2q: d = (L, a, b, c); tile 2q + 1: d = (b, c, d, Rr)
-        *reinterpret_cast<float2*>(dst + 0 * 32) = make_float2(L - xb[s_][c], xb[s_][c] - xd[s_][c]);
-        *reinterpret_cast<float2*>(dst + 1 * 32) = make_float2(xa[s_][c] + xb[s_][c], xc[s_][c] + xd[s_][c]);
-        *reinterpret_cast<float2*>(dst + 2 * 32) = make_float2(xb[s_][c] - xa[s_][c], xd[s_][c] - xc[s_][c]);
-        *reinterpret_cast<float2*>(dst + 3 * 32) = make_float2(xa[s_][c] - xc[s_][c], xc[s_][c] - Rr);
+        *reinterpret_cast<float2*>(dst + 0 * 32) = make_float2(L - xb[c], xb[c] - xd[c]);
+        *reinterpret_cast<float2*>(dst + 1 * 32) = make_float2(xa[c] + xb[c], xc[c] + xd[c]);
+        *reinterpret_cast<float2*>(dst + 2 * 32) = make_float2(xb[c] - xa[c], xd[c] - xc[c]);
+        *reinterpret_cast<float2*>(dst + 3 * 32) = make_float2(xa[c] - xc[c], xc[c] - Rr);
       }
     };
-    // the chunk sequence of this workgroup: (brick, c0), c0 fastest.  `n2` = the chunk whose rows are requested next
-    long long n2b = br0;
-    int n2c = 0;
-    long long placed = -1;
-    auto n2_valid = [&]() { return n2b < br1; };
-    auto n2_advance = [&]() { n2c += CI; if (n2c >= p.Cin) { n2c = 0; ++n2b; } };
-    auto request = [&](auto P) {  // rows of chunk n2 -> register set P (nothing when the sequence is over)
-      if (!n2_valid()) return false;
-      if (placed != n2b) { place(n2b); placed = n2b; }
-      fetch(P, n2c);
-      n2_advance();
-      return true;
-    };
-    // per chunk k (its MFMA phase runs on buffer k & 1): U slab of chunk k + 1 by DMA, rows of chunk k + 2 requested,
-    // rows of chunk k + 1 (requested one phase ago, set P) transformed into buffer (k + 1) & 1
-    long long n1b = br0;  // chunk k + 1 of the loop below, starting with chunk 0 for the prologue
-    int n1c = 0;
-    auto n1_advance = [&]() { n1c += CI; if (n1c >= p.Cin) { n1c = 0; ++n1b; } };
-    auto fill = [&](auto P, auto Q, int buf) {  // chunk n1: set P holds its rows; request the following chunk into Q
-      dma_u(n1c, buf);
-      if (request(Q)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CI) : "memory");  // all but the newest requests
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      put(P, buf);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      n1_advance();
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    const long long nchunks = (br1 - br0) * ((p.Cin + CI - 1) / CI);
-    if (nchunks > 0) {
-      request(I0{});
-      fill(I0{}, I1{}, 0);
-    }
+    fetch(0);
+    dma_u(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    put(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (long long k = 0; k < nchunks; k += 2) {
-      if (k + 1 < nchunks) fill(I1{}, I0{}, 1);  // chunk k + 1 -> buffer 1 while chunk k computes on buffer 0
-      __builtin_amdgcn_s_barrier();
-      if (k + 1 >= nchunks) break;
-      if (k + 2 < nchunks) fill(I0{}, I1{}, 0);  // chunk k + 2 -> buffer 0 while chunk k + 1 computes on buffer 1
-      __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int c0 = 0; c0 < p.Cin; c0 += CI) {
+      if (c0 + CI < p.Cin) {
+        fetch(c0 + CI);
+        dma_u(c0 + CI, buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        put(buf ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // the next chunk is in LDS; the matrix waves are done reading `buf`
+      buf ^= 1;
     }
 #else
     (void)xvol; (void)NUW;
@@ -178,9 +140,6 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
   const int aBo = NV + kh * (CI / 2) * WN_UCH + col;
   constexpr int NP = (CI / 2) * 36;  // reduction steps per chunk: channel pair x (kz, ky) x t
 
-  __builtin_amdgcn_s_barrier();  // the first chunk has landed
-  int buf = 0;
-  for (long long brick = br0; brick < br1; ++brick) {
   f32x16 acc[4][2];
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt)
@@ -189,46 +148,37 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tt][m][r] = 0.f;
 
+  __builtin_amdgcn_s_barrier();  // chunk 0 has landed
+  int buf = 0;
   for (int c0 = 0; c0 < p.Cin; c0 += CI) {
     const float* bB = lds + buf * BUF + bBo;
     const float* aB = lds + buf * BUF + aBo;
-    // operands of the four transformed components t = 0..3 of one (channel pair, kz, ky): 12 LDS reads, issued a whole
-    // group (8 MFMAs = 512 matrix-pipe cycles) ahead of their use -- with two MFMAs per reduction step, reading one
-    // STEP ahead (as the direct kernel does with its eight) leaves the LDS latency uncovered
-    auto lds_group = [&](int g, float (&a)[4][2], float (&bq)[4]) {
-      const int cl = g / 9, kk = g - cl * 9;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        a[tt][0] = aB[cl * WN_UCH + kk * 256 + tt * 64];
-        a[tt][1] = aB[cl * WN_UCH + kk * 256 + tt * 64 + 32];
-        bq[tt] = bB[cl * WN_VCH + ((kk / 3) * 4 + (kk % 3)) * WN_ROWF + tt * 32];
-      }
+    auto lds_ops = [&](int j, float (&a)[2], float& bq) {
+      const int cl = j / 36, r = j - cl * 36;
+      const int kk = r >> 2, tt = r & 3;
+      a[0] = aB[cl * WN_UCH + kk * 256 + tt * 64];
+      a[1] = aB[cl * WN_UCH + kk * 256 + tt * 64 + 32];
+      bq = bB[cl * WN_VCH + ((kk / 3) * 4 + (kk % 3)) * WN_ROWF + tt * 32];
     };
-    auto mma_group = [&](const float (&a)[4][2], const float (&bq)[4]) {
+    float a0[2], a1[2], b0, b1;
+    lds_ops(0, a0, b0);
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        acc[tt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt][0], bq[tt], acc[tt][0], 0, 0, 0);
-        acc[tt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt][1], bq[tt], acc[tt][1], 0, 0, 0);
+    for (int j = 0; j < NP; j += 2) {
+      if (j + 1 < NP) lds_ops(j + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[j & 3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0, acc[j & 3][0], 0, 0, 0);
+      acc[j & 3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0, acc[j & 3][1], 0, 0, 0);
+      if (j + 2 < NP) lds_ops(j + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < NP) {
+        acc[(j + 1) & 3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b1, acc[(j + 1) & 3][0], 0, 0, 0);
+        acc[(j + 1) & 3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b1, acc[(j + 1) & 3][1], 0, 0, 0);
       }
-    };
-    constexpr int NG = NP / 4;
-    float ga0[4][2], gb0[4], ga1[4][2], gb1[4];
-    lds_group(0, ga0, gb0);
-#pragma unroll
-    for (int g = 0; g < NG; g += 2) {
-      if (g + 1 < NG) lds_group(g + 1, ga1, gb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_group(ga0, gb0);
-      if (g + 2 < NG) lds_group(g + 2, ga0, gb0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + 1 < NG) mma_group(ga1, gb1);
     }
-    __builtin_amdgcn_s_barrier();  // the loaders may refill `buf`; the next chunk (this brick's or the next one's) is in
+    __builtin_amdgcn_s_barrier();
     buf ^= 1;
   }
 
-  int b, oz0, oy0, ox0;
-  decode(brick, b, oz0, oy0, ox0);
   // ---- epilogue: output transform, pair exchange, fused epilogues
   const int oz = oz0 + wz, oy = oy0 + wy;
   const bool odd = (col & 1) != 0;
@@ -309,7 +259,7 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
   if (dy != nullptr) {
     // the 16 lanes with equal (col & 1, kh) hold the same channels: butterfly over them, lanes col < 2 write the wave's
     // row [channel][slope-gradient term, bias-gradient term]
-    float* __restrict__ prow = p.dpart + ((size_t)brick * 4 + wv) * 64 * 2;
+    float* __restrict__ prow = p.dpart + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 64 * 2;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -329,7 +279,6 @@ __global__ __launch_bounds__(512, CI == 2 ? 2 : 1) void conv3d_wino_ws_kernel(co
           }
         }
   }
-  }  // bricks
 }
 
 inline bool wino_ok(const FP& p, const float* x, const float* ws, int Cin, int Cout, int kernel, int stride, bool has_ms) {
@@ -347,12 +296,12 @@ inline int launch_wino(const float* X, const float* Ut, const float* bias, float
   p.tz = fs::cdiv(p.Do, 2); p.ty = fs::cdiv(p.Ho, 2); p.tx = p.Wo / 64;
   p.tiles = (long long)p.B * p.tz * p.ty * p.tx;
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
-  // FLOWSCI_WINO_CI=2: 2-channel chunks, 70 KB of LDS, two workgroups per CU (A/B switch; 4-channel chunks with one
-  // workgroup per CU are the default)
-  const unsigned nwg = 256;  // one persistent workgroup per CU (wino_ok: >= 512 bricks)
-  static const bool ci2 = getenv("FLOWSCI_WINO_CI") != nullptr && atoi(getenv("FLOWSCI_WINO_CI")) == 2;
-  if (ci2) hipLaunchKernelGGL((conv3d_wino_ws_kernel<2>), dim3(nwg, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
-  else hipLaunchKernelGGL((conv3d_wino_ws_kernel<4>), dim3(nwg, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
+  // (measured and not kept, tests/tools/wino_bench.py on the 64 -> 64 layer at 2 x 64^3, 0.69 ms as built: 2-channel
+  // chunks with two workgroups per CU 0.87 ms; persistent workgroups whose loaders run across brick boundaries 0.72 ms
+  // at 256 VGPRs; operand reads a whole 8-MFMA group ahead and input rows requested two chunks ahead: no change;
+  // s_setprio for the matrix waves: no change.  The matrix waves alone -- loaders reduced to their barriers -- take
+  // 0.57 ms = the MFMA work at the ~2.06 GHz these kernels hold; the loaders alone 0.21 ms.)
+  hipLaunchKernelGGL((conv3d_wino_ws_kernel<4>), dim3((unsigned)p.tiles, 1), dim3(512), 0, st, X, Ut, bias, Y, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
