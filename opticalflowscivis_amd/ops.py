@@ -1647,12 +1647,31 @@ def conv3d_wrw(g, src, k, stride, pad):
     if src.shape[0] != B:
         raise ValueError("batch mismatch")
     dw = g.new_zeros(Cg, Cs, k, k, k)
+    fq = 2 * g.numel() * Cs * int(k) ** 3
+    wino = conv3d_wrw_takes_winograd(B, Cg, Cs, g.shape[2:], src.shape[2:], k, stride, pad, g.data_ptr() % 16,
+                                     src.data_ptr() % 16)
     with torch.cuda.device(g.device):
         _call("fs_conv3d_wrw", g.data_ptr(), src.data_ptr(), dw.data_ptr(), B, Cg, Cs, g.shape[2],
               g.shape[3], g.shape[4], src.shape[2], src.shape[3], src.shape[4], int(k), int(stride),
               int(pad), _stream(g), algo_bytes=4 * (g.numel() + src.numel()),
-              algo_flops=2 * g.numel() * Cs * int(k) ** 3)
+              algo_flops=fq * 2 // 3 if wino else fq, equiv_flops=fq)
     return dw
+
+
+def conv3d_wrw_takes_winograd(B, Cg, Cs, g_dhw, src_dhw, k, stride, pad, g_misalign=0, src_misalign=0):
+    """Does fs_conv3d_wrw run this call in the Winograd F(2,3) domain (csrc/convwrwwino.hpp)?  Mirrors
+    `wrw_wino_ok` there (the weight gradient has no re-layout plan to ask): the 64 -> 64 k3 s1 p1 layers with rows
+    of 64 x, an even number of y rows, >= 1024 position bricks, 16-byte aligned operands.  Only the flop accounting
+    of the timing records depends on it."""
+    import os
+    if os.environ.get("FLOWSCI_WRW_NO_WINO") is not None or os.environ.get("FLOWSCI_WRW_REG") is not None:
+        return False
+    D, H, W = (int(v) for v in g_dhw)
+    if (int(k), int(stride), int(pad)) != (3, 1, 1) or Cg != 64 or Cs != 64 or tuple(int(v) for v in src_dhw) != (D, H, W):
+        return False
+    if W % 64 or H % 2 or g_misalign or src_misalign or 64 * D * H * W * 4 >= 2 ** 31:
+        return False
+    return B * D * (H // 2) * (W // 64) >= 1024
 
 
 FS_ERR_UNSUPPORTED = 5

@@ -97,3 +97,43 @@ def test_wino_is_not_taken_where_it_does_not_apply(ops):
     w = torch.randn(128, 64, 3, 3, 3, device=DEV)    # more than one 64-channel group
     x = torch.randn(2, 64, 32, 32, 64, device=DEV)
     assert not _is_wino(ops, x, w, 64, 128, (32, 32, 64), 0)
+
+
+@pytest.mark.parametrize("B,size", [(2, (32, 32, 64)), (2, (33, 32, 64)), (1, (64, 64, 64)), (2, (16, 32, 128))])
+def test_wino_weight_gradient_vs_fp64(ops, B, size):
+    """fs_conv3d_wrw on the 64 -> 64 k3 layers in the Winograd domain (csrc/convwrwwino.hpp: both operands transformed
+    as they are read from LDS, G^T applied in the atomic epilogue) against the fp64 weight gradient, and the whole
+    layer through the autograd node (forward, input gradient and weight gradient all on the F(2,3) kernels)."""
+    from opticalflowscivis_amd import convgrad
+    assert ops.conv3d_wrw_takes_winograd(B, 64, 64, size, size, 3, 1, 1, 0, 0)
+    g = torch.Generator().manual_seed(size[0] + B)
+    x = torch.randn((B, 64) + size, generator=g)
+    w = torch.randn(64, 64, 3, 3, 3, generator=g) / (64 * 27) ** 0.5
+    G = torch.randn((B, 64) + size, generator=g)
+    # fp64 reference of dW[co, ci, k] = sum G[b, co, o] x_pad[b, ci, o + k]: evaluated tap by tap (the fp64 convolution
+    # backward of a 64^3 volume is slow on the host)
+    xp = F.pad(x.double(), (1, 1, 1, 1, 1, 1))
+    Gd = G.double()
+    D, H, W = size
+    ref = torch.empty(64, 64, 27, dtype=torch.float64)
+    for k in range(27):
+        kz, ky, kx = k // 9, (k // 3) % 3, k % 3
+        ref[:, :, k] = torch.einsum("bgzyx,bczyx->gc", Gd, xp[:, :, kz:kz + D, ky:ky + H, kx:kx + W])
+    ref = ref.view(64, 64, 3, 3, 3)
+    got = ops.conv3d_wrw(G.to(DEV), x.to(DEV), 3, 1, 1)
+    scale = float(ref.abs().max())
+    assert float((got.cpu().double() - ref).abs().max()) < 3e-5 * scale
+    # through the layer's autograd node
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    y = convgrad._ConvFn.apply(xd, wd, None, (1, 1, 1), (1, 1, 1), False)
+    gx, gw = torch.autograd.grad((y * G.to(DEV)).sum(), [xd, wd])
+    assert float((gw.cpu().double() - ref).abs().max()) < 3e-5 * scale
+    gx_ref = F.conv3d(G.double(), w.transpose(0, 1).flip(2, 3, 4).double(), None, 1, 1)
+    assert float((gx.cpu().double() - gx_ref).abs().max()) < TOL * float(gx_ref.abs().max())
+
+
+def test_wino_weight_gradient_is_not_taken_where_it_does_not_apply(ops):
+    assert not ops.conv3d_wrw_takes_winograd(2, 64, 64, (32, 32, 32), (32, 32, 32), 3, 1, 1, 0, 0)   # rows of 32
+    assert not ops.conv3d_wrw_takes_winograd(2, 64, 32, (32, 32, 64), (32, 32, 64), 3, 1, 1, 0, 0)   # 32 source channels
+    assert not ops.conv3d_wrw_takes_winograd(1, 64, 64, (8, 8, 64), (8, 8, 64), 3, 1, 1, 0, 0)       # too few bricks
+    assert not ops.conv3d_wrw_takes_winograd(2, 64, 64, (32, 32, 64), (32, 32, 64), 3, 1, 1, 4, 0)   # misaligned
