@@ -37,7 +37,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino_ws_kernel(const float* __r
   constexpr int NV = CI * WN_VCH, NU = CI * WN_UCH;
   constexpr int NUP = (NU / 4 + 63) / 64;  // wave-instructions of 64 x 16 bytes for the U slab
   constexpr int NUW = (NUP + 3) / 4;       // per loader wave
-  constexpr int BUF = NV + NU;
+  // (an LDS-DMA wave-instruction fills 256 floats: the slab's slot is rounded up to that, or its last instruction
+  // would write out-of-range zeros over the first staged row of the OTHER buffer)
+  constexpr int BUF = NV + NUP * 256;
   static_assert((NV % 4) == 0 && (NU % 4) == 0 && 2 * BUF * 4 <= 160 * 1024, "two 16-byte aligned buffers in LDS");
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 

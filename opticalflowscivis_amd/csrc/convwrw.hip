@@ -27,6 +27,7 @@
 // contiguous bytes per half-wave = the full-rate shape).
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 

@@ -29,7 +29,11 @@ constexpr int WW_XP = 72;                       // staged source row: 4 margin +
 constexpr int WW_CHS = (WW_TY + 2) * WW_XP + 4; // source channel pitch (+4, as above)
 constexpr int WW_NG = 64 * WW_GP;               // 8448 floats
 constexpr int WW_NS = 32 * WW_CHS;              // 9344 floats
-constexpr int WW_BUF = WW_NG + WW_NS;           // 17792 floats = 69.5 KB; two buffers
+// an LDS-DMA wave-instruction fills 256 floats: both images are rounded up to that, or the last instruction of the
+// source image would write its out-of-range zeros over the first gradient row of the OTHER buffer
+constexpr int WW_NSL = (WW_NS + 255) / 256 * 256; // 9472
+constexpr int WW_BUF = WW_NG + WW_NSL;          // 17920 floats = 70 KB; two buffers
+static_assert(WW_NG % 256 == 0, "the gradient image ends on a wave-instruction boundary");
 
 struct WWP {
   int B, D, H, W;    // one extent: stride 1, pad 1
@@ -38,6 +42,7 @@ struct WWP {
   int spw;           // bricks per workgroup
 };
 
+template <int DBG>
 __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __restrict__ G,
                                                                 const float* __restrict__ Src,
                                                                 float* __restrict__ dW, WWP p) {
@@ -87,6 +92,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __
       b = (int)(q / p.D);
     }
     auto stage = [&](int buf) {
+      if (DBG == 1) return;
       const int oy0 = byi * WW_TY, ox0 = bxi * 64;
       float* dbase = lds + buf * WW_BUF;
       __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(G + (size_t)b * 64 * vol), (short)0, 0x7fffffff, 0x00020000);
@@ -127,87 +133,120 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __
     return;
   }
 
-  // ---- matrix waves: (row tile m, component pair tp)
+  // ---- matrix waves: (brick row h, component pair tp), both 32-channel row tiles of the gradient.  (First form: waves
+  // = (row tile, pair), every wave walking both brick rows: each read all three source tiles -- 7 LDS reads per 6
+  // MFMAs, with the 4-way bank conflicts of the 16-byte-aligned pitches the LDS was the bound: 1.28 ms per launch,
+  // slower than the direct kernel.  A wave now owns ONE row of the brick and both row tiles: 8 reads per 12 MFMAs.)
   const int l31 = lane & 31, kh = lane >> 5;
-  const int m = wv >> 1, tp = wv & 1;
-  // A: gradient row of channel m * 32 + l31; B: source rows of channel l31 (this half), column tile n = ky
-  const int aBo = (m * 32 + l31) * WW_GP + 2 * kh;                    // + row * 64 + 4 kk: (dy[2j], dy[2j+1]), j = 2 kk + kh
-  const int bBo = WW_NG + l31 * WW_CHS + 4 + 2 * kh + (tp ? 2 : -1);   // + (row + ky) * XP + 4 kk: d0 (tp 0) or d3 (tp 1)
-  const int bPo = WW_NG + l31 * WW_CHS + 4 + 2 * kh;                   // + ...: the aligned pair (d1, d2)
+  const int h = wv >> 1, tp = wv & 1;
+  const int aBo = l31 * WW_GP + h * 64 + 2 * kh;                                  // + m * 32 * GP + 4 kk: (dy[2j], dy[2j+1])
+  const int bPo = WW_NG + l31 * WW_CHS + h * WW_XP + 4 + 2 * kh;                  // + n * XP + 4 kk: the aligned pair (d1, d2)
+  const int bBo = bPo + ((wv & 1) ? 2 : -1);                                            // d0 (tp 0) or d3 (tp 1)
 
-  f32x16 acc[3][2];
+  f32x16 acc[3][2][2];
+  // (the component pair is wave-uniform: two specialised instances of the loop, selected once, instead of selects in
+  // front of every MFMA)
+  auto kloop = [&](auto TPc) {
+  constexpr int tp = decltype(TPc)::value;
 #pragma unroll
   for (int n = 0; n < 3; ++n)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][c][r] = 0.f;
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][m][c][r] = 0.f;
 
   __builtin_amdgcn_s_barrier();  // brick s0 has landed
   int buf = 0;
   for (long long st = s0; st < s1; ++st) {
     const float* base = lds + buf * WW_BUF;
-    // reduction step q: row q / 16, tile pair kk = q % 16 (x-tiles 2 kk + kh)
-    auto lds_ops = [&](int q, float2& a, float2 (&bp)[3], float (&be)[3]) {
-      const int row = q >> 4, kk = q & 15;
-      a = *reinterpret_cast<const float2*>(base + aBo + row * 64 + 4 * kk);
+    // reduction step kk: x-tiles 2 kk + kh of this wave's row
+    auto lds_ops = [&](int kk, float2 (&a)[2], float2 (&bp)[3], float (&be)[3]) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const float2*>(base + aBo + m * 32 * WW_GP + 4 * kk);
 #pragma unroll
       for (int n = 0; n < 3; ++n) {
-        bp[n] = *reinterpret_cast<const float2*>(base + bPo + (row + n) * WW_XP + 4 * kk);
-        be[n] = base[bBo + (row + n) * WW_XP + 4 * kk];
+        bp[n] = *reinterpret_cast<const float2*>(base + bPo + n * WW_XP + 4 * kk);
+        be[n] = base[bBo + n * WW_XP + 4 * kk];
       }
     };
-    auto mma = [&](const float2& a, const float2 (&bp)[3], const float (&be)[3]) {
+    auto mma = [&](const float2 (&a)[2], const float2 (&bp)[3], const float (&be)[3]) {
       // dM: t = 0: dy0, t = 1: dy0 + dy1 | t = 2: dy0 - dy1, t = 3: dy1 (its sign is applied in the epilogue)
-      const float a0 = tp ? a.x - a.y : a.x;
-      const float a1 = tp ? a.y : a.x + a.y;
+      float a0[2], a1[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        a0[m] = tp ? a[m].x - a[m].y : a[m].x;
+        a1[m] = tp ? a[m].y : a[m].x + a[m].y;
+      }
 #pragma unroll
       for (int n = 0; n < 3; ++n) {
         // V: t = 0: d0 - d2, t = 1: d1 + d2 | t = 2: d2 - d1, t = 3: d1 - d3     (bp = (d1, d2), be = d0 or d3)
         const float v0 = tp ? bp[n].y - bp[n].x : be[n] - bp[n].y;
         const float v1 = tp ? bp[n].x - be[n] : bp[n].x + bp[n].y;
-        acc[n][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, v0, acc[n][0], 0, 0, 0);
-        acc[n][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, v1, acc[n][1], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          acc[n][m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], v0, acc[n][m][0], 0, 0, 0);
+          acc[n][m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], v1, acc[n][m][1], 0, 0, 0);
+        }
       }
     };
-    constexpr int NQ = WW_TY * 16;
-    float2 a0, a1, p0[3], p1[3];
+    float2 a0[2], a1[2], p0[3], p1[3];
     float e0[3], e1[3];
-    lds_ops(0, a0, p0, e0);
+    if (DBG != 2) lds_ops(0, a0, p0, e0);
 #pragma unroll
-    for (int q = 0; q < NQ; q += 2) {
+    for (int q = 0; q < (DBG == 2 ? 0 : 16); q += 2) {
       lds_ops(q + 1, a1, p1, e1);
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, p0, e0);
-      if (q + 2 < NQ) lds_ops(q + 2, a0, p0, e0);
+      if (q + 2 < 16) lds_ops(q + 2, a0, p0, e0);
       __builtin_amdgcn_sched_barrier(0);
       mma(a1, p1, e1);
     }
     __builtin_amdgcn_s_barrier();  // the next brick has landed, everyone is done reading `buf`
     buf ^= 1;
   }
+  };
+  if (wv & 1) kloop(std::integral_constant<int, 1>{}); else kloop(std::integral_constant<int, 0>{});
 
-  // ---- epilogue: this wave's share of G^T dU -> dW[co][ci][kz, ky = n, kx] (float atomics; dW is zero-filled)
+  // ---- epilogue.  The four waves' shares of G^T dU are first combined in LDS (dg[co][ci][ky, kx], 72 KB of the now idle
+  // staging buffers), then added to dW with float atomics whose lanes walk dW's own order (runs of 9 contiguous floats
+  // per (co, ci)).  The first form added every wave's share straight to dW, lane = ci: 18.6 M atomics per launch, each
+  // wave-instruction touching 64 cache lines (108-byte lane stride) -- device-scope atomics are served at the memory
+  // side, and that epilogue alone took 1.0 ms of a 1.6 ms launch (ablation builds).  Now 4.6 M atomics in ~7-line
+  // instructions.
   //   tp 0 (dU_0, dU_1):   kx 0 += dU_0 + dU_1 / 2,  kx 1 += dU_1 / 2,  kx 2 += dU_1 / 2
   //   tp 1 (dU_2, dU_3'):  kx 0 += dU_2 / 2,         kx 1 -= dU_2 / 2,  kx 2 += dU_2 / 2 - dU_3'    (dU_3 = -dU_3')
+  if (DBG == 3) return;
+  float* dg = lds;
+  constexpr int NDG = 64 * 32 * 9;
+  static_assert(NDG <= 2 * WW_BUF, "the combine buffer fits the staging buffers");
+  for (int i = t; i < NDG; i += 256) dg[i] = 0.f;   // (the loaders have left: 256 matrix threads, and the barriers
+  __builtin_amdgcn_s_barrier();                     //  below count the live waves only)
 #pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    const int ci = c0 + l31;
+  for (int n = 0; n < 3; ++n)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      float* dst = dW + ((size_t)co * 64 + ci) * 27 + kz * 9 + n * 3;
-      const float u0 = acc[n][0][r], u1 = acc[n][1][r];
-      if (tp == 0) {
-        atomicAdd(dst + 0, u0 + 0.5f * u1);
-        atomicAdd(dst + 1, 0.5f * u1);
-        atomicAdd(dst + 2, 0.5f * u1);
-      } else {
-        atomicAdd(dst + 0, 0.5f * u0);
-        atomicAdd(dst + 1, -0.5f * u0);
-        atomicAdd(dst + 2, 0.5f * u0 - u1);
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float* dst = dg + (co * 32 + l31) * 9 + n * 3;  // lane stride 9 floats: conflict-free
+        const float u0 = acc[n][m][0][r], u1 = acc[n][m][1][r];
+        if (tp == 0) {
+          atomicAdd(dst + 0, u0 + 0.5f * u1);
+          atomicAdd(dst + 1, 0.5f * u1);
+          atomicAdd(dst + 2, 0.5f * u1);
+        } else {
+          atomicAdd(dst + 0, 0.5f * u0);
+          atomicAdd(dst + 1, -0.5f * u0);
+          atomicAdd(dst + 2, 0.5f * u0 - u1);
+        }
       }
-    }
+  __builtin_amdgcn_s_barrier();
+  for (int i = t; i < NDG; i += 256) {
+    const int co = i / 288, r2 = i - co * 288;
+    const int ci = r2 / 9, k9 = r2 - ci * 9;
+    atomicAdd(dW + ((size_t)co * 64 + c0 + ci) * 27 + kz * 9 + k9, dg[i]);
   }
 }
 
@@ -231,7 +270,11 @@ inline int launch_wrw_wino(const float* G, const float* Src, float* dW, const WP
   long long spw = (p.bricks + slabs - 1) / slabs;
   p.spw = (int)spw;
   const long long gx = (p.bricks + spw - 1) / spw;
-  hipLaunchKernelGGL(conv3d_wrw_wino_kernel, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
+  static const int dbg = getenv("FLOWSCI_WINO_DBG") ? atoi(getenv("FLOWSCI_WINO_DBG")) : 0;
+  if (dbg == 1) hipLaunchKernelGGL(conv3d_wrw_wino_kernel<1>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
+  else if (dbg == 2) hipLaunchKernelGGL(conv3d_wrw_wino_kernel<2>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
+  else if (dbg == 3) hipLaunchKernelGGL(conv3d_wrw_wino_kernel<3>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
+  else hipLaunchKernelGGL(conv3d_wrw_wino_kernel<0>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
