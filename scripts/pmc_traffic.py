@@ -35,6 +35,7 @@ def kernel_sources_sha256():
 
 RULES = [  # (substring of the kernel name, entry point, counts as a launch of the entry point)
     ("conv3d_fwd_kernel", "fs_conv3d_fwd", True), ("conv3d_fwd_ws_kernel", "fs_conv3d_fwd", True),
+    ("conv3d_wino_ws_kernel", "fs_conv3d_fwd", True),
     ("wprep_one_kernel", "fs_conv3d_fwd", False), ("wprep_batch_kernel", "fs_conv3d_wprep_batch", True),
     ("conv3d_wrw_", "fs_conv3d_wrw", True),
     ("convtr_", "fs_conv3d_tr", True),
