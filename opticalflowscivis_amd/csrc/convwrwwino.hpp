@@ -42,6 +42,11 @@ struct WWP {
   int spw;           // bricks per workgroup
 };
 
+// DBG (measurement builds, FLOWSCI_WINO_DBG): 1 = the loaders only keep the barrier protocol, 2 = the matrix waves skip
+// their operand reads and MFMAs.  Measured at 2 x 64^3 (tests/tools/wino_wrw_bench.py, ~0.04 ms of harness included):
+// 0.78 ms as built; matrix waves + epilogue alone 0.79 -> the MFMA work at the kernel's clock is 0.57; loaders +
+// epilogue alone 0.26; the direct kernel 0.96.  Letting the compiler interleave operand reads and transforms with the
+// MFMAs (no sched_barrier, or sched_group_barrier MFMA / DS / VALU triples) changes nothing.
 template <int DBG>
 __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __restrict__ G,
                                                                 const float* __restrict__ Src,
@@ -217,7 +222,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __
   // instructions.
   //   tp 0 (dU_0, dU_1):   kx 0 += dU_0 + dU_1 / 2,  kx 1 += dU_1 / 2,  kx 2 += dU_1 / 2
   //   tp 1 (dU_2, dU_3'):  kx 0 += dU_2 / 2,         kx 1 -= dU_2 / 2,  kx 2 += dU_2 / 2 - dU_3'    (dU_3 = -dU_3')
-  if (DBG == 3) return;
   float* dg = lds;
   constexpr int NDG = 64 * 32 * 9;
   static_assert(NDG <= 2 * WW_BUF, "the combine buffer fits the staging buffers");
@@ -273,7 +277,6 @@ inline int launch_wrw_wino(const float* G, const float* Src, float* dW, const WP
   static const int dbg = getenv("FLOWSCI_WINO_DBG") ? atoi(getenv("FLOWSCI_WINO_DBG")) : 0;
   if (dbg == 1) hipLaunchKernelGGL(conv3d_wrw_wino_kernel<1>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   else if (dbg == 2) hipLaunchKernelGGL(conv3d_wrw_wino_kernel<2>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
-  else if (dbg == 3) hipLaunchKernelGGL(conv3d_wrw_wino_kernel<3>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   else hipLaunchKernelGGL(conv3d_wrw_wino_kernel<0>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
