@@ -43,7 +43,7 @@ RULES = [  # (substring of the kernel name, entry point, counts as a launch of t
     ("warp3d_fwd_kernel<512, true, false>", "fs_warp3d_pair_fwd", True),
     ("prelu_bwd_kernel", "fs_prelu_bwd", True), ("prelu_ga_kernel", "fs_prelu_bwd", False),
     ("merge_fwd_kernel", "fs_merge_fwd", True), ("merge_bwd_kernel", "fs_merge_bwd", True),
-    ("distill3_fwd_kernel", "fs_distill3_fwd", True), ("distill3_bwd_kernel", "fs_distill3_bwd", True),
+    ("distill3_fwd_kernel", "fs_distill_fwd", True), ("distill3_bwd_kernel", "fs_distill_bwd", True),
 ]
 WARP_BWD_ORDER = ["fs_warp3d_pair_bwd", "fs_warp3d_pair_bwd_acc3", "fs_upsample_warp3d_pair_bwd3",
                   "fs_upsample_warp3d_pair_bwd3"]
