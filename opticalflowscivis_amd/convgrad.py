@@ -108,7 +108,7 @@ def _conv_forward(x, w, b, stride, padding, transposed, prelu_weight=None):
 def _conv_grad_input(x, w, gy, stride, padding, transposed):
     nd = x.dim() - 2
     k = tuple(w.shape[2:])
-    if (not transposed and all(s == 1 for s in stride) and all(2 * p == kk - 1 for p, kk in zip(padding, k))):
+    if (nd == 3 and not transposed and all(s == 1 for s in stride) and all(2 * p == kk - 1 for p, kk in zip(padding, k))):
         # stride-1 "same" convolution: its input gradient IS a forward convolution of grad_out with the
         # flipped, channel-transposed filter
         if nd == 3 and _hip_fwd_ok(gy, w.shape[1], x.shape[2:], k, stride, padding):
@@ -357,6 +357,9 @@ def head_fused_ok(head, x, addend):
         (addend is None or (addend.is_cuda and addend.dtype == torch.float32))
 
 
+_FUSE_2D = os.environ.get("FLOWSCI_CONV2D_UNFUSED") != "1"  # A/B switch: 2-D (conv, PReLU) pairs as two stock nodes
+
+
 class ConvPReLU(nn.Sequential):
     """nn.Sequential(conv, PReLU) -- the reference's `conv()` / `deconv()` helpers
     (Flow-3D/model/IFNet.py:13-29) -- with the same children (`0` = convolution, `1` = PReLU: identical
@@ -364,12 +367,17 @@ class ConvPReLU(nn.Sequential):
 
     def forward(self, x):
         conv, act = self[0], self[1]
-        if (_hip_autograd(x) and x.dim() == 5 and x.dtype == torch.float32 and isinstance(conv, (Conv3d, ConvTranspose3d))
+        nd = x.dim() - 2
+        # 3-D: this package's convolution kernels; 2-D (Flow-2D's IFNet): the stock MIOpen convolution inside the same
+        # node, so that the PReLU backward pass (csrc/prelu.hip), which streams the convolution's grad_out anyway, also
+        # delivers its bias gradient -- ATen's separate reduction per layer was 48 launches x 14 us of the C2 step
+        kinds = {3: (Conv3d, ConvTranspose3d), 2: (nn.Conv2d, nn.ConvTranspose2d) if _FUSE_2D else ()}.get(nd, ())
+        if (_hip_autograd(x) and x.dtype == torch.float32 and kinds and isinstance(conv, kinds)
                 and act.weight.numel() in (1, conv.out_channels) and conv.groups == 1
-                and _tuple(conv.dilation, 3) == (1, 1, 1) and getattr(conv, "padding_mode", "zeros") == "zeros"
-                and _tuple(getattr(conv, "output_padding", 0), 3) == (0, 0, 0)):
-            return _ConvPReLUFn.apply(x, conv.weight, conv.bias, act.weight, _tuple(conv.stride, 3),
-                                      _tuple(conv.padding, 3), isinstance(conv, ConvTranspose3d))
+                and _tuple(conv.dilation, nd) == (1,) * nd and getattr(conv, "padding_mode", "zeros") == "zeros"
+                and _tuple(getattr(conv, "output_padding", 0), nd) == (0,) * nd):
+            return _ConvPReLUFn.apply(x, conv.weight, conv.bias, act.weight, _tuple(conv.stride, nd),
+                                      _tuple(conv.padding, nd), isinstance(conv, kinds[1]))
         return act(conv(x))
 
 

@@ -24,10 +24,10 @@ _INTERP = {2: "bilinear", 3: "trilinear"}
 
 
 def _conv(nd, cin, cout, kernel_size=3, stride=1, padding=1):
-    # Sequential(conv, PReLU) as in the reference (same keys / init order); in 3-D the pair trains as one
-    # fused autograd node (convgrad.ConvPReLU)
-    seq = convgrad.ConvPReLU if nd == 3 else nn.Sequential
-    return seq(_CONV[nd](cin, cout, kernel_size, stride, padding, bias=True), convgrad.PReLU(cout))
+    # Sequential(conv, PReLU) as in the reference (same keys / init order); the pair trains as one autograd node
+    # (convgrad.ConvPReLU: fused epilogues on the 3-D kernels; in 2-D the stock MIOpen convolution with its bias
+    # gradient taken from the PReLU backward pass)
+    return convgrad.ConvPReLU(_CONV[nd](cin, cout, kernel_size, stride, padding, bias=True), convgrad.PReLU(cout))
 
 
 class _Head(nn.Sequential):
@@ -43,7 +43,7 @@ class _Head(nn.Sequential):
                                               self[2].bias, addend)
             h = convgrad.ConvPReLU.forward(self, x)
             return self[2](h) if addend is None else self[2](h, addend)
-        y = super().forward(x)
+        y = self[2](convgrad.ConvPReLU.forward(self, x))  # 2-D: stock kernels, (deconv, PReLU) as one node
         return y if addend is None else y + addend
 
 
