@@ -613,6 +613,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
 }
 
 #include "convwino.hpp"
+#include "convwino4.hpp"
 
 template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
 int launch_ws(const float* X, const float* Wt, const float* bias, float* Y, FP& p, hipStream_t st) {
@@ -699,7 +700,8 @@ extern "C" long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel) {
   int cinp, coutp;
   wt_dims(Cin, Cout, kernel, &cinp, &coutp);
   const long long direct = (long long)cinp * kernel * kernel * kernel * coutp;
-  const long long wino = (kernel == 3 && coutp == 64) ? (long long)cinp * FS_WINO_UCH : 0;  // the F(2,3) slab is 4/3 larger
+  // the Winograd slabs of the 64-channel k3 layers are larger: F(2,3) 4/3, F(4,3) twice the taps
+  const long long wino = (kernel == 3 && coutp == 64) ? (long long)cinp * (FS_WINO4_UCH > FS_WINO_UCH ? FS_WINO4_UCH : FS_WINO_UCH) : 0;
   return direct > wino ? direct : wino;
 }
 
@@ -774,6 +776,15 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   const int K3 = kernel * kernel * kernel;
   // the 64-channel k3 layers of the 64^3 trunk: 1-D Winograd F(2,3) along x (convwino.hpp), its own filter slab
   p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+  // ... F(4,3) (convwino4.hpp: half the direct form's multiply-adds) where its 4 x 2 x 64 bricks fill the chip
+  if (wino4_ok(p, x, ws, Cin, Cout, kernel, stride, ms != nullptr) &&
+      (dp == nullptr || (bias == nullptr && z == nullptr && addend == nullptr))) {
+    wprep_do(wprep_job(FS_WPREP_WINO4, w, ws, (long long)cinp * FS_WINO4_UCH, Cout, Cin, cinp, wmode), plan, st);
+    if (plan != nullptr) return FS_OK;
+    const int rc = launch_wino4(x, ws, bias, y, p, st);
+    if (rc != FS_OK || dp == nullptr) return rc;
+    return dp_finish(64);
+  }
   if (wino_ok(p, x, ws, Cin, Cout, kernel, stride, ms != nullptr) &&
       (dp == nullptr || (bias == nullptr && z == nullptr && addend == nullptr))) {
     wprep_do(wprep_job(FS_WPREP_WINO, w, ws, (long long)cinp * FS_WINO_UCH, Cout, Cin, cinp, wmode), plan, st);

@@ -14,8 +14,11 @@
 //   FS_WPREP_P8   p = {Cin, Cout, CinP, RT}                 W'[ci][neighbour][row] (+16 pad) of the all-parities kernel
 //   FS_WPREP_WINO p = {Cout, Cin, CinP, mode}              Ut[ci][kz*3+ky][t 0..3][co 0..63] (+16 pad per ci): the F(2,3)
 //       filter transform along kx of the taps FS_WPREP_FWD would deliver (same two modes)          (convwino.hpp)
-enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4 };
+//   FS_WPREP_WINO4 p = {Cout, Cin, CinP, mode}             Ut[ci][kz*3+ky][t 0..5][co 0..63]: the F(4,3) filter transform
+//       (points 0, +-1, +-2, inf) of the same taps                                                  (convwino4.hpp)
+enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4, FS_WPREP_WINO4 = 5 };
 constexpr int FS_WINO_UCH = 9 * 4 * 64 + 16;  // floats per input channel of the Winograd slab (== WN_UCH)
+constexpr int FS_WINO4_UCH = 9 * 6 * 64;      // ... of the F(4,3) slab (== W4_UCH)
 
 __host__ __device__ constexpr int wprep_p8_k(int par, int d) { return par == 0 ? (d == 0 ? 1 : 3) : (d == 0 ? 0 : 2); }
 
@@ -51,6 +54,26 @@ __device__ __forceinline__ float wprep_elem(const FsWprepJob& j, int e) {
       for (int kx = 0; kx < 3; ++kx)
         g[kx] = mode ? w[((size_t)ci * Cout + co) * 27 + (26 - (kk * 3 + kx))] : w[((size_t)co * Cin + ci) * 27 + kk * 3 + kx];
       return tt == 0 ? g[0] : tt == 1 ? 0.5f * ((g[0] + g[1]) + g[2]) : tt == 2 ? 0.5f * ((g[0] - g[1]) + g[2]) : g[2];
+    }
+    case FS_WPREP_WINO4: {
+      const int Cout = j.p[0], Cin = j.p[1], mode = j.p[3];
+      const int ci = e / FS_WINO4_UCH, i = e - ci * FS_WINO4_UCH;
+      if (ci >= Cin) return 0.f;
+      const int kk = i / 384, r = i - kk * 384;
+      const int tt = r >> 6, co = r & 63;
+      if (co >= Cout) return 0.f;
+      float g[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        g[kx] = mode ? w[((size_t)ci * Cout + co) * 27 + (26 - (kk * 3 + kx))] : w[((size_t)co * Cin + ci) * 27 + kk * 3 + kx];
+      switch (tt) {
+        case 0: return 0.25f * g[0];
+        case 1: return (-1.f / 6.f) * ((g[0] + g[2]) + g[1]);
+        case 2: return (-1.f / 6.f) * ((g[0] + g[2]) - g[1]);
+        case 3: return (1.f / 24.f) * g[0] + ((1.f / 12.f) * g[1] + (1.f / 6.f) * g[2]);
+        case 4: return (1.f / 24.f) * g[0] + ((-1.f / 12.f) * g[1] + (1.f / 6.f) * g[2]);
+        default: return g[2];
+      }
     }
     default: {  // FS_WPREP_P8
       const int Cin = j.p[0], Cout = j.p[1], RT = j.p[3];

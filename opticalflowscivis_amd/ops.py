@@ -1590,16 +1590,17 @@ def _prepared(w, nfloats, key, plan):
 _wino_seen = {}
 
 
-def _fwd_takes_winograd(xptr, B, Cin, Cout, dhw, wmode):
-    """Does fs_conv3d_fwd* run this k3 s1 p1 call as the 1-D Winograd F(2,3) kernel (csrc/convwino.hpp)?  Asked of
-    the library's own dispatch (its re-layout plan), cached per geometry; only the flop accounting of the timing
-    records depends on it: that kernel EXECUTES 2/3 of the direct formulation's multiply-adds."""
+def _fwd_k3_macs(xptr, B, Cin, Cout, dhw, wmode):
+    """Multiply-adds per output and input channel that fs_conv3d_fwd* EXECUTES for this k3 s1 p1 call: 27 as a direct
+    implicit GEMM, 18 as the 1-D Winograd F(2,3) kernel (csrc/convwino.hpp), 13.5 as F(4,3) (csrc/convwino4.hpp).
+    Asked of the library's own dispatch (its re-layout plan), cached per geometry; only the flop accounting of the
+    timing records depends on it."""
     key = (xptr % 16, B, Cin, Cout) + tuple(int(v) for v in dhw) + (int(wmode),)
     if key not in _wino_seen:
         buf = (_lib.FsWprepJob * 4)()
         n = _lib.lib().fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000 + xptr % 16, 0x1000, 0x1000, B, Cin, Cout, *key[4:7],
                                                 *key[4:7], 3, 1, 1, int(wmode))
-        _wino_seen[key] = (n == 1 and buf[0].kind == 4)
+        _wino_seen[key] = {4: 18.0, 5: 13.5}.get(buf[0].kind, 27.0) if n == 1 else 27.0
     return _wino_seen[key]
 
 
@@ -1829,7 +1830,7 @@ def conv3d_k3_grad_input_dprelu(gy, w, act_y, prelu_weight):
         rc = _call_rc("fs_conv3d_fwd_dprelu", gy.data_ptr(), wp, act_y.data_ptr(), a.data_ptr(), a.numel(),
                       out.data_ptr(), ga.data_ptr(), gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, Cg, Cx, D, H, W,
                       D, H, W, 3, 1, 1, _stream(gy), algo_bytes=4 * (gy.numel() + 2 * out.numel()),
-                      algo_flops=2 * out.numel() * Cg * (18 if _fwd_takes_winograd(gy.data_ptr(), B, Cg, Cx, (D, H, W), 1) else 27),
+                      algo_flops=int(2 * out.numel() * Cg * _fwd_k3_macs(gy.data_ptr(), B, Cg, Cx, (D, H, W), 1)),
                       equiv_flops=2 * out.numel() * Cg * 27, record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
     if rc == FS_ERR_UNSUPPORTED:
         return None
@@ -1881,8 +1882,9 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
     y = x.new_empty((B, Cout, Do, Ho, Wo))
     wp, ws = _prepared_fwd(w, x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), (Do, Ho, Wo), k, stride, pad, wmode)
     nb, fq = 4 * (x.numel() + y.numel()), 2 * y.numel() * Cin * int(k) ** 3
-    fl = fq * 2 // 3 if (int(k) == 3 and int(stride) == 1 and int(pad) == 1 and
-                         _fwd_takes_winograd(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), wmode)) else fq
+    fl = fq
+    if int(k) == 3 and int(stride) == 1 and int(pad) == 1:  # the Winograd forms execute fewer multiply-adds
+        fl = int(2 * y.numel() * Cin * _fwd_k3_macs(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), wmode))
     if addend is not None:
         addend = _need_cuda_f32("addend", addend, 5)
         if addend.shape != y.shape:

@@ -1,8 +1,9 @@
-"""-m gpu: the 1-D Winograd F(2,3) form of the 64-channel k3 trunk convolutions (csrc/convwino.hpp) against fp64:
-every fused epilogue (bias, PReLU output + residual addend, plain addend, the PReLU-backward form), both weight modes
-(forward taps / flipped + transposed for the input gradient), volume edges that are not multiples of the 2 x 2 brick,
-channel counts below the 64-row tile.  The transform's coefficients are +-1 and 1/2: the error against fp64 stays
-within 2x the direct kernel's bound (3e-5 of the output's magnitude)."""
+"""-m gpu: the 1-D Winograd forms of the 64-channel k3 trunk convolutions -- F(2,3) (csrc/convwino.hpp) and F(4,3)
+(csrc/convwino4.hpp, taken where its larger bricks fill the chip) -- against fp64: every fused epilogue (bias, PReLU output
++ residual addend, plain addend, the PReLU-backward form), both weight modes (forward taps / flipped + transposed for
+the input gradient), volume edges that are not multiples of the brick, channel counts below the 64-row tile.  F(2,3)'s
+coefficients are +-1 and 1/2, F(4,3)'s reach 8 and 1/24: the error against fp64 stays within 2x the direct kernel's
+bound (3e-5 of the output's magnitude) for both."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -18,26 +19,41 @@ def ops():
     return o
 
 
-def _is_wino(ops, x, w, cin, cout, size, wmode):
-    """The library's own dispatch: does this call take the Winograd slab (FsWprepJob kind 4)?"""
+def _slab_kind(ops, x, w, cin, cout, size, wmode):
+    """The library's own dispatch: which filter slab does this call take (FsWprepJob kind: 0 direct taps, 4 the F(2,3)
+    transform, 5 the F(4,3) transform)?"""
     from opticalflowscivis_amd import _lib
     L = _lib.lib()
     buf = (_lib.FsWprepJob * 4)()
     ws = torch.empty(int(L.fs_conv3d_fwd_ws_floats(cin, cout, 3)), device=DEV)
     n = L.fs_conv3d_fwd_wprep_jobs(buf, 4, x.data_ptr(), w.data_ptr(), ws.data_ptr(), x.shape[0], cin, cout, *size, *size,
                                    3, 1, 1, wmode)
-    return n == 1 and buf[0].kind == 4
+    assert n == 1
+    return buf[0].kind
+
+
+def _expected_kind(B, size):
+    """F(4,3) where its 4 x 2 x 64 bricks give every CU two rounds, else F(2,3) on 2 x 2 x 64 bricks."""
+    D, H, W = size
+    return 5 if B * ((D + 3) // 4) * ((H + 1) // 2) * (W // 64) >= 512 else 4
+
+
+def _is_wino(ops, x, w, cin, cout, size, wmode):
+    return _slab_kind(ops, x, w, cin, cout, size, wmode) in (4, 5)
 
 
 @pytest.mark.parametrize("B,cin,cout,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (33, 31, 64)), (2, 8, 20, (32, 32, 64)),
-                                             (2, 64, 64, (16, 32, 128)), (2, 12, 64, (64, 64, 64))])
+                                             (2, 64, 64, (16, 32, 128)), (2, 12, 64, (64, 64, 64)),
+                                             # F(4,3) bricks (4 x 2 x 64): whole, ragged in z and y, few channels, two x bricks
+                                             (2, 64, 64, (64, 32, 64)), (2, 64, 64, (62, 33, 64)), (2, 8, 20, (64, 32, 64)),
+                                             (2, 64, 64, (32, 32, 128))])
 def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
     g = torch.Generator().manual_seed(cin * 100 + size[0])
     x = torch.randn((B, cin) + size, generator=g)
     w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
     b = torch.randn(cout, generator=g)
     xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
-    assert _is_wino(ops, xd, wd, cin, cout, size, 0)
+    assert _slab_kind(ops, xd, wd, cin, cout, size, 0) == _expected_kind(B, size)
     ref = F.conv3d(x.double(), w.double(), b.double(), 1, 1)
     scale = float(ref.abs().max())
     got = ops.conv3d_fwd(xd, wd, bd, 3, 1, 1, 0)
@@ -57,7 +73,8 @@ def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
     assert float((got.cpu().double() - (ref + add.double())).abs().max()) < TOL * max(scale, float((ref + add.double()).abs().max()))
 
 
-@pytest.mark.parametrize("B,cg,cx,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (33, 34, 64)), (2, 64, 32, (32, 32, 64))])
+@pytest.mark.parametrize("B,cg,cx,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (33, 34, 64)), (2, 64, 32, (32, 32, 64)),
+                                          (2, 64, 64, (64, 32, 64)), (2, 64, 64, (61, 35, 64)), (2, 64, 32, (64, 32, 64))])
 def test_wino_input_gradient_and_prelu_backward_vs_fp64(ops, B, cg, cx, size):
     """wmode 1: the layer weight [Cout_layer = cg][Cin_layer = cx] read flipped + transposed; and the same convolution
     with the PReLU backward as its epilogue (fs_conv3d_fwd_dprelu, kernel 3)."""
@@ -65,7 +82,7 @@ def test_wino_input_gradient_and_prelu_backward_vs_fp64(ops, B, cg, cx, size):
     gy = torch.randn((B, cg) + size, generator=g)
     w = torch.randn(cg, cx, 3, 3, 3, generator=g) / (cg * 27) ** 0.5
     gyd, wd = gy.to(DEV), w.to(DEV)
-    assert _is_wino(ops, gyd, wd, cg, cx, size, 1)
+    assert _slab_kind(ops, gyd, wd, cg, cx, size, 1) == _expected_kind(B, size)
     ref = F.conv3d(gy.double(), w.transpose(0, 1).flip(2, 3, 4).double(), None, 1, 1)
     scale = float(ref.abs().max())
     got = ops.conv3d_fwd(gyd, wd, None, 3, 1, 1, 1)
