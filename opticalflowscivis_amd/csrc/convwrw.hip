@@ -613,6 +613,7 @@ int launch_dma(const float* G, const float* Src, float* dW, const WP& w, hipStre
 }
 
 #include "convwrwwino.hpp"
+#include "convwrwwino4.hpp"
 
 }  // namespace
 
@@ -666,7 +667,8 @@ static int conv3d_wrw_impl(const float* g, const float* src, const float* const*
     if (dma_ok && kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) return launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st);
     return FS_ERR_UNSUPPORTED;
   }
-  // the 64 -> 64 k3 layers of the 64^3 trunk: the Winograd F(2,3) form (convwrwwino.hpp)
+  // the 64 -> 64 k3 layers of the 64^3 trunk: the Winograd F(4,3) form (convwrwwino4.hpp), or F(2,3) (convwrwwino.hpp)
+  if (dma_ok && wrw_wino4_ok(p, g, src, kernel, stride)) return launch_wrw_wino4(g, src, dw, p, st);
   if (dma_ok && wrw_wino_ok(p, g, src, kernel, stride)) return launch_wrw_wino(g, src, dw, p, st);
   if (dma_ok) {
     if (kernel == 3 && Cg > 32 && Cs >= 8 && Wo == 16) return launch_dma<3, 1, 16, 2, 1, 4, 3, 1, 16>(g, src, dw, p, st);

@@ -42,6 +42,84 @@ struct WWP {
   int spw;           // bricks per workgroup
 };
 
+// The loader waves (4-7) of the Winograd-domain weight-gradient kernels: per position brick, the RAW gradient rows
+// [64][2 rows x 64] and the source rows z + kz - 1, y - 1 .. y + 2 of 32 channels (4 floats of margin left and right)
+// by `buffer_load_dwordx4 ... lds`, one brick ahead of the matrix waves, one barrier per brick.
+template <int DBG>
+__device__ __forceinline__ void ww_loader_waves(const float* __restrict__ G, const float* __restrict__ Src, const WWP& p,
+                                                float* lds, int wv, int lane, int kz, int c0, long long s0, long long s1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NGP = (WW_NG / 4 + 63) / 64, NSP = (WW_NS / 4 + 63) / 64;  // 16-byte pieces in wave-instructions
+  constexpr int NGW = (NGP + 3) / 4, NSW = (NSP + 3) / 4;
+  const size_t vol = (size_t)p.D * p.H * p.W;
+  const int bxn = p.W / 64;
+  // piece k of loader wave wv fills the 16-byte slots 64 (wv + 4 k) + lane of an image
+  unsigned goff[NGW], soff[NSW];
+  int srow[NSW], sx[NSW];
+#pragma unroll
+  for (int k = 0; k < NGW; ++k) {
+    const int f = (64 * (wv + 4 * k) + lane) * 4;
+    const int co = f / WW_GP, w = f - co * WW_GP;
+    const int row = w / 64, x = w % 64;
+    goff[k] = (f < WW_NG && w < WW_TY * 64) ? ((unsigned)co * (unsigned)vol + (unsigned)(row * p.W + x)) * 4u : DMA_OOB;
+  }
+#pragma unroll
+  for (int k = 0; k < NSW; ++k) {
+    const int f = (64 * (wv + 4 * k) + lane) * 4;
+    const int c = f / WW_CHS, r = f - c * WW_CHS;
+    const int y = r / WW_XP, x = r - y * WW_XP;  // staged row y = source row oy0 - 1 + y, column ox0 - 4 + x
+    const bool ok = f < WW_NS && r < (WW_TY + 2) * WW_XP;
+    soff[k] = ok ? ((unsigned)c * (unsigned)vol + (unsigned)(y * p.W + x)) * 4u : DMA_OOB;
+    srow[k] = y;
+    sx[k] = x;
+  }
+  int bxi, byi, z, b;
+  {
+    long long q = s0;
+    bxi = (int)(q % bxn); q /= bxn;
+    byi = (int)(q % p.by); q /= p.by;
+    z = (int)(q % p.D);
+    b = (int)(q / p.D);
+  }
+  auto stage = [&](int buf) {
+    if (DBG == 1) return;
+    const int oy0 = byi * WW_TY, ox0 = bxi * 64;
+    float* dbase = lds + buf * WW_BUF;
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(G + (size_t)b * 64 * vol), (short)0, 0x7fffffff, 0x00020000);
+    const unsigned pos0 = (unsigned)(((z * p.H + oy0) * p.W + ox0) * 4);
+#pragma unroll
+    for (int k = 0; k < NGW; ++k)
+      if (wv + 4 * k < NGP)  // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(dbase + 256 * (wv + 4 * k)), 16, goff[k], pos0, 0, 0);
+    // source rows of plane z + kz - 1 (all zero when that plane is outside the volume)
+    const int sz = z + kz - 1;
+    const bool zok = sz >= 0 && sz < p.D;
+    const long long org = ((long long)(zok ? sz : 0) * p.H + (oy0 - 1)) * p.W + (ox0 - 4);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Src + ((size_t)b * 64 + c0) * vol + org), (short)0,
+                                                                   zok ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NSW; ++k)
+      if (wv + 4 * k < NSP) {  // wave-uniform
+        const int gy = oy0 - 1 + srow[k], gx = ox0 - 4 + sx[k];
+        const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;  // W % 64 == 0: a 16-byte piece is in or out whole
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dbase + WW_NG + 256 * (wv + 4 * k)), 16,
+                                                 in ? soff[k] : DMA_OOB, 0, 0, 0);
+      }
+    if (++bxi == bxn) { bxi = 0; if (++byi == p.by) { byi = 0; if (++z == p.D) { z = 0; ++b; } } }
+  };
+  if (s0 < s1) stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (long long st = s0; st < s1; ++st) {
+    if (st + 1 < s1) stage(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf ^= 1;
+  }
+#endif
+}
+
 // DBG (measurement builds, FLOWSCI_WINO_DBG): 1 = the loaders only keep the barrier protocol, 2 = the matrix waves skip
 // their operand reads and MFMAs.  Measured at 2 x 64^3 (tests/tools/wino_wrw_bench.py, ~0.04 ms of harness included):
 // 0.78 ms as built; matrix waves + epilogue alone 0.79 -> the MFMA work at the kernel's clock is 0.57; loaders +
@@ -52,8 +130,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __
                                                                 const float* __restrict__ Src,
                                                                 float* __restrict__ dW, WWP p) {
   static_assert(2 * WW_BUF * 4 <= 160 * 1024 && (WW_NG % 4) == 0 && (WW_NS % 4) == 0, "two aligned buffers in LDS");
-  constexpr int NGP = (WW_NG / 4 + 63) / 64, NSP = (WW_NS / 4 + 63) / 64;  // 16-byte pieces in wave-instructions
-  constexpr int NGW = (NGP + 3) / 4, NSW = (NSP + 3) / 4;
   __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -61,80 +137,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __
   const int wv = wave & 3;
   const int kz = blockIdx.y % 3, chalf = blockIdx.y / 3;  // column group: kz, source-channel half
   const int c0 = chalf * 32;
-  const size_t vol = (size_t)p.D * p.H * p.W;
   const long long s0 = (long long)blockIdx.x * p.spw;
   const long long s1 = min(s0 + (long long)p.spw, p.bricks);
-  const int bxn = p.W / 64;
 
   if (wave >= 4) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // piece k of loader wave wv fills the 16-byte slots 64 (wv + 4 k) + lane of an image
-    unsigned goff[NGW], soff[NSW];
-    int srow[NSW], sx[NSW];
-#pragma unroll
-    for (int k = 0; k < NGW; ++k) {
-      const int f = (64 * (wv + 4 * k) + lane) * 4;
-      const int co = f / WW_GP, w = f - co * WW_GP;
-      const int row = w / 64, x = w % 64;
-      goff[k] = (f < WW_NG && w < WW_TY * 64) ? ((unsigned)co * (unsigned)vol + (unsigned)(row * p.W + x)) * 4u : DMA_OOB;
-    }
-#pragma unroll
-    for (int k = 0; k < NSW; ++k) {
-      const int f = (64 * (wv + 4 * k) + lane) * 4;
-      const int c = f / WW_CHS, r = f - c * WW_CHS;
-      const int y = r / WW_XP, x = r - y * WW_XP;  // staged row y = source row oy0 - 1 + y, column ox0 - 4 + x
-      const bool ok = f < WW_NS && r < (WW_TY + 2) * WW_XP;
-      soff[k] = ok ? ((unsigned)c * (unsigned)vol + (unsigned)(y * p.W + x)) * 4u : DMA_OOB;
-      srow[k] = y;
-      sx[k] = x;
-    }
-    int bxi, byi, z, b;
-    {
-      long long q = s0;
-      bxi = (int)(q % bxn); q /= bxn;
-      byi = (int)(q % p.by); q /= p.by;
-      z = (int)(q % p.D);
-      b = (int)(q / p.D);
-    }
-    auto stage = [&](int buf) {
-      if (DBG == 1) return;
-      const int oy0 = byi * WW_TY, ox0 = bxi * 64;
-      float* dbase = lds + buf * WW_BUF;
-      __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(G + (size_t)b * 64 * vol), (short)0, 0x7fffffff, 0x00020000);
-      const unsigned pos0 = (unsigned)(((z * p.H + oy0) * p.W + ox0) * 4);
-#pragma unroll
-      for (int k = 0; k < NGW; ++k)
-        if (wv + 4 * k < NGP)  // wave-uniform
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(dbase + 256 * (wv + 4 * k)), 16, goff[k], pos0, 0, 0);
-      // source rows of plane z + kz - 1 (all zero when that plane is outside the volume)
-      const int sz = z + kz - 1;
-      const bool zok = sz >= 0 && sz < p.D;
-      const long long org = ((long long)(zok ? sz : 0) * p.H + (oy0 - 1)) * p.W + (ox0 - 4);
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Src + ((size_t)b * 64 + c0) * vol + org), (short)0,
-                                                                     zok ? 0x7fffffff : 0, 0x00020000);
-#pragma unroll
-      for (int k = 0; k < NSW; ++k)
-        if (wv + 4 * k < NSP) {  // wave-uniform
-          const int gy = oy0 - 1 + srow[k], gx = ox0 - 4 + sx[k];
-          const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;  // W % 64 == 0: a 16-byte piece is in or out whole
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dbase + WW_NG + 256 * (wv + 4 * k)), 16,
-                                                   in ? soff[k] : DMA_OOB, 0, 0, 0);
-        }
-      if (++bxi == bxn) { bxi = 0; if (++byi == p.by) { byi = 0; if (++z == p.D) { z = 0; ++b; } } }
-    };
-    if (s0 < s1) stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    for (long long st = s0; st < s1; ++st) {
-      if (st + 1 < s1) stage(buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      buf ^= 1;
-    }
-#else
-    (void)vol; (void)NGW; (void)NSW; (void)bxn;
-#endif
+    ww_loader_waves<DBG>(G, Src, p, lds, wv, lane, kz, c0, s0, s1);
     return;
   }
 

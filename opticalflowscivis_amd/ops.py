@@ -1655,13 +1655,15 @@ def conv3d_wrw(g, src, k, stride, pad):
         _call("fs_conv3d_wrw", g.data_ptr(), src.data_ptr(), dw.data_ptr(), B, Cg, Cs, g.shape[2],
               g.shape[3], g.shape[4], src.shape[2], src.shape[3], src.shape[4], int(k), int(stride),
               int(pad), _stream(g), algo_bytes=4 * (g.numel() + src.numel()),
-              algo_flops=fq * 2 // 3 if wino else fq, equiv_flops=fq)
+              algo_flops=(fq * 2 // 3 if _os.environ.get("FLOWSCI_WRW_NO_WINO4") is not None else fq // 2) if wino else fq,
+              equiv_flops=fq)
     return dw
 
 
 def conv3d_wrw_takes_winograd(B, Cg, Cs, g_dhw, src_dhw, k, stride, pad, g_misalign=0, src_misalign=0):
-    """Does fs_conv3d_wrw run this call in the Winograd F(2,3) domain (csrc/convwrwwino.hpp)?  Mirrors
-    `wrw_wino_ok` there (the weight gradient has no re-layout plan to ask): the 64 -> 64 k3 s1 p1 layers with rows
+    """Does fs_conv3d_wrw run this call in a Winograd domain (F(4,3), csrc/convwrwwino4.hpp: half the direct form's
+    multiply-adds; F(2,3), csrc/convwrwwino.hpp, two thirds, with FLOWSCI_WRW_NO_WINO4 set)?  Mirrors `wrw_wino_ok`
+    there (the weight gradient has no re-layout plan to ask): the 64 -> 64 k3 s1 p1 layers with rows
     of 64 x, an even number of y rows, >= 1024 position bricks, 16-byte aligned operands.  Only the flop accounting
     of the timing records depends on it."""
     import os

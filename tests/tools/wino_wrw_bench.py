@@ -18,5 +18,7 @@ for _ in range(20):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 fl = 2 * g.numel() * 64 * 27
-print("wrw: %.3f ms/launch (incl. the zero fill) = %.1f TFLOP/s direct-equivalent; dW abs sum %.6e [FLOWSCI_WRW_NO_WINO=%s]" % (
-    ms, fl / ms / 1e9, float(dw.double().abs().sum()), os.environ.get("FLOWSCI_WRW_NO_WINO", "")), flush=True)
+print("wrw: %.3f ms/launch (incl. the zero fill) = %.1f TFLOP/s direct-equivalent; dW abs sum %.6e "
+      "[FLOWSCI_WRW_NO_WINO=%s FLOWSCI_WRW_NO_WINO4=%s]" % (
+          ms, fl / ms / 1e9, float(dw.double().abs().sum()), os.environ.get("FLOWSCI_WRW_NO_WINO", ""),
+          os.environ.get("FLOWSCI_WRW_NO_WINO4", "")), flush=True)
