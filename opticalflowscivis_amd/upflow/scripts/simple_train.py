@@ -19,26 +19,43 @@ from ..model.upflow import UPFlow_net
 
 
 class Loss_manager:
-    """simple_train.py:65-95: sums whichever terms the network produced."""
+    """simple_train.py:65-95: sums whichever terms the network produced.  The reference reads every term back with
+    `.item()` as it is formed (three host synchronisations per step); here the running sums stay on the device -- one
+    stack + one add per step -- and are read when `log_info()` is asked for them: same log line, a step without host
+    synchronisation (and therefore capturable into a HIP graph)."""
     NAMES = ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss', 'eq_loss', 'oi_loss')
 
     def __init__(self):
-        self.sums, self.count = {}, 0
+        self.prepare_epoch()
 
     def prepare_epoch(self):
-        self.sums, self.count = {}, 0
+        self.names, self.acc, self.count = None, None, 0
 
     def compute_loss(self, loss_dict, batch_N):
         loss = 0
+        names, vals = [], []
         for name in self.NAMES:
             v = loss_dict.get(name)
             if v is None:
                 continue
             v = v.mean()
-            self.sums[name] = self.sums.get(name, 0.0) + float(v.detach()) * batch_N
+            names.append(name)
+            vals.append(v.detach())
             loss = loss + v
+        if vals:
+            if self.names != names:  # first step of an epoch (or the set of terms changed: start over)
+                self.names, self.count = names, 0
+                self.acc = torch.zeros(len(names), dtype=torch.float64, device=vals[0].device)
+            self.acc.add_(torch.stack(vals), alpha=batch_N)
         self.count += batch_N
         return loss
+
+    @property
+    def sums(self):
+        """{term: sum over the epoch's samples} as Python floats (synchronises)."""
+        if self.acc is None:
+            return {}
+        return dict(zip(self.names, self.acc.tolist()))
 
     def log_info(self):
         return " ".join("%s:%.4f" % (k, v / max(self.count, 1)) for k, v in self.sums.items())
