@@ -1,5 +1,6 @@
-"""fs_conv3d_fwd on the 64 -> 64 k3 layer of the 64^3 trunk (B = 2): the Winograd F(2,3) kernel vs the direct
-loader-wave kernel (FLOWSCI_FWD_NO_WINO=1 in a second process), time and error against fp64 on a sub-volume."""
+"""fs_conv3d_fwd on the 64 -> 64 k3 layer of the 64^3 trunk (B = 2): the Winograd F(4,3) kernel vs F(2,3)
+(FLOWSCI_FWD_NO_WINO4=1) vs the direct loader-wave kernel (FLOWSCI_FWD_NO_WINO=1), each in its own process: time and
+error against fp64 on a sub-volume."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -25,4 +26,5 @@ for wmode in (0, 1):
     err = float((y[:1, :, 1:9].double() - ref).abs().max()) / float(ref.abs().max())
     fl = 2 * y.numel() * 64 * 27
     print("wmode %d: %.3f ms/launch (incl. the weight re-layout launch) = %.1f TFLOP/s direct-equivalent; max err vs fp64 %.2e "
-          "[FLOWSCI_FWD_NO_WINO=%s]" % (wmode, ms, fl / ms / 1e9, err, os.environ.get("FLOWSCI_FWD_NO_WINO", "")), flush=True)
+          "[FLOWSCI_FWD_NO_WINO=%s FLOWSCI_FWD_NO_WINO4=%s]" % (wmode, ms, fl / ms / 1e9, err, os.environ.get("FLOWSCI_FWD_NO_WINO", ""),
+                                                                 os.environ.get("FLOWSCI_FWD_NO_WINO4", "")), flush=True)
