@@ -614,6 +614,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
 
 #include "convwino.hpp"
 #include "convwino4.hpp"
+#include "convwino2d.hpp"
 
 template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
 int launch_ws(const float* X, const float* Wt, const float* bias, float* Y, FP& p, hipStream_t st) {
@@ -701,7 +702,8 @@ extern "C" long long fs_conv3d_fwd_ws_floats(int Cin, int Cout, int kernel) {
   wt_dims(Cin, Cout, kernel, &cinp, &coutp);
   const long long direct = (long long)cinp * kernel * kernel * kernel * coutp;
   // the Winograd slabs of the 64-channel k3 layers are larger: F(2,3) 4/3, F(4,3) twice the taps
-  const long long wino = (kernel == 3 && coutp == 64) ? (long long)cinp * (FS_WINO4_UCH > FS_WINO_UCH ? FS_WINO4_UCH : FS_WINO_UCH) : 0;
+  constexpr int wino_uch = FS_WINO2D_UCH > FS_WINO4_UCH ? FS_WINO2D_UCH : (FS_WINO4_UCH > FS_WINO_UCH ? FS_WINO4_UCH : FS_WINO_UCH);
+  const long long wino = (kernel == 3 && coutp == 64) ? (long long)cinp * wino_uch : 0;
   return direct > wino ? direct : wino;
 }
 
@@ -764,8 +766,8 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   hipStream_t st = (hipStream_t)stream;
   // after a loader-wave launch with the fused PReLU-backward epilogue: finish its partial sums (CP = channels per
   // workgroup; the stage-1 partials live behind the rows in `part`, 8-byte aligned)
-  auto dp_finish = [&](int CP) {
-    const long long rows = p.tiles * 4;
+  auto dp_finish = [&](int CP, int rows_per_brick = 4) {
+    const long long rows = p.tiles * rows_per_brick;
     const int mg = p.CoutP / CP;
     double* partial = reinterpret_cast<double*>(dp->part + (rows * mg * CP * 2 + 1) / 2 * 2);
     hipLaunchKernelGGL(dprelu_finish1_kernel, dim3(kFinishBlocks, mg), dim3(256), 0, st, dp->part, (int)rows, CP, partial);
@@ -776,6 +778,15 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
   const int K3 = kernel * kernel * kernel;
   // the 64-channel k3 layers of the 64^3 trunk: 1-D Winograd F(2,3) along x (convwino.hpp), its own filter slab
   p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+  // ... F(2,3) along y x F(4,3) along x (convwino2d.hpp: a third of the direct form's multiply-adds) on the 64^3 trunk
+  if (wino2d_ok(p, x, ws, Cin, Cout, kernel, stride, ms != nullptr) &&
+      (dp == nullptr || (bias == nullptr && z == nullptr && addend == nullptr))) {
+    wprep_do(wprep_job(FS_WPREP_WINO2D, w, ws, (long long)cinp * FS_WINO2D_UCH, Cout, Cin, cinp, wmode), plan, st);
+    if (plan != nullptr) return FS_OK;
+    const int rc = launch_wino2d(x, ws, bias, y, p, st);
+    if (rc != FS_OK || dp == nullptr) return rc;
+    return dp_finish(64, 1);
+  }
   // ... F(4,3) (convwino4.hpp: half the direct form's multiply-adds) where its 4 x 2 x 64 bricks fill the chip
   if (wino4_ok(p, x, ws, Cin, Cout, kernel, stride, ms != nullptr) &&
       (dp == nullptr || (bias == nullptr && z == nullptr && addend == nullptr))) {

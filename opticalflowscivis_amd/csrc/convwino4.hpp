@@ -271,7 +271,8 @@ inline bool wino4_ok(const FP& p, const float* x, const float* ws, int Cin, int 
   if ((((uintptr_t)x | (uintptr_t)ws) & 15) != 0) return false;
   if ((long long)p.Di * p.Hi * p.Wi * 4 >= (1ll << 31)) return false;
   // enough bricks for two rounds of one workgroup per CU (the 64^3 trunk of the scale-1 blocks: 2 x 16 x 32 x 1 = 1024)
-  return (long long)p.B * fs::cdiv(p.Do, 4) * fs::cdiv(p.Ho, 2) * (p.Wo / 64) >= 512;
+  static const long long min_bricks = getenv("FLOWSCI_WINO4_MIN") ? atoll(getenv("FLOWSCI_WINO4_MIN")) : 512;
+  return (long long)p.B * fs::cdiv(p.Do, 4) * fs::cdiv(p.Ho, 2) * (p.Wo / 64) >= min_bricks;
 }
 
 inline int launch_wino4(const float* X, const float* Ut, const float* bias, float* Y, FP& p, hipStream_t st) {

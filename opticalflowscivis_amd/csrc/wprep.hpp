@@ -16,9 +16,25 @@
 //       filter transform along kx of the taps FS_WPREP_FWD would deliver (same two modes)          (convwino.hpp)
 //   FS_WPREP_WINO4 p = {Cout, Cin, CinP, mode}             Ut[ci][kz*3+ky][t 0..5][co 0..63]: the F(4,3) filter transform
 //       (points 0, +-1, +-2, inf) of the same taps                                                  (convwino4.hpp)
-enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4, FS_WPREP_WINO4 = 5 };
+//   FS_WPREP_WINO2D p = {Cout, Cin, CinP, mode}            Ut[ci][kz][ty 0..3][tx 0..5][co 0..63]: F(2,3) along ky and F(4,3)
+//       along kx of the same taps                                                                   (convwino2d.hpp)
+enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4, FS_WPREP_WINO4 = 5,
+       FS_WPREP_WINO2D = 6 };
 constexpr int FS_WINO_UCH = 9 * 4 * 64 + 16;  // floats per input channel of the Winograd slab (== WN_UCH)
 constexpr int FS_WINO4_UCH = 9 * 6 * 64;      // ... of the F(4,3) slab (== W4_UCH)
+constexpr int FS_WINO2D_UCH = 3 * 24 * 64;    // ... of the F(2,3) x F(4,3) slab (== W2_UCH)
+
+// F(4,3) filter transform G g (points 0, +-1, +-2, inf), component tt
+__device__ __forceinline__ float wprep_g43(const float (&g)[3], int tt) {
+  switch (tt) {
+    case 0: return 0.25f * g[0];
+    case 1: return (-1.f / 6.f) * ((g[0] + g[2]) + g[1]);
+    case 2: return (-1.f / 6.f) * ((g[0] + g[2]) - g[1]);
+    case 3: return (1.f / 24.f) * g[0] + ((1.f / 12.f) * g[1] + (1.f / 6.f) * g[2]);
+    case 4: return (1.f / 24.f) * g[0] + ((-1.f / 12.f) * g[1] + (1.f / 6.f) * g[2]);
+    default: return g[2];
+  }
+}
 
 __host__ __device__ constexpr int wprep_p8_k(int par, int d) { return par == 0 ? (d == 0 ? 1 : 3) : (d == 0 ? 0 : 2); }
 
@@ -66,14 +82,28 @@ __device__ __forceinline__ float wprep_elem(const FsWprepJob& j, int e) {
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
         g[kx] = mode ? w[((size_t)ci * Cout + co) * 27 + (26 - (kk * 3 + kx))] : w[((size_t)co * Cin + ci) * 27 + kk * 3 + kx];
-      switch (tt) {
-        case 0: return 0.25f * g[0];
-        case 1: return (-1.f / 6.f) * ((g[0] + g[2]) + g[1]);
-        case 2: return (-1.f / 6.f) * ((g[0] + g[2]) - g[1]);
-        case 3: return (1.f / 24.f) * g[0] + ((1.f / 12.f) * g[1] + (1.f / 6.f) * g[2]);
-        case 4: return (1.f / 24.f) * g[0] + ((-1.f / 12.f) * g[1] + (1.f / 6.f) * g[2]);
-        default: return g[2];
+      return wprep_g43(g, tt);
+    }
+    case FS_WPREP_WINO2D: {
+      const int Cout = j.p[0], Cin = j.p[1], mode = j.p[3];
+      const int ci = e / FS_WINO2D_UCH, i = e - ci * FS_WINO2D_UCH;
+      if (ci >= Cin) return 0.f;
+      const int kz = i / 1536, r = i - kz * 1536;
+      const int ty = r / 384, r2 = r - ty * 384;
+      const int tx = r2 >> 6, co = r2 & 63;
+      if (co >= Cout) return 0.f;
+      float u[3];  // the x-transformed taps of the three ky rows
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float g[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = (kz * 3 + ky) * 3 + kx;
+          g[kx] = mode ? w[((size_t)ci * Cout + co) * 27 + (26 - tap)] : w[((size_t)co * Cin + ci) * 27 + tap];
+        }
+        u[ky] = wprep_g43(g, tx);
       }
+      return ty == 0 ? u[0] : ty == 1 ? 0.5f * ((u[0] + u[1]) + u[2]) : ty == 2 ? 0.5f * ((u[0] - u[1]) + u[2]) : u[2];
     }
     default: {  // FS_WPREP_P8
       const int Cin = j.p[0], Cout = j.p[1], RT = j.p[3];

@@ -1592,7 +1592,8 @@ _wino_seen = {}
 
 def _fwd_k3_macs(xptr, B, Cin, Cout, dhw, wmode):
     """Multiply-adds per output and input channel that fs_conv3d_fwd* EXECUTES for this k3 s1 p1 call: 27 as a direct
-    implicit GEMM, 18 as the 1-D Winograd F(2,3) kernel (csrc/convwino.hpp), 13.5 as F(4,3) (csrc/convwino4.hpp).
+    implicit GEMM, 18 as the 1-D Winograd F(2,3) kernel (csrc/convwino.hpp), 13.5 as F(4,3) (csrc/convwino4.hpp), 9 as the
+    2-D F(2,3) x F(4,3) kernel (csrc/convwino2d.hpp).
     Asked of the library's own dispatch (its re-layout plan), cached per geometry; only the flop accounting of the
     timing records depends on it."""
     key = (xptr % 16, B, Cin, Cout) + tuple(int(v) for v in dhw) + (int(wmode),)
@@ -1600,7 +1601,7 @@ def _fwd_k3_macs(xptr, B, Cin, Cout, dhw, wmode):
         buf = (_lib.FsWprepJob * 4)()
         n = _lib.lib().fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000 + xptr % 16, 0x1000, 0x1000, B, Cin, Cout, *key[4:7],
                                                 *key[4:7], 3, 1, 1, int(wmode))
-        _wino_seen[key] = {4: 18.0, 5: 13.5}.get(buf[0].kind, 27.0) if n == 1 else 27.0
+        _wino_seen[key] = {4: 18.0, 5: 13.5, 6: 9.0}.get(buf[0].kind, 27.0) if n == 1 else 27.0
     return _wino_seen[key]
 
 

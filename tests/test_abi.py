@@ -100,13 +100,15 @@ def test_weight_relayout_plans_without_gpu():
     fwd = lambda cin, cout, n, k, wmode, x=0x4000, w=0x1000: L.fs_conv3d_fwd_wprep_jobs(
         buf, 4, x, w, 0x2000, 2, cin, cout, n, n, n, n if k == 3 else n // 2, n if k == 3 else n // 2,
         n if k == 3 else n // 2, k, 1 if k == 3 else 2, 1, wmode)
-    # the 64-channel k3 layers of the 64^3 trunk take the Winograd F(4,3)-transformed filter (kind 5), in both weight
-    # modes; a volume whose 4 x 2 x 64 bricks do not fill the chip twice takes F(2,3) (kind 4, 2 x 2 x 64 bricks)
+    # the 64-channel k3 layers of the 64^3 trunk take the 2-D Winograd (F(2,3) along y x F(4,3) along x) filter slab
+    # (kind 6), in both weight modes; so does any volume with one 2 x 2 x 64 brick per CU
     for wmode in (0, 1):
-        assert fwd(64, 64, 64, 3, wmode) == 1 and buf[0].kind == 5 and buf[0].w == 0x1000 and buf[0].ws == 0x2000
-        assert buf[0].total == 64 * (9 * 6 * 64) == L.fs_conv3d_fwd_ws_floats(64, 64, 3)
-    half = L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 2, 64, 64, 32, 32, 64, 32, 32, 64, 3, 1, 1, 0)
-    assert half == 1 and buf[0].kind == 4 and buf[0].total == 64 * (9 * 4 * 64 + 16)
+        assert fwd(64, 64, 64, 3, wmode) == 1 and buf[0].kind == 6 and buf[0].w == 0x1000 and buf[0].ws == 0x2000
+        assert buf[0].total == 64 * (3 * 24 * 64) == L.fs_conv3d_fwd_ws_floats(64, 64, 3)
+    half = L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 2, 64, 64, 16, 32, 64, 16, 32, 64, 3, 1, 1, 0)
+    assert half == 1 and buf[0].kind == 6
+    few = L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 1, 64, 64, 8, 8, 64, 8, 8, 64, 3, 1, 1, 0)
+    assert few == 1 and buf[0].kind == 0   # 16 bricks: the direct kernel
     # ... not at 32^3 (rows of 32), not from a misaligned input: the direct taps (kind 0)
     assert fwd(64, 64, 32, 3, 0) == 1 and buf[0].kind == 0 and buf[0].total == 64 * 27 * 64
     assert fwd(64, 64, 64, 3, 0, x=0x4004) == 1 and buf[0].kind == 0

@@ -1,9 +1,13 @@
-"""-m gpu: the 1-D Winograd forms of the 64-channel k3 trunk convolutions -- F(2,3) (csrc/convwino.hpp) and F(4,3)
-(csrc/convwino4.hpp, taken where its larger bricks fill the chip) -- against fp64: every fused epilogue (bias, PReLU output
-+ residual addend, plain addend, the PReLU-backward form), both weight modes (forward taps / flipped + transposed for
-the input gradient), volume edges that are not multiples of the brick, channel counts below the 64-row tile.  F(2,3)'s
-coefficients are +-1 and 1/2, F(4,3)'s reach 8 and 1/24: the error against fp64 stays within 2x the direct kernel's
-bound (3e-5 of the output's magnitude) for both."""
+"""-m gpu: the Winograd forms of the 64-channel k3 trunk convolutions against fp64 -- forward / input gradient: the 2-D
+F(2,3) x F(4,3) kernel (csrc/convwino2d.hpp) that the dispatch takes, and in a subprocess the 1-D F(4,3) / F(2,3) kernels
+it superseded (csrc/convwino4.hpp, convwino.hpp: reached with FLOWSCI_FWD_NO_WINO2D / _NO_WINO4); weight gradient: F(4,3)
+(csrc/convwrwwino4.hpp).  Every fused epilogue (bias, PReLU output + residual addend, plain addend, the PReLU-backward
+form), both weight modes (forward taps / flipped + transposed for the input gradient), volume edges that are not
+multiples of the brick, channel counts below the 64-row tile.  The coefficients reach 8 and 1/24: the error against fp64
+stays within 2x the direct kernel's bound (3e-5 of the output's magnitude)."""
+import os
+import subprocess
+import sys
 import pytest
 import torch
 import torch.nn.functional as F
@@ -21,7 +25,7 @@ def ops():
 
 def _slab_kind(ops, x, w, cin, cout, size, wmode):
     """The library's own dispatch: which filter slab does this call take (FsWprepJob kind: 0 direct taps, 4 the F(2,3)
-    transform, 5 the F(4,3) transform)?"""
+    transform, 5 the F(4,3) transform, 6 the 2-D F(2,3) x F(4,3) transform)?"""
     from opticalflowscivis_amd import _lib
     L = _lib.lib()
     buf = (_lib.FsWprepJob * 4)()
@@ -33,20 +37,23 @@ def _slab_kind(ops, x, w, cin, cout, size, wmode):
 
 
 def _expected_kind(B, size):
-    """F(4,3) where its 4 x 2 x 64 bricks give every CU two rounds, else F(2,3) on 2 x 2 x 64 bricks."""
+    """The 2-D form wherever its 2 x 2 x 64 bricks give every CU one (the 1-D forms it superseded need 512 bricks of the
+    same or twice the size: they are reached only with the 2-D form switched off, see the subprocess test below)."""
     D, H, W = size
-    return 5 if B * ((D + 3) // 4) * ((H + 1) // 2) * (W // 64) >= 512 else 4
+    return 6 if B * ((D + 1) // 2) * ((H + 1) // 2) * (W // 64) >= 256 else 0
 
 
 def _is_wino(ops, x, w, cin, cout, size, wmode):
-    return _slab_kind(ops, x, w, cin, cout, size, wmode) in (4, 5)
+    return _slab_kind(ops, x, w, cin, cout, size, wmode) in (4, 5, 6)
 
 
 @pytest.mark.parametrize("B,cin,cout,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (33, 31, 64)), (2, 8, 20, (32, 32, 64)),
                                              (2, 64, 64, (16, 32, 128)), (2, 12, 64, (64, 64, 64)),
                                              # F(4,3) bricks (4 x 2 x 64): whole, ragged in z and y, few channels, two x bricks
                                              (2, 64, 64, (64, 32, 64)), (2, 64, 64, (62, 33, 64)), (2, 8, 20, (64, 32, 64)),
-                                             (2, 64, 64, (32, 32, 128))])
+                                             (2, 64, 64, (32, 32, 128)),
+                                             # the 2-D form's 2 x 2 x 64 bricks: ragged in z and y, few channels, two x bricks
+                                             (2, 64, 64, (63, 33, 64)), (2, 12, 24, (64, 32, 64)), (2, 64, 64, (66, 34, 64))])
 def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
     g = torch.Generator().manual_seed(cin * 100 + size[0])
     x = torch.randn((B, cin) + size, generator=g)
@@ -74,7 +81,8 @@ def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
 
 
 @pytest.mark.parametrize("B,cg,cx,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (33, 34, 64)), (2, 64, 32, (32, 32, 64)),
-                                          (2, 64, 64, (64, 32, 64)), (2, 64, 64, (61, 35, 64)), (2, 64, 32, (64, 32, 64))])
+                                          (2, 64, 64, (64, 32, 64)), (2, 64, 64, (61, 35, 64)), (2, 64, 32, (64, 32, 64)),
+                                          (2, 64, 64, (48, 32, 64))])
 def test_wino_input_gradient_and_prelu_backward_vs_fp64(ops, B, cg, cx, size):
     """wmode 1: the layer weight [Cout_layer = cg][Cin_layer = cx] read flipped + transposed; and the same convolution
     with the PReLU backward as its epilogue (fs_conv3d_fwd_dprelu, kernel 3)."""
@@ -103,6 +111,16 @@ def test_wino_input_gradient_and_prelu_backward_vs_fp64(ops, B, cg, cx, size):
         n = float(ref.numel() / cx) ** 0.5
         assert float((fused[1].cpu().double() - ga).abs().max()) < 2e-5 * max(1.0, float(ga.abs().max())) + 1e-5 * n * scale
         assert float((fused[2].cpu().double() - gb).abs().max()) < 2e-5 * max(1.0, float(gb.abs().max())) + 1e-5 * n * scale
+
+
+@pytest.mark.parametrize("env,kind", [({"FLOWSCI_FWD_NO_WINO2D": "1"}, 5), ({"FLOWSCI_FWD_NO_WINO4": "1"}, 4)])
+def test_superseded_1d_kernels_in_a_fresh_process(env, kind):
+    """The dispatch switches are read once per process: F(4,3) (kind 5) and F(2,3) (kind 4) along x only, same checks."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "wino_check.py"), str(kind)],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ("kind=%d" % kind) in r.stdout and "OK" in r.stdout
 
 
 def test_wino_is_not_taken_where_it_does_not_apply(ops):
