@@ -13,11 +13,11 @@
 // Kernel: loader-wave form, one 8-wave workgroup per CU, brick = 2 z x 2 y x 64 x (MFMA column = (z row, x-tile)), chunks of
 // 2 input channels (one 32x32x2 k-pair; the filter slab is 18 KB per channel), THREE LDS buffers of 49 KB: a chunk lasts
 // only ~2 300 MFMA cycles, so the slab is requested two chunks ahead and the input rows one chunk ahead of their transform.
-//   waves 4, 5: the transformed input of channel 0 / 1 of the chunk.  A lane owns one x-tile of one staged z row with all
-//     four y rows (4 float4 loads; 16 lanes per z row, the four z rows of the brick in one wave): By^T in registers,
-//     the neighbouring columns of the y-transformed rows by DPP row shifts (halo columns by dword loads in lanes 0 / 15),
-//     Bx^T, 24 dword writes.
-//   waves 6, 7: the U slab of the chunk by `buffer_load_dwordx4 ... lds` (36 wave-instructions).
+//   loader waves 4-7: the transformed input (a lane owns one x-tile of one staged z row with all four y rows -- 4 float4
+//     loads; 16 lanes per z row, the four z rows of the brick in one wave: By^T in registers, the neighbouring columns of
+//     the y-transformed rows by DPP row shifts (halo columns by dword loads in lanes 0 / 15), Bx^T, 24 dword writes) and
+//     the U slab of the chunk by `buffer_load_dwordx4 ... lds` (36 wave-instructions), both dealt evenly to the four
+//     waves and to the periods (see the loader code).
 //   matrix waves 0-3: one y-component ty each: 6 x-components x 2 channel tiles = 12 accumulator tiles (192 VGPRs).
 //   epilogue: Ax^T in registers (4 consecutive x per lane and channel), the four waves' results meet in LDS (128 KB of
 //     the idle staging buffers), every wave finishes 16 channels: Ay^T, the direct kernel's fused epilogues, 16-byte stores.
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
   constexpr int CI = 2;
   constexpr int NV = CI * W2_VCH, NU = CI * W2_UCH;
   constexpr int NUP = NU / 256;            // LDS-DMA wave-instructions (64 x 16 bytes) of the U slab
-  constexpr int NUW = (NUP + 1) / 2;       // per DMA wave (two of them)
+  constexpr int NUW = NUP / 4;             // per loader wave
   constexpr int BUF = NV + NU;
   constexpr int NEX = 4 * 64 * 32 * 4;     // the epilogue's exchange image: [ty][co][column] float4
   constexpr int NB = 3;                    // staging buffers: the U slab is requested TWO chunks ahead (a chunk is only ~2 300
@@ -62,52 +62,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
   const int oz0 = tzi * 2, oy0 = tyi * 2, ox0 = txi * 64;
   const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
 
-  if (wave >= 6) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // ---- U slab: wave 6 the even, wave 7 the odd wave-instructions
-    const int w2 = wave - 6;
-    unsigned uoff[NUW];
-#pragma unroll
-    for (int k = 0; k < NUW; ++k) uoff[k] = (unsigned)(64 * (w2 + 2 * k) + lane) * 16u;
-    auto dma_u = [&](int c0, int buf) {
-      if (DBG == 1 || DBG == 3) return;
-      __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(Ut + (size_t)c0 * W2_UCH), (short)0, NU * 4, 0x00020000);
-      float* base = lds + buf * BUF + NV;
-#pragma unroll
-      for (int k = 0; k < NUW; ++k)
-        if (w2 + 2 * k < NUP)  // wave-uniform
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + 256 * (w2 + 2 * k)), 16, uoff[k], 0, 0, 0);
-    };
-    static_assert(NUP % 2 == 0, "both DMA waves issue NUW instructions per chunk");
-    const int nch = p.Cin / CI;
-    dma_u(0, 0);
-    if (nch > 1) {
-      dma_u(CI, 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NUW) : "memory");  // chunk 0 has landed, chunk 1 may be in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    for (int k = 0; k < nch; ++k) {
-      // period k: the matrix waves read buffer k % 3; chunk k + 1 must have landed by its end, chunk k + 2 is requested
-      if (k + 2 < nch) {
-        dma_u((k + 2) * CI, (k + 2) % NB);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NUW) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-    }
-#else
-    (void)NUW;
-#endif
-    return;
-  }
   if (wave >= 4) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // ---- transformed input of channel (c0 + wave - 4): lane = (staged z row zr = lane >> 4, x-tile q = lane & 15)
-    const int cc = wave - 4;
-    const int zr = lane >> 4, q = lane & 15;
+    // ---- loader waves.  The vector-ALU work of a loader wave is NOT hidden behind the matrix wave it shares a SIMD with
+    // (ablation builds: the input transform alone cost 0.11 of 0.48 ms when two waves did all of it), so it is spread
+    // evenly over all four SIMDs and all periods: a wave handles input channel cc = lw & 1 of every second chunk
+    // (parity lw >> 1) in two half-steps -- y components 0, 1 in one period, 2, 3 in the next -- and a quarter of
+    // every chunk's U slab.  Chunk j is read by the matrix waves in period j and is complete at the end of period j - 1:
+    //   period j - 3: its rows are requested (after the wave's previous chunk is finished)
+    //   period j - 2: By^T, then Bx^T of ty 0, 1 -> buffer j % 3      period j - 1: Bx^T of ty 2, 3
+    const int lw = wave - 4, par = lw >> 1, cc = lw & 1;
+    const int zr = lane >> 4, q = lane & 15;  // lane = (staged z row, x-tile)
     const int gz = oz0 - 1 + zr, gx = ox0 + 4 * q;
     const int hx = q == 0 ? ox0 - 1 : ox0 + 64;
     unsigned voff[4], hoff[4];
@@ -120,10 +85,22 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
       hoff[yr] = (rowok && (q == 0 || q == 15) && hx >= 0 && hx < p.Wi) ? (rbase + hx) * 4u : DMA_OOB;
     }
     const int vdst = cc * W2_VCH + zr * W2_ZP + q;
-    float xr[4][4], xh[4];
-    auto fetch = [&](int c0) {
+    unsigned uoff[NUW];
+#pragma unroll
+    for (int k = 0; k < NUW; ++k) uoff[k] = (unsigned)(64 * (lw + 4 * k) + lane) * 16u;
+    auto dma_u = [&](int chunk, int buf) {
+      if (DBG == 1 || DBG == 3) return;
+      __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(Ut + (size_t)chunk * CI * W2_UCH), (short)0, NU * 4, 0x00020000);
+      float* base = lds + buf * BUF + NV;
+#pragma unroll
+      for (int k = 0; k < NUW; ++k)  // NUP == 4 NUW: every wave issues all of its NUW
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + 256 * (lw + 4 * k)), 16, uoff[k], 0, 0, 0);
+    };
+    float xr[4][4], xh[4];   // the raw rows in flight
+    float yt[4][4], yh[4];   // By^T of the chunk in work (lives across the two half-steps)
+    auto fetch = [&](int chunk) {
       if (DBG == 2 || DBG == 3) return;
-      const int ch = c0 + cc;
+      const int ch = chunk * CI + cc;
       const bool live = ch < p.Cin;
       const float* base = X + ((size_t)b * p.Cin + (live ? ch : 0)) * xvol;
       __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, live ? (int)((unsigned)xvol * 4u) : 0, 0x00020000);
@@ -135,11 +112,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
         xh[yr] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, hoff[yr], 0, 0));
       }
     };
-    auto put = [&](int buf) {
+    auto ytrans = [&]() {  // By^T over the four rows, column by column (the 4 own columns and the halo column)
       if (DBG == 2 || DBG == 3) return;
-      float* dstb = lds + buf * BUF + vdst;
-      // By^T over the four rows, column by column (the 4 own columns and the halo column)
-      float yt[4][4], yh[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         yt[0][i] = xr[0][i] - xr[2][i];
@@ -148,13 +122,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
         yt[3][i] = xr[1][i] - xr[3][i];
       }
       yh[0] = xh[0] - xh[2]; yh[1] = xh[1] + xh[2]; yh[2] = xh[2] - xh[1]; yh[3] = xh[1] - xh[3];
+    };
+    auto put_half = [&](int buf, auto HALF) {
+      if (DBG == 2 || DBG == 3) return;
+      constexpr int half = decltype(HALF)::value;
+      float* dstb = lds + buf * BUF + vdst;
 #pragma unroll
-      for (int ty = 0; ty < 4; ++ty) {
-        const float d1 = yt[ty][0], d2 = yt[ty][1], d3 = yt[ty][2], d4 = yt[ty][3];
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const float d1 = yt[2 * half + t2][0], d2 = yt[2 * half + t2][1], d3 = yt[2 * half + t2][2], d4 = yt[2 * half + t2][3];
+        const float dh = yh[2 * half + t2];
         // d0 = left neighbour's last column, d5 = right neighbour's first; lanes 0 / 15 of a row keep the halo column
-        const float d0 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(yh[ty]), __float_as_uint(d4), 0x111, 0xF, 0xF, false));
-        const float d5 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(yh[ty]), __float_as_uint(d1), 0x101, 0xF, 0xF, false));
-        float* dst = dstb + ty * 96;
+        const float d0 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(dh), __float_as_uint(d4), 0x111, 0xF, 0xF, false));
+        const float d5 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(dh), __float_as_uint(d1), 0x101, 0xF, 0xF, false));
+        float* dst = dstb + (2 * half + t2) * 96;
         const float p31 = d3 - d1, r42 = d4 - d2;
         dst[0 * 16] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
         dst[1 * 16] = fmaf(-4.f, d1 + d2, d3 + d4);
@@ -164,24 +144,53 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
         dst[5 * 16] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
       }
     };
+    static_assert(NUP == 4 * NUW, "every loader wave issues NUW slab instructions per chunk");
     const int nch = p.Cin / CI;
-    fetch(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    put(0);
-    if (nch > 1) fetch(CI);  // in flight during the first period
+    const std::integral_constant<int, 0> H0{};
+    const std::integral_constant<int, 1> H1{};
+    // prologue = "period -1": chunk 0 whole (parity 0), the first half of chunk 1 (parity 1); slabs of chunks 0 and 1
+    dma_u(0, 0);
+    if (nch > 1) dma_u(1, 1);
+    if (par == 0) {
+      fetch(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ytrans();
+      put_half(0, H0);
+      put_half(0, H1);
+      if (nch > 2) fetch(2);
+    } else if (nch > 1) {
+      fetch(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ytrans();
+      put_half(1, H0);
+    }
+    if (par != 0 || nch <= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the slabs)
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                               // ... all but the 8 row loads of chunk 2
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int k = 0; k < nch; ++k) {
-      if (k + 1 < nch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk k + 1's rows were requested a whole period ago
-        put((k + 1) % NB);
-        if (k + 2 < nch) fetch((k + 2) * CI);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int t0 = 0; t0 < nch; ++t0) {
+      // request this wave's quarter of chunk t0 + 2's slab, then wait for everything it requested in the previous period
+      // (a quarter of chunk t0 + 1's slab, maybe rows: they have had a whole period to arrive)
+      if (t0 + 2 < nch) {
+        dma_u(t0 + 2, (t0 + 2) % NB);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DBG == 1 || DBG == 3 ? 0 : NUW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();  // chunk k + 1 is in LDS; the matrix waves are done reading chunk k
+      if (((t0 + 1) & 1) == par) {
+        if (t0 + 1 < nch) {          // second half of chunk t0 + 1, then its successor's rows
+          put_half((t0 + 1) % NB, H1);
+          if (t0 + 3 < nch) fetch(t0 + 3);
+        }
+      } else if (t0 + 2 < nch) {     // first half of chunk t0 + 2
+        ytrans();
+        put_half((t0 + 2) % NB, H0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // chunk t0 + 1 is in LDS; the matrix waves are done reading chunk t0
     }
 #else
-    (void)xvol;
+    (void)xvol; (void)NUW;
 #endif
     return;
   }
