@@ -28,7 +28,9 @@ constexpr int W2_UCH = FS_WINO2D_UCH;         // channel pitch of U: [kz][ty][tx
 
 // DBG (measurement builds, FLOWSCI_WINO_DBG): 1 = the U DMA is skipped, 2 = the input waves skip loads and transforms,
 // 3 = both (matrix waves + epilogue alone), 4 = the matrix waves skip their operand reads and MFMAs (loaders alone).
-template <int DBG>
+// XT = x-tiles per row of a brick: 16 (rows of 64 x, brick 2 z x 2 y x 64 x) or 8 (rows of 32 x: the 16 x-tile slots of a z
+// row are then 2 y-tiles x 8 x-tiles, brick 2 z x 4 y x 32 x -- the 32^3 trunk of the scale-2 block).
+template <int DBG, int XT>
 __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* __restrict__ X,
                                                                  const float* __restrict__ Ut,
                                                                  const float* __restrict__ bias,
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
   const int tyi = (int)(tile % p.ty); tile /= p.ty;
   const int tzi = (int)(tile % p.tz);
   const int b = (int)(tile / p.tz);
-  const int oz0 = tzi * 2, oy0 = tyi * 2, ox0 = txi * 64;
+  constexpr int YT = 16 / XT;  // y-tiles of a brick
+  const int oz0 = tzi * 2, oy0 = tyi * 2 * YT, ox0 = txi * 4 * XT;
   const size_t xvol = (size_t)p.Di * p.Hi * p.Wi;
 
   if (wave >= 4) {
@@ -73,16 +76,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
     //   period j - 2: By^T, then Bx^T of ty 0, 1 -> buffer j % 3      period j - 1: Bx^T of ty 2, 3
     const int lw = wave - 4, par = lw >> 1, cc = lw & 1;
     const int zr = lane >> 4, q = lane & 15;  // lane = (staged z row, x-tile)
-    const int gz = oz0 - 1 + zr, gx = ox0 + 4 * q;
-    const int hx = q == 0 ? ox0 - 1 : ox0 + 64;
+    const int qx = q & (XT - 1), qy = q / XT;   // x-tile, y-tile of the lane's slot
+    const int gz = oz0 - 1 + zr, gx = ox0 + 4 * qx;
+    const int hx = qx == 0 ? ox0 - 1 : ox0 + 4 * XT;
     unsigned voff[4], hoff[4];
 #pragma unroll
     for (int yr = 0; yr < 4; ++yr) {
-      const int gy = oy0 - 1 + yr;
+      const int gy = oy0 + 2 * qy - 1 + yr;
       const bool rowok = gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
       const unsigned rbase = ((unsigned)(rowok ? gz : 0) * p.Hi + (rowok ? gy : 0)) * p.Wi;
-      voff[yr] = (rowok && gx < p.Wi) ? (rbase + gx) * 4u : DMA_OOB;   // Wi % 64 == 0: a float4 is in or out whole
-      hoff[yr] = (rowok && (q == 0 || q == 15) && hx >= 0 && hx < p.Wi) ? (rbase + hx) * 4u : DMA_OOB;
+      voff[yr] = (rowok && gx < p.Wi) ? (rbase + gx) * 4u : DMA_OOB;   // Wi % (4 XT) == 0: a float4 is in or out whole
+      hoff[yr] = (rowok && (qx == 0 || qx == XT - 1) && hx >= 0 && hx < p.Wi) ? (rbase + hx) * 4u : DMA_OOB;
     }
     const int vdst = cc * W2_VCH + zr * W2_ZP + q;
     unsigned uoff[NUW];
@@ -131,9 +135,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
       for (int t2 = 0; t2 < 2; ++t2) {
         const float d1 = yt[2 * half + t2][0], d2 = yt[2 * half + t2][1], d3 = yt[2 * half + t2][2], d4 = yt[2 * half + t2][3];
         const float dh = yh[2 * half + t2];
-        // d0 = left neighbour's last column, d5 = right neighbour's first; lanes 0 / 15 of a row keep the halo column
-        const float d0 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(dh), __float_as_uint(d4), 0x111, 0xF, 0xF, false));
-        const float d5 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(dh), __float_as_uint(d1), 0x101, 0xF, 0xF, false));
+        // d0 = left neighbour's last column, d5 = right neighbour's first; the first / last x-tile of a row keeps the halo
+        // column (lanes 0 / 15 of the DPP row by the shift itself; XT = 8: also the seam between the two y-tiles)
+        float d0 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(dh), __float_as_uint(d4), 0x111, 0xF, 0xF, false));
+        float d5 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(dh), __float_as_uint(d1), 0x101, 0xF, 0xF, false));
+        if (XT < 16) {
+          d0 = qx == 0 ? dh : d0;
+          d5 = qx == XT - 1 ? dh : d5;
+        }
         float* dst = dstb + (2 * half + t2) * 96;
         const float p31 = d3 - d1, r42 = d4 - d2;
         dst[0 * 16] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
@@ -252,8 +261,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
 
   // ---- epilogue 2: wave wv finishes channels 16 wv .. 16 wv + 15; lane = (y row lane >> 5, z row (lane >> 4) & 1, x-tile)
   const int yy = lane >> 5, c5 = lane & 31;
-  const int oz = oz0 + (c5 >> 4), oy = oy0 + yy;
-  const int xq = ox0 + 4 * (c5 & 15);
+  const int oz = oz0 + (c5 >> 4), oy = oy0 + 2 * ((c5 & 15) / XT) + yy;
+  const int xq = ox0 + 4 * (c5 & (XT - 1));
   const size_t yvol = (size_t)p.Do * p.Ho * p.Wo;
   const bool live = oz < p.Do && oy < p.Ho;
   const size_t orow = ((size_t)(live ? oz : 0) * p.Ho + (live ? oy : 0)) * p.Wo + xq;
@@ -328,32 +337,42 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
   }
 }
 
+inline int wino2d_xt(const FP& p) { return p.Wo % 64 == 0 ? 16 : 8; }
+
 inline bool wino2d_ok(const FP& p, const float* x, const float* ws, int Cin, int Cout, int kernel, int stride, bool has_ms) {
   static const bool off = getenv("FLOWSCI_FWD_NO_WINO2D") != nullptr || getenv("FLOWSCI_FWD_NO_WINO4") != nullptr ||
                           getenv("FLOWSCI_FWD_NO_WINO") != nullptr;
   if (off || kernel != 3 || stride != 1 || p.pad != 1 || has_ms) return false;
   if (Cin % 4 != 0 || Cout > 64 || p.CoutP != 64) return false;
-  if (p.Wi != p.Wo || p.Wi % 64 != 0 || p.Di != p.Do || p.Hi != p.Ho) return false;
+  if (p.Wi != p.Wo || p.Wi % 32 != 0 || p.Di != p.Do || p.Hi != p.Ho) return false;
   if ((((uintptr_t)x | (uintptr_t)ws) & 15) != 0) return false;
   if ((long long)p.Di * p.Hi * p.Wi * 4 >= (1ll << 31)) return false;
-  // one 2 x 2 x 64 brick per CU is enough: measured (tests/tools/wino_bench.py, 64 -> 64 layer) 0.072 ms at 256 bricks
-  // against 0.129 for the direct small-brick kernel, 0.131 / 0.143 / 0.183 / 0.257 (2-D / F(4,3) / F(2,3) / direct) at 512;
-  // the 64^3 trunk has 2048
+  // one brick (2 z x 2 y x 64 x, or 2 z x 4 y x 32 x) per CU is enough: measured (tests/tools/wino_bench.py, 64 -> 64 layer)
+  // 0.072 ms at 256 bricks against 0.129 for the direct small-brick kernel, 0.131 / 0.143 / 0.183 / 0.257 (2-D / F(4,3) /
+  // F(2,3) / direct) at 512; the 64^3 trunk has 2048
   static const long long min_bricks = getenv("FLOWSCI_WINO2D_MIN") ? atoll(getenv("FLOWSCI_WINO2D_MIN")) : 256;
-  return (long long)p.B * fs::cdiv(p.Do, 2) * fs::cdiv(p.Ho, 2) * (p.Wo / 64) >= min_bricks;
+  const int xt = wino2d_xt(p);
+  return (long long)p.B * fs::cdiv(p.Do, 2) * fs::cdiv(p.Ho, 2 * (16 / xt)) * (p.Wo / (4 * xt)) >= min_bricks;
+}
+
+template <int XT>
+void launch_wino2d_t(const float* X, const float* Ut, const float* bias, float* Y, const FP& p, hipStream_t st) {
+  static const int dbg = getenv("FLOWSCI_WINO_DBG") ? atoi(getenv("FLOWSCI_WINO_DBG")) : 0;
+  const dim3 g((unsigned)p.tiles, 1);
+  if (dbg == 1) hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<1, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
+  else if (dbg == 2) hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<2, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
+  else if (dbg == 3) hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<3, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
+  else if (dbg == 4) hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<4, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
+  else hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<0, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
 }
 
 inline int launch_wino2d(const float* X, const float* Ut, const float* bias, float* Y, FP& p, hipStream_t st) {
-  p.tz = fs::cdiv(p.Do, 2); p.ty = fs::cdiv(p.Ho, 2); p.tx = p.Wo / 64;
+  const int xt = wino2d_xt(p);
+  p.tz = fs::cdiv(p.Do, 2); p.ty = fs::cdiv(p.Ho, 2 * (16 / xt)); p.tx = p.Wo / (4 * xt);
   p.tiles = (long long)p.B * p.tz * p.ty * p.tx;
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
-  static const int dbg = getenv("FLOWSCI_WINO_DBG") ? atoi(getenv("FLOWSCI_WINO_DBG")) : 0;
-  const dim3 g((unsigned)p.tiles, 1);
-  if (dbg == 1) hipLaunchKernelGGL(conv3d_wino2d_ws_kernel<1>, g, dim3(512), 0, st, X, Ut, bias, Y, p);
-  else if (dbg == 2) hipLaunchKernelGGL(conv3d_wino2d_ws_kernel<2>, g, dim3(512), 0, st, X, Ut, bias, Y, p);
-  else if (dbg == 3) hipLaunchKernelGGL(conv3d_wino2d_ws_kernel<3>, g, dim3(512), 0, st, X, Ut, bias, Y, p);
-  else if (dbg == 4) hipLaunchKernelGGL(conv3d_wino2d_ws_kernel<4>, g, dim3(512), 0, st, X, Ut, bias, Y, p);
-  else hipLaunchKernelGGL(conv3d_wino2d_ws_kernel<0>, g, dim3(512), 0, st, X, Ut, bias, Y, p);
+  if (xt == 16) launch_wino2d_t<16>(X, Ut, bias, Y, p, st);
+  else launch_wino2d_t<8>(X, Ut, bias, Y, p, st);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -109,8 +109,9 @@ def test_weight_relayout_plans_without_gpu():
     assert half == 1 and buf[0].kind == 6
     few = L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 1, 64, 64, 8, 8, 64, 8, 8, 64, 3, 1, 1, 0)
     assert few == 1 and buf[0].kind == 0   # 16 bricks: the direct kernel
-    # ... not at 32^3 (rows of 32), not from a misaligned input: the direct taps (kind 0)
-    assert fwd(64, 64, 32, 3, 0) == 1 and buf[0].kind == 0 and buf[0].total == 64 * 27 * 64
+    # ... not at 16^3 (rows of 16), not from a misaligned input: the direct taps (kind 0)
+    assert fwd(64, 64, 16, 3, 0) == 1 and buf[0].kind == 0 and buf[0].total == 64 * 27 * 64
+    assert fwd(64, 64, 32, 3, 0) == 1 and buf[0].kind == 6   # rows of 32: 2 x 4 x 32 bricks, one per CU at 2 x 32^3
     assert fwd(64, 64, 64, 3, 0, x=0x4004) == 1 and buf[0].kind == 0
     assert fwd(11, 32, 64, 4, 0) == 1 and buf[0].kind == 0 and buf[0].total == L.fs_conv3d_fwd_ws_floats(11, 32, 4) == 12 * 64 * 32
     assert L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 1, 8, 8, 8, 8, 8, 4, 4, 4, 5, 1, 2, 0) == -3   # -FS_ERR_ARG

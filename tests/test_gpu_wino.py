@@ -37,10 +37,15 @@ def _slab_kind(ops, x, w, cin, cout, size, wmode):
 
 
 def _expected_kind(B, size):
-    """The 2-D form wherever its 2 x 2 x 64 bricks give every CU one (the 1-D forms it superseded need 512 bricks of the
-    same or twice the size: they are reached only with the 2-D form switched off, see the subprocess test below)."""
+    """The 2-D form wherever its bricks (2 x 2 x 64, or 2 x 4 x 32 on rows of 32) give every CU one (the 1-D forms it
+    superseded need 512 bricks of the same or twice the size: they are reached only with the 2-D form switched off, see
+    the subprocess test below)."""
     D, H, W = size
-    return 6 if B * ((D + 1) // 2) * ((H + 1) // 2) * (W // 64) >= 256 else 0
+    if W % 32:
+        return 0
+    yt = 1 if W % 64 == 0 else 2
+    xb = W // 64 if W % 64 == 0 else W // 32
+    return 6 if B * ((D + 1) // 2) * ((H + 2 * yt - 1) // (2 * yt)) * xb >= 256 else 0
 
 
 def _is_wino(ops, x, w, cin, cout, size, wmode):
@@ -53,7 +58,9 @@ def _is_wino(ops, x, w, cin, cout, size, wmode):
                                              (2, 64, 64, (64, 32, 64)), (2, 64, 64, (62, 33, 64)), (2, 8, 20, (64, 32, 64)),
                                              (2, 64, 64, (32, 32, 128)),
                                              # the 2-D form's 2 x 2 x 64 bricks: ragged in z and y, few channels, two x bricks
-                                             (2, 64, 64, (63, 33, 64)), (2, 12, 24, (64, 32, 64)), (2, 64, 64, (66, 34, 64))])
+                                             (2, 64, 64, (63, 33, 64)), (2, 12, 24, (64, 32, 64)), (2, 64, 64, (66, 34, 64)),
+                                             # rows of 32 (2 x 4 x 32 bricks): whole, ragged, three x bricks
+                                             (2, 64, 64, (32, 32, 32)), (2, 64, 48, (31, 30, 32)), (2, 16, 64, (32, 18, 96))])
 def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
     g = torch.Generator().manual_seed(cin * 100 + size[0])
     x = torch.randn((B, cin) + size, generator=g)
@@ -82,7 +89,7 @@ def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
 
 @pytest.mark.parametrize("B,cg,cx,size", [(2, 64, 64, (32, 32, 64)), (2, 64, 64, (33, 34, 64)), (2, 64, 32, (32, 32, 64)),
                                           (2, 64, 64, (64, 32, 64)), (2, 64, 64, (61, 35, 64)), (2, 64, 32, (64, 32, 64)),
-                                          (2, 64, 64, (48, 32, 64))])
+                                          (2, 64, 64, (48, 32, 64)), (2, 64, 64, (32, 34, 32))])
 def test_wino_input_gradient_and_prelu_backward_vs_fp64(ops, B, cg, cx, size):
     """wmode 1: the layer weight [Cout_layer = cg][Cin_layer = cx] read flipped + transposed; and the same convolution
     with the PReLU backward as its epilogue (fs_conv3d_fwd_dprelu, kernel 3)."""
@@ -124,9 +131,9 @@ def test_superseded_1d_kernels_in_a_fresh_process(env, kind):
 
 
 def test_wino_is_not_taken_where_it_does_not_apply(ops):
-    x = torch.randn(2, 64, 32, 32, 32, device=DEV)   # rows of 32
+    x = torch.randn(2, 64, 64, 64, 16, device=DEV)   # rows of 16
     w = torch.randn(64, 64, 3, 3, 3, device=DEV)
-    assert not _is_wino(ops, x, w, 64, 64, (32, 32, 32), 0)
+    assert not _is_wino(ops, x, w, 64, 64, (64, 64, 16), 0)
     x = torch.randn(1, 64, 8, 8, 64, device=DEV)     # too few bricks to fill the chip
     assert not _is_wino(ops, x, w, 64, 64, (8, 8, 64), 0)
     w = torch.randn(128, 64, 3, 3, 3, device=DEV)    # more than one 64-channel group
