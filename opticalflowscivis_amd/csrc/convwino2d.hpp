@@ -337,6 +337,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
   }
 }
 
+// Measured and not kept (tests/tools/wino_bench.py, 64 -> 64 at 2 x 64^3, 0.466 ms as built incl. the re-layout launch;
+// ablation builds: matrix waves + epilogue alone 0.354, loaders alone 0.276): two waves doing all of the input transform
+// and two all of the slab requests 0.479; the last two reduction steps of a chunk held back across the barrier so that
+// their MFMAs cover the first operand reads of the next chunk, operands read two steps ahead: 0.461 (within noise).
 inline int wino2d_xt(const FP& p) { return p.Wo % 64 == 0 ? 16 : 8; }
 
 inline bool wino2d_ok(const FP& p, const float* x, const float* ws, int Cin, int Cout, int kernel, int stride, bool has_ms) {
