@@ -56,11 +56,11 @@ def roofline(dom, k, S, B):
     traffic, src = pmc_traffic(dom, S, B)
     if "TFLOPps" in k and dom in ("fs_conv3d_wrw", "fs_conv3d_fwd", "fs_conv3d_tr"):
         # `achieved` = ALGORITHMIC flops (the direct convolution's 2 * out * Cin * k^3) per second, as the
-        # roofline contract defines it.  The 64-channel k3 trunk layers run in a 1-D Winograd F(4,3) domain that
-        # EXECUTES 1/2 of those multiply-adds (csrc/convwino4.hpp, convwrwwino4.hpp; F(2,3), 2/3, on smaller volumes),
-        # so for an entry point that contains them the algorithmic rate is above what the matrix cores execute -- and
-        # may exceed the peak: both are reported, `frac` is algorithmic / peak, `frac_executed` is the matrix cores'
-        # real utilisation.
+        # roofline contract defines it.  The 64-channel k3 trunk layers run in a Winograd domain that EXECUTES 1/3 of
+        # those multiply-adds (forward / input gradient: F(2,3) along y x F(4,3) along x, csrc/convwino2d.hpp) or 1/2
+        # (weight gradient: F(4,3) along x, csrc/convwrwwino4.hpp), so for an entry point that contains them the
+        # algorithmic rate is above what the matrix cores execute -- and may exceed the peak: both are reported, `frac`
+        # is algorithmic / peak, `frac_executed` is the matrix cores' real utilisation.
         algo = k.get("TFLOPps_direct_equivalent", k["TFLOPps"])
         rec = {"bound": "mfma", "kernel": dom, "achieved": algo, "peak": MFMA_F32_PEAK_TFLOPS,
                "unit": "TFLOP/s", "frac": round(algo / MFMA_F32_PEAK_TFLOPS, 4),
@@ -68,7 +68,8 @@ def roofline(dom, k, S, B):
                "traffic": traffic, "traffic_source": src}
         if algo != k["TFLOPps"]:
             rec["note"] = ("achieved = algorithmic (direct-convolution) flops / s; the Winograd-domain trunk layers execute "
-                           "half of them, so frac can exceed 1 -- frac_executed is the matrix cores' utilisation")
+                           "a third (forward / input gradient) or half (weight gradient) of them, so frac can exceed 1 -- "
+                           "frac_executed is the matrix cores' utilisation")
         return rec
     return {"bound": "hbm", "kernel": dom, "achieved": k["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(k["algo_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src}

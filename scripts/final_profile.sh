@@ -29,9 +29,10 @@ bash scripts/prof_configs.sh > $O/prof_configs.log 2>&1 || true
 python -m opticalflowscivis_amd.flow3d.train --dataset droplet3d --size 256 --samples 24 --batch_size 2 --epoch 2 --mode train \
     --log_every 4 --log_path /tmp/tl256 > $O/train256.txt 2>&1 || true
 # the Winograd-domain trunk kernels against the direct ones, and the weight gradient's ablation builds
-{ python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO4=1 python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO=1 python tests/tools/wino_bench.py;
+{ python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO2D=1 python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO4=1 python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO=1 python tests/tools/wino_bench.py;
   python tests/tools/wino_wrw_bench.py; FLOWSCI_WRW_NO_WINO4=1 python tests/tools/wino_wrw_bench.py; FLOWSCI_WRW_NO_WINO=1 python tests/tools/wino_wrw_bench.py;
-  FLOWSCI_WINO_DBG=1 python tests/tools/wino_wrw_bench.py; FLOWSCI_WINO_DBG=2 python tests/tools/wino_wrw_bench.py; } 2>&1 \
+  FLOWSCI_WINO_DBG=1 python tests/tools/wino_wrw_bench.py; FLOWSCI_WINO_DBG=2 python tests/tools/wino_wrw_bench.py;
+  FLOWSCI_WINO_DBG=3 python tests/tools/wino_bench.py; FLOWSCI_WINO_DBG=4 python tests/tools/wino_bench.py; } 2>&1 \
     | grep -E "wmode|wrw:" > $O/wino_kernels.txt || true
 # the direct kernels of the trunk shapes still pass their tests when the Winograd forms are switched off
 FLOWSCI_FWD_NO_WINO=1 FLOWSCI_WRW_NO_WINO=1 python -m pytest tests/test_gpu_losses.py tests/test_gpu_scale.py -q -k "conv or res_unit or head or 256" \
