@@ -109,11 +109,23 @@ __global__ __launch_bounds__(256) void distill_bwd_kernel(const float* __restric
     const long long b = i / p.S;
     const int r = (int)(i - b * p.S);
     const float lm = distill_mask(mi, mt, gt, p, b, r);
-    float q = 0.f;
-    for (int c = 0; c < p.F; ++c) {
-      const long long e = (b * p.F + c) * (long long)p.S + r;
-      const float d = ft[e] - fi[e];
-      q += d * d;
+    constexpr int MAXF = 6;  // the differences stay in registers between the norm and the gradient (see distill3_bwd_kernel)
+    float q = 0.f, dreg[MAXF];
+    const bool keep = p.F <= MAXF;
+    if (keep) {
+#pragma unroll
+      for (int c = 0; c < MAXF; ++c) {
+        const long long e = (b * p.F + (c < p.F ? c : 0)) * (long long)p.S + r;
+        const float d = ft[e] - fi[e];
+        dreg[c] = d;
+        if (c < p.F) q += d * d;
+      }
+    } else {
+      for (int c = 0; c < p.F; ++c) {
+        const long long e = (b * p.F + c) * (long long)p.S + r;
+        const float d = ft[e] - fi[e];
+        q += d * d;
+      }
     }
     const float root = sqrtf(q / (float)p.F);
     // d/df sqrt(mean_c d_c^2) = -d_c / (F * root); the reference's pow(0.5) backward is inf at
@@ -121,9 +133,15 @@ __global__ __launch_bounds__(256) void distill_bwd_kernel(const float* __restric
     // k == 0: the caller has discarded this loss term (Flow-2D's NaN / > 10 guard, RIFE.py:295-296, evaluated on
     // the device): the gradient is exactly 0 then, also where the flows themselves are not finite (0 * NaN).
     const float sc = (root > 0.f) ? (k * lm / ((float)p.F * root)) : 0.f;
-    for (int c = 0; c < p.F; ++c) {
-      const long long e = (b * p.F + c) * (long long)p.S + r;
-      gfi[e] = (k == 0.f) ? 0.f : -(ft[e] - fi[e]) * sc;
+    if (keep) {
+#pragma unroll
+      for (int c = 0; c < MAXF; ++c)
+        if (c < p.F) gfi[(b * p.F + c) * (long long)p.S + r] = (k == 0.f) ? 0.f : -dreg[c] * sc;
+    } else {
+      for (int c = 0; c < p.F; ++c) {
+        const long long e = (b * p.F + c) * (long long)p.S + r;
+        gfi[e] = (k == 0.f) ? 0.f : -(ft[e] - fi[e]) * sc;
+      }
     }
   }
 }
@@ -183,12 +201,31 @@ __global__ __launch_bounds__(256) void distill3_bwd_kernel(D3 a, const float* __
 #pragma unroll
       for (int k = 0; k < 3; ++k) am[k] += fabsf(a.mi[k][e] - g);
     }
+    // the flow differences stay in registers between the norm and the gradient (F <= 6: the 3-D / 2-D flow pairs): PMC
+    // had this kernel fetching 1.76x its algorithmic reads when the second pass read the four flow tensors again
+    constexpr int MAXF = 6;
     float q[3] = {0.f, 0.f, 0.f};
-    for (int c = 0; c < p.F; ++c) {
-      const long long e = (b * p.F + c) * (long long)p.S + r;
-      const float f = ft[e];
+    float dreg[3][MAXF];
+    const bool keep = p.F <= MAXF;
+    if (keep) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const float d = f - a.fi[k][e]; q[k] += d * d; }
+      for (int c = 0; c < MAXF; ++c) {
+        const long long e = (b * p.F + (c < p.F ? c : 0)) * (long long)p.S + r;
+        const float f = ft[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float d = f - a.fi[k][e];
+          dreg[k][c] = d;
+          if (c < p.F) q[k] += d * d;
+        }
+      }
+    } else {
+      for (int c = 0; c < p.F; ++c) {
+        const long long e = (b * p.F + c) * (long long)p.S + r;
+        const float f = ft[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float d = f - a.fi[k][e]; q[k] += d * d; }
+      }
     }
     float sc[3];
 #pragma unroll
@@ -197,11 +234,21 @@ __global__ __launch_bounds__(256) void distill3_bwd_kernel(D3 a, const float* __
       const float root = sqrtf(q[k] / (float)p.F);
       sc[k] = (root > 0.f) ? (kk * lm / ((float)p.F * root)) : 0.f;  // see distill_bwd_kernel
     }
-    for (int c = 0; c < p.F; ++c) {
-      const long long e = (b * p.F + c) * (long long)p.S + r;
-      const float f = ft[e];
+    if (keep) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) a.gfi[k][e] = (kk == 0.f) ? 0.f : -(f - a.fi[k][e]) * sc[k];  // see distill_bwd_kernel
+      for (int c = 0; c < MAXF; ++c)
+        if (c < p.F) {
+          const long long e = (b * p.F + c) * (long long)p.S + r;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a.gfi[k][e] = (kk == 0.f) ? 0.f : -dreg[k][c] * sc[k];  // see distill_bwd_kernel
+        }
+    } else {
+      for (int c = 0; c < p.F; ++c) {
+        const long long e = (b * p.F + c) * (long long)p.S + r;
+        const float f = ft[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.gfi[k][e] = (kk == 0.f) ? 0.f : -(f - a.fi[k][e]) * sc[k];  // see distill_bwd_kernel
+      }
     }
   }
 }
