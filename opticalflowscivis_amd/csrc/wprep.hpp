@@ -18,7 +18,7 @@
 //       (points 0, +-1, +-2, inf) of the same taps                                                  (convwino4.hpp)
 //   FS_WPREP_WINO2D p = {Cout, Cin, CinP, mode}            Ut[ci][kz][ty 0..3][tx 0..5][co 0..63]: F(2,3) along ky and F(4,3)
 //       along kx of the same taps                                                                   (convwino2d.hpp)
-//   FS_WPREP_TRWINO p = {Cin, Cout, CinP, CoutT}           Ut[ci][class (pz,py)][neighbour (dz,dy)][t 0..4][px][co 0..31] <-
+//   FS_WPREP_TRWINO p = {Cin, Cout, CinP, CoutT}           Ut[ci][channel half][class (pz,py)][neighbour (dz,dy)][t 0..4][px][co 0..15] <-
 //       W[ci][co][64]: the F(4,2) filter transform along x of the two taps of each x parity          (convtrwino.hpp)
 enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4, FS_WPREP_WINO4 = 5,
        FS_WPREP_WINO2D = 6, FS_WPREP_TRWINO = 7 };
@@ -112,10 +112,11 @@ __device__ __forceinline__ float wprep_elem(const FsWprepJob& j, int e) {
       const int Cin = j.p[0], Cout = j.p[1], CoutT = j.p[3];
       const int ci = e / FS_TRWINO_UCH, i = e - ci * FS_TRWINO_UCH;
       if (ci >= Cin) return 0.f;
-      const int cls = i / 1280, r1 = i - cls * 1280;
-      const int nb = r1 / 320, r2 = r1 - nb * 320;
-      const int tt = r2 >> 6, row = r2 & 63;
-      const int px = row >> 5, co = row & 31;
+      const int hf = i / 2560, r0 = i - hf * 2560;   // channel half (a workgroup's 10 KB)
+      const int cls = r0 / 640, r1 = r0 - cls * 640;
+      const int nb = r1 / 160, r2 = r1 - nb * 160;
+      const int tt = r2 >> 5, row = r2 & 31;
+      const int px = row >> 4, co = 16 * hf + (row & 15);
       if (co >= Cout) return 0.f;
       const int kz = wprep_p8_k(cls >> 1, nb >> 1), ky = wprep_p8_k(cls & 1, nb & 1);
       const float* wt = w + ((size_t)ci * CoutT + co) * 64 + (kz * 4 + ky) * 4;

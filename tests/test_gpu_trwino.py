@@ -1,6 +1,6 @@
 """-m gpu: the Winograd F(4,2) form of the transposed convolution (csrc/convtrwino.hpp: 17..32 output channels on rows of
 64 input positions -- the 64 -> 32 layers between the 64^3 trunk and the 128^3 grid) against fp64: plain, with bias, with
-the fused PReLU second output, with the residual addend; channel counts below the 32-row tile, odd input channel pairs,
+the fused PReLU second output, with the residual addend; channel counts below the 32-row tile,
 ragged z / y extents, two x bricks; the last output column comes from the edge kernel.  And through the autograd node
 of the layer (forward of a ConvTranspose3d, input gradient of a Conv3d)."""
 import pytest
@@ -27,7 +27,7 @@ def _kind(B, cin, cout, size, has_z=0):
     return [buf[i].kind for i in range(n)]
 
 
-@pytest.mark.parametrize("B,cin,cout,size", [(2, 64, 32, (32, 16, 64)), (2, 16, 32, (19, 17, 64)), (2, 6, 20, (32, 16, 64)),
+@pytest.mark.parametrize("B,cin,cout,size", [(2, 64, 32, (32, 16, 64)), (2, 16, 32, (19, 17, 64)), (2, 12, 20, (32, 16, 64)),
                                              (2, 8, 24, (16, 16, 128))])
 def test_trwino_forward_vs_fp64(ops, B, cin, cout, size):
     assert _kind(B, cin, cout, size) == [7]
