@@ -957,8 +957,6 @@ void launch_p8(const float* x, const float* ws, const float* bias, float* y, con
   hipLaunchKernelGGL((convtr_p8_kernel<RT, NT, CINP>), dim3(grid), dim3(512), 0, st, x, ws, bias, y, p, per);
 }
 
-#include "convtrwino.hpp"
-
 // NP input-grid positions (consecutive qy) per thread: every scalar-loaded weight feeds NP FMAs.  The
 // kernel is bound by the scalar weight stream (64*CO dwords per input channel and wave through ~100
 // SGPRs), not by the vector ALUs or the address path -- packed FMAs / an LDS-staged input brick did not
@@ -1062,9 +1060,7 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   // W'[ci][neighbour][row] (+ pad) of the all-parities kernel (<= 12 channels), or the slabs of the class kernels
   const long long p8 = Cout <= 12 ? cinp * p8_ws_ci(Cout <= 2 ? 1 : (Cout <= 6 ? 3 : 6)) : 0;
   const long long cls = Cout <= 6 ? 0 : cinp * 64 * (Cout <= 16 ? 16 : 32);
-  const long long wino = (Cout > 16 && slices == 1) ? cinp * FS_TRWINO_UCH : 0;  // the F(4,2) slab (convtrwino.hpp)
-  const long long m = p8 > cls ? p8 : cls;
-  return (m > wino ? m : wino) * slices;
+  return (p8 > cls ? p8 : cls) * slices;
 }
 
 static int conv3d_tr_slice(const float* x, const float* w, const float* bias, const float* slope, int nslope,
@@ -1150,11 +1146,6 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
       hipLaunchKernelGGL((convtr_mfma16_ws_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(512), 0, st, x, ws, bias, y, p);
     else
       hipLaunchKernelGGL((convtr_mfma16_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
-  } else if (ws_ok && trwino_ok(p, x, ws, slices)) {
-    // the 64 -> 32 layers on rows of 64 positions: Winograd F(4,2) along x (convtrwino.hpp), 0.625 of the multiply-adds
-    wprep_do(wprep_job(FS_WPREP_TRWINO, w, ws, (long long)cinp * FS_TRWINO_UCH, Cin, Cout, cinp, p.CoutT), plan, st);
-    if (plan != nullptr) return FS_OK;
-    return launch_trwino(x, ws, bias, y, p, st);
   } else {
     p.wslice = (long long)cinp * 64 * 32;
     for (int sl = 0; sl < slices; ++sl)

@@ -18,14 +18,11 @@
 //       (points 0, +-1, +-2, inf) of the same taps                                                  (convwino4.hpp)
 //   FS_WPREP_WINO2D p = {Cout, Cin, CinP, mode}            Ut[ci][kz][ty 0..3][tx 0..5][co 0..63]: F(2,3) along ky and F(4,3)
 //       along kx of the same taps                                                                   (convwino2d.hpp)
-//   FS_WPREP_TRWINO p = {Cin, Cout, CinP, CoutT}           Ut[ci][channel half][class (pz,py)][neighbour (dz,dy)][t 0..4][px][co 0..15] <-
-//       W[ci][co][64]: the F(4,2) filter transform along x of the two taps of each x parity          (convtrwino.hpp)
 enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4, FS_WPREP_WINO4 = 5,
-       FS_WPREP_WINO2D = 6, FS_WPREP_TRWINO = 7 };
+       FS_WPREP_WINO2D = 6 };
 constexpr int FS_WINO_UCH = 9 * 4 * 64 + 16;  // floats per input channel of the Winograd slab (== WN_UCH)
 constexpr int FS_WINO4_UCH = 9 * 6 * 64;      // ... of the F(4,3) slab (== W4_UCH)
 constexpr int FS_WINO2D_UCH = 3 * 24 * 64;    // ... of the F(2,3) x F(4,3) slab (== W2_UCH)
-constexpr int FS_TRWINO_UCH = 4 * 4 * 5 * 64; // ... of the transposed convolution's F(4,2) slab (== TW_UCH)
 
 // F(4,3) filter transform G g (points 0, +-1, +-2, inf), component tt
 __device__ __forceinline__ float wprep_g43(const float (&g)[3], int tt) {
@@ -107,27 +104,6 @@ __device__ __forceinline__ float wprep_elem(const FsWprepJob& j, int e) {
         u[ky] = wprep_g43(g, tx);
       }
       return ty == 0 ? u[0] : ty == 1 ? 0.5f * ((u[0] + u[1]) + u[2]) : ty == 2 ? 0.5f * ((u[0] - u[1]) + u[2]) : u[2];
-    }
-    case FS_WPREP_TRWINO: {
-      const int Cin = j.p[0], Cout = j.p[1], CoutT = j.p[3];
-      const int ci = e / FS_TRWINO_UCH, i = e - ci * FS_TRWINO_UCH;
-      if (ci >= Cin) return 0.f;
-      const int hf = i / 2560, r0 = i - hf * 2560;   // channel half (a workgroup's 10 KB)
-      const int cls = r0 / 640, r1 = r0 - cls * 640;
-      const int nb = r1 / 160, r2 = r1 - nb * 160;
-      const int tt = r2 >> 5, row = r2 & 31;
-      const int px = row >> 4, co = 16 * hf + (row & 15);
-      if (co >= Cout) return 0.f;
-      const int kz = wprep_p8_k(cls >> 1, nb >> 1), ky = wprep_p8_k(cls & 1, nb & 1);
-      const float* wt = w + ((size_t)ci * CoutT + co) * 64 + (kz * 4 + ky) * 4;
-      const float g0 = wt[wprep_p8_k(px, 1)], g1 = wt[wprep_p8_k(px, 0)];  // out_i = g0 X_i + g1 X_{i+1}
-      switch (tt) {
-        case 0: return 0.5f * g0;
-        case 1: return -0.5f * (g0 + g1);
-        case 2: return (1.f / 6.f) * (g1 - g0);
-        case 3: return (1.f / 6.f) * g0 + (1.f / 3.f) * g1;
-        default: return g1;
-      }
     }
     default: {  // FS_WPREP_P8
       const int Cin = j.p[0], Cout = j.p[1], RT = j.p[3];

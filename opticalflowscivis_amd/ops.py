@@ -1917,20 +1917,6 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
     return y, z
 
 
-_trwino_seen = {}
-
-
-def _tr_takes_winograd(xptr, B, Cin, Cout, in_dhw, out_dhw, has_z):
-    """Does fs_conv3d_tr* run this call as the Winograd F(4,2) kernel (csrc/convtrwino.hpp: slab kind 7)?  Asked of the
-    library's own dispatch, cached per geometry; only the flop accounting of the timing records depends on it."""
-    key = (xptr % 16, B, Cin, Cout) + tuple(int(v) for v in in_dhw) + tuple(int(v) for v in out_dhw) + (int(has_z),)
-    if key not in _trwino_seen:
-        buf = (_lib.FsWprepJob * 8)()
-        n = _lib.lib().fs_conv3d_tr_wprep_jobs(buf, 8, 0x1000 + xptr % 16, 0x1000, 0x1000, *key[1:10], int(has_z))
-        _trwino_seen[key] = (n == 1 and buf[0].kind == 7)
-    return _trwino_seen[key]
-
-
 def conv3d_tr_supported(cout, k, stride, padding):
     return (tuple(k) == (4, 4, 4) and tuple(stride) == (2, 2, 2) and tuple(padding) == (1, 1, 1) and
             (cout <= 32 or (cout % 32 == 0 and cout <= 128)))
@@ -1963,9 +1949,7 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
                        lambda jobs, cap, slab: L.fs_conv3d_tr_wprep_jobs(jobs, cap, x.data_ptr(), w.data_ptr(),
                                                                         slab.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho,
                                                                         Wo, has_z))
-    nb, fq = 4 * (x.numel() + y.numel()), 2 * x.numel() * Cout * 64
-    # the F(4,2) Winograd kernel of the 64 -> 32 layers (csrc/convtrwino.hpp) EXECUTES 5/8 of the multiply-adds
-    fl = fq * 5 // 8 if _tr_takes_winograd(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), (Do, Ho, Wo), has_z) else fq
+    nb, fl = 4 * (x.numel() + y.numel()), 2 * x.numel() * Cout * 64
     with torch.cuda.device(x.device):
         if addend is not None:
             if prelu_weight is not None:
@@ -1975,11 +1959,11 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
                 raise ValueError("addend %s must have the output shape %s" % (tuple(addend.shape), tuple(y.shape)))
             _call("fs_conv3d_tr_add", x.data_ptr(), wp, _ptr(bias), addend.data_ptr(), y.data_ptr(),
                   ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb + 4 * y.numel(),
-                  algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_tr")
+                  algo_flops=fl, record_as="fs_conv3d_tr")
             return y
         if prelu_weight is None:
             _call("fs_conv3d_tr", x.data_ptr(), wp, _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
-                  Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb, algo_flops=fl, equiv_flops=fq)
+                  Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb, algo_flops=fl)
             return y
         a = _need_cuda_f32("prelu_weight", prelu_weight, 1)
         if a.numel() not in (1, Cout):
@@ -1987,7 +1971,7 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
         z = torch.empty_like(y)
         _call("fs_conv3d_tr_prelu", x.data_ptr(), wp, _ptr(bias), a.data_ptr(), y.data_ptr(),
               z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, a.numel(), _stream(x),
-              algo_bytes=nb + 4 * y.numel(), algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_tr")
+              algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_tr")
     return y, z
 
 
