@@ -39,8 +39,10 @@ enum {
  *   300  round 2 inserted `const int* in_hw` into fs_warp2d_{fwd,bwd} and fs_warp2d_pair_{fwd,bwd} (without bumping
  *        the number: fixed in round 3) and added the f1-f4 / conv3d entry points.
  *   310  round 3: fs_conv3d_fwd* / fs_conv3d_tr* accept w = NULL ("ws is prepared"), fs_conv3d_*_wprep_jobs,
- *        fs_conv3d_wprep_batch. */
-#define FS_ABI_VERSION 310
+ *        fs_conv3d_wprep_batch.
+ *   320  round 4: fs_conv3d_wrw_kernel_id (which weight-gradient kernel a call dispatches to; nothing launched).
+ *        The library reads no environment variable any more (measurement switches live in the -DFS_ABLATION build). */
+#define FS_ABI_VERSION 320
 int fs_version(void);
 /* Static string for an FS_* code. */
 const char* fs_error_string(int code);
@@ -540,6 +542,16 @@ int fs_prelu_bwd(const float* x, const float* grad_out, const float* weight,
 int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B, int Cg, int Cs,
                   int Do, int Ho, int Wo, int Di, int Hi, int Wi,
                   int kernel, int stride, int pad, fs_stream_t stream);
+/* Which kernel fs_conv3d_wrw runs for these arguments (its own dispatch, nothing launched, pointers only inspected
+ * for alignment; `dw` is not needed): FS_WRW_KERNEL_* >= 0, or -(FS_ERR_*) for arguments it would refuse.  For flop
+ * accounting (the Winograd form executes half the direct form's multiply-adds) and for tests that must know which
+ * kernel they exercised. */
+enum { FS_WRW_KERNEL_BRICK = 0,   /* register-staged position bricks (any shape) */
+       FS_WRW_KERNEL_DMA = 1,     /* loader-wave form, direct implicit GEMM */
+       FS_WRW_KERNEL_WINO23 = 2,  /* Winograd F(2,3) along x (ablation build only) */
+       FS_WRW_KERNEL_WINO43 = 3   /* Winograd F(4,3) along x: the 64 -> 64 k3 trunk layers */ };
+int fs_conv3d_wrw_kernel_id(const float* g, const float* src, int B, int Cg, int Cs,
+                            int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride, int pad);
 
 /* IFBlock's first convolution without its `torch.cat` (Flow-3D/model/IFNet.py:183 `x = torch.cat((x, flow), 1)`
  * over `torch.cat((img0, img1, warped_img0, warped_img1, mask), 1)`, :190-191): the Cin <= 12 input channels are

@@ -13,8 +13,27 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libflowsci_hip.so")
-ABI_VERSION = 310  # FS_ABI_VERSION of the include/flowsci_hip.h the SIGNATURES below were written against
+PRODUCT_LIB_PATH = os.path.join(_HERE, "csrc", "libflowsci_hip.so")
+# FLOWSCI_HIP_LIBRARY=<path>: load another build of the same sources instead -- the ablation build
+# (`make -C opticalflowscivis_amd/csrc ablation` -> csrc/ablation/libflowsci_hip_ab.so), in which superseded kernels and
+# the FLOWSCI_* measurement switches exist.  The product library reads no environment variable, and the package's own
+# A/B switches (`ablation_env`) are honoured only in this mode; bench.py reports the mode in its JSON line.
+LIB_PATH = os.environ.get("FLOWSCI_HIP_LIBRARY") or PRODUCT_LIB_PATH
+ABLATION = LIB_PATH != PRODUCT_LIB_PATH
+
+
+def ablation_env(name):
+    """Value of a FLOWSCI_* measurement switch, or None outside ablation mode (the switch then does not exist)."""
+    return os.environ.get(name) if ABLATION else None
+
+
+def switches():
+    """What in the environment can change dispatch or numerics: the library in use and every FLOWSCI_* variable set
+    (INTEGRATION.md "Switches" says which of them are read in which mode)."""
+    return {"library": "ablation build: " + LIB_PATH if ABLATION else "product",
+            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("FLOWSCI_")}}
+
+ABI_VERSION = 320  # FS_ABI_VERSION of the include/flowsci_hip.h the SIGNATURES below were written against
 
 _f32p = ctypes.c_void_p  # device pointers travel as integers
 _int = ctypes.c_int
@@ -99,6 +118,7 @@ SIGNATURES = {
     "fs_corr3d_fwd": [_f32p] * 3 + [_int] * 6 + [_stream],
     "fs_corr3d_bwd": [_f32p] * 5 + [_int] * 6 + [_stream],
     "fs_conv3d_wrw": [_f32p] * 3 + [_int] * 12 + [_stream],
+    "fs_conv3d_wrw_kernel_id": [_f32p] * 2 + [_int] * 12,
     "fs_conv3d_fwd_prelu_ms": [_ptrv, _i64p] + [_f32p] * 6 + [_int] * 13 + [_stream],
     "fs_conv3d_wrw_ms": [_f32p, _ptrv, _i64p, _f32p] + [_int] * 12 + [_stream],
     "fs_wssim_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],

@@ -49,8 +49,10 @@ def _note_stock_path(what, x, w, stride, padding):
                   RuntimeWarning, stacklevel=3)
 
 
-_MIN_WORKGROUPS = int(os.environ.get("FLOWSCI_CONV_FWD_MIN_WG", "0"))
-_MIN_TR_POSITIONS = int(os.environ.get("FLOWSCI_CONV_TR_MIN_POS", "0"))  # input voxels (all samples)
+from ._lib import ablation_env as _ab_env
+
+_MIN_WORKGROUPS = int(_ab_env("FLOWSCI_CONV_FWD_MIN_WG") or 0)      # (measurement switches: ablation mode only)
+_MIN_TR_POSITIONS = int(_ab_env("FLOWSCI_CONV_TR_MIN_POS") or 0)    # input voxels (all samples)
 
 
 def _hip_fwd_ok(x, cout, out_dhw, k, stride, padding):
@@ -288,7 +290,7 @@ def conv_prelu_cat(block, pieces):
     kernels can read the pieces in place (training on the GPU, fp32, k = 4 / stride 2); None otherwise."""
     conv, act = block[0], block[1]
     x0 = pieces[0]
-    if os.environ.get("FLOWSCI_CONV0_CAT") == "1":  # A/B switch: concatenate as the reference does
+    if _ab_env("FLOWSCI_CONV0_CAT") == "1":  # A/B switch (ablation mode): concatenate as the reference does
         return None
     if not (_hip_autograd(x0) and x0.dim() == 5 and x0.dtype == torch.float32 and isinstance(conv, Conv3d)
             and act.weight.numel() in (1, conv.out_channels) and conv.groups == 1
@@ -357,7 +359,7 @@ def head_fused_ok(head, x, addend):
         (addend is None or (addend.is_cuda and addend.dtype == torch.float32))
 
 
-_FUSE_2D = os.environ.get("FLOWSCI_CONV2D_UNFUSED") != "1"  # A/B switch: 2-D (conv, PReLU) pairs as two stock nodes
+_FUSE_2D = _ab_env("FLOWSCI_CONV2D_UNFUSED") != "1"  # A/B switch (ablation mode): 2-D (conv, PReLU) pairs as two stock nodes
 
 
 class ConvPReLU(nn.Sequential):

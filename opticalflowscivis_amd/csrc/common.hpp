@@ -19,6 +19,19 @@
     if (hipGetLastError() != hipSuccess) return FS_ERR_LAUNCH; \
   } while (0)
 
+// Measurement switches.  The shipped library reads NO environment variable: every dispatch decision is a function of
+// the call's arguments.  A/B and ablation runs use a second build of the same sources (`make ablation`,
+// -DFS_ABLATION -> ablation/libflowsci_hip_ab.so, loaded only through FLOWSCI_HIP_LIBRARY=<path>), in which the
+// superseded kernels are compiled in and FLOWSCI_* variables (latched once per process) select them.
+#ifdef FS_ABLATION
+#include <stdlib.h>
+#define FS_AB_ENV(name) (getenv(name) != nullptr)
+#define FS_AB_ENV_LL(name, dflt) (getenv(name) ? atoll(getenv(name)) : (long long)(dflt))
+#else
+#define FS_AB_ENV(name) false
+#define FS_AB_ENV_LL(name, dflt) ((long long)(dflt))
+#endif
+
 namespace fs {
 
 constexpr int kWave = 64;

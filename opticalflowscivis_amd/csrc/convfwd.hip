@@ -612,8 +612,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
   }
 }
 
+#ifdef FS_ABLATION  // the 1-D forms convwino2d.hpp superseded on every shape they cover: measurement builds only
 #include "convwino.hpp"
 #include "convwino4.hpp"
+#endif
 #include "convwino2d.hpp"
 
 template <int K, int S, int CI, int MT, int NT, int TZ, int TY, int TW>
@@ -787,6 +789,7 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     if (rc != FS_OK || dp == nullptr) return rc;
     return dp_finish(64, 1);
   }
+#ifdef FS_ABLATION
   // ... F(4,3) (convwino4.hpp: half the direct form's multiply-adds) where its 4 x 2 x 64 bricks fill the chip
   if (wino4_ok(p, x, ws, Cin, Cout, kernel, stride, ms != nullptr) &&
       (dp == nullptr || (bias == nullptr && z == nullptr && addend == nullptr))) {
@@ -804,13 +807,14 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     if (rc != FS_OK || dp == nullptr) return rc;
     return dp_finish(64);
   }
+#endif
   wprep_do(wprep_job(FS_WPREP_FWD, w, ws, (long long)cinp * K3 * p.CoutP, Cout, Cin, K3, cinp, p.CoutP, wmode), plan, st);
   if (plan != nullptr) return FS_OK;  // every kernel below reads the same slab
   // loader-wave kernels (k = 4: 100 / 129 TFLOP/s vs 92 / 120 for conv0a / conv0b at 256^3; k = 3: every 32-column
   // layer, see below): 16-byte
   // pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets inside one staged channel
   // chunk, enough bricks to fill the chip with one workgroup per CU
-  static const bool reg_only = getenv("FLOWSCI_FWD_REG") != nullptr;
+  static const bool reg_only = FS_AB_ENV("FLOWSCI_FWD_REG");
   const bool ws_ok = !reg_only && Wi % 4 == 0 && Wo > 16 && (((ms ? (uintptr_t)0 : (uintptr_t)x) | (uintptr_t)ws) & 15) == 0 &&
                      ms_aligned && (long long)(kernel == 3 ? 4 : 2) * Di * Hi * Wi * 4 < (1ll << 31);
   // only the 32-channel loader-wave kernel reads per-channel planes (IFBlock's conv0[0] at scale 1)

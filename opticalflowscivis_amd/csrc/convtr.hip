@@ -1091,11 +1091,11 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   p.wslice = 0;
   hipStream_t st = (hipStream_t)stream;
   if ((long long)B * p.Dq * p.Hq * p.Wq >= (1ll << 31) * 256) return FS_ERR_SHAPE;
-  static const bool reg_only = getenv("FLOWSCI_TR_REG") != nullptr;
+  static const bool reg_only = FS_AB_ENV("FLOWSCI_TR_REG");
   // (the 6-row-tile instantiation for 7..12 channels works -- tests/test_gpu_losses.py covers it through
   // FLOWSCI_TR_P8_ALL=1 -- but measured 2.50 vs 2.44 ms against the 16-row class kernel on the 32 -> 11 input
   // gradient at 128^3, so those layers stay there)
-  static const bool p8_all = getenv("FLOWSCI_TR_P8_ALL") != nullptr;
+  static const bool p8_all = FS_AB_ENV("FLOWSCI_TR_P8_ALL");
   if (Cout <= (p8_all ? 12 : 6) && !reg_only && z == nullptr && ws != nullptr && Cin <= (Cout <= 6 ? 64 : 32) && Dout == 2 * Di && Hout == 2 * Hi &&
       Wout == 2 * Wi && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 &&
       (long long)4 * Di * Hi * Wi * 4 < (1ll << 31)) {

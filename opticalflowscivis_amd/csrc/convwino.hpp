@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino_ws_kernel(const float* __r
 }
 
 inline bool wino_ok(const FP& p, const float* x, const float* ws, int Cin, int Cout, int kernel, int stride, bool has_ms) {
-  static const bool off = getenv("FLOWSCI_FWD_NO_WINO") != nullptr;
+  static const bool off = FS_AB_ENV("FLOWSCI_FWD_NO_WINO");
   if (off || kernel != 3 || stride != 1 || p.pad != 1 || has_ms) return false;
   if (Cin % 4 != 0 || Cout > 64 || p.CoutP != 64) return false;
   if (p.Wi != p.Wo || p.Wi % 64 != 0 || p.Di != p.Do || p.Hi != p.Ho) return false;

@@ -344,8 +344,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ws_kernel(const float* _
 inline int wino2d_xt(const FP& p) { return p.Wo % 64 == 0 ? 16 : 8; }
 
 inline bool wino2d_ok(const FP& p, const float* x, const float* ws, int Cin, int Cout, int kernel, int stride, bool has_ms) {
-  static const bool off = getenv("FLOWSCI_FWD_NO_WINO2D") != nullptr || getenv("FLOWSCI_FWD_NO_WINO4") != nullptr ||
-                          getenv("FLOWSCI_FWD_NO_WINO") != nullptr;
+  static const bool off = FS_AB_ENV("FLOWSCI_FWD_NO_WINO2D") || FS_AB_ENV("FLOWSCI_FWD_NO_WINO4") || FS_AB_ENV("FLOWSCI_FWD_NO_WINO");
   if (off || kernel != 3 || stride != 1 || p.pad != 1 || has_ms) return false;
   if (Cin % 4 != 0 || Cout > 64 || p.CoutP != 64) return false;
   if (p.Wi != p.Wo || p.Wi % 32 != 0 || p.Di != p.Do || p.Hi != p.Ho) return false;
@@ -354,20 +353,23 @@ inline bool wino2d_ok(const FP& p, const float* x, const float* ws, int Cin, int
   // one brick (2 z x 2 y x 64 x, or 2 z x 4 y x 32 x) per CU is enough: measured (tests/tools/wino_bench.py, 64 -> 64 layer)
   // 0.072 ms at 256 bricks against 0.129 for the direct small-brick kernel, 0.131 / 0.143 / 0.183 / 0.257 (2-D / F(4,3) /
   // F(2,3) / direct) at 512; the 64^3 trunk has 2048
-  static const long long min_bricks = getenv("FLOWSCI_WINO2D_MIN") ? atoll(getenv("FLOWSCI_WINO2D_MIN")) : 256;
+  static const long long min_bricks = FS_AB_ENV_LL("FLOWSCI_WINO2D_MIN", 256);
   const int xt = wino2d_xt(p);
   return (long long)p.B * fs::cdiv(p.Do, 2) * fs::cdiv(p.Ho, 2 * (16 / xt)) * (p.Wo / (4 * xt)) >= min_bricks;
 }
 
 template <int XT>
 void launch_wino2d_t(const float* X, const float* Ut, const float* bias, float* Y, const FP& p, hipStream_t st) {
-  static const int dbg = getenv("FLOWSCI_WINO_DBG") ? atoi(getenv("FLOWSCI_WINO_DBG")) : 0;
   const dim3 g((unsigned)p.tiles, 1);
+#ifdef FS_ABLATION  // instantiations that SKIP work (wrong results by design): measurement builds only
+  static const int dbg = (int)FS_AB_ENV_LL("FLOWSCI_WINO_DBG", 0);
   if (dbg == 1) hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<1, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
   else if (dbg == 2) hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<2, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
   else if (dbg == 3) hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<3, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
   else if (dbg == 4) hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<4, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
-  else hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<0, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
+  else
+#endif
+    hipLaunchKernelGGL((conv3d_wino2d_ws_kernel<0, XT>), g, dim3(512), 0, st, X, Ut, bias, Y, p);
 }
 
 inline int launch_wino2d(const float* X, const float* Ut, const float* bias, float* Y, FP& p, hipStream_t st) {

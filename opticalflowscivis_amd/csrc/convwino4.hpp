@@ -264,14 +264,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino4_ws_kernel(const float* __
 }
 
 inline bool wino4_ok(const FP& p, const float* x, const float* ws, int Cin, int Cout, int kernel, int stride, bool has_ms) {
-  static const bool off = getenv("FLOWSCI_FWD_NO_WINO4") != nullptr || getenv("FLOWSCI_FWD_NO_WINO") != nullptr;
+  static const bool off = FS_AB_ENV("FLOWSCI_FWD_NO_WINO4") || FS_AB_ENV("FLOWSCI_FWD_NO_WINO");
   if (off || kernel != 3 || stride != 1 || p.pad != 1 || has_ms) return false;
   if (Cin % 4 != 0 || Cout > 64 || p.CoutP != 64) return false;
   if (p.Wi != p.Wo || p.Wi % 64 != 0 || p.Di != p.Do || p.Hi != p.Ho) return false;
   if ((((uintptr_t)x | (uintptr_t)ws) & 15) != 0) return false;
   if ((long long)p.Di * p.Hi * p.Wi * 4 >= (1ll << 31)) return false;
   // enough bricks for two rounds of one workgroup per CU (the 64^3 trunk of the scale-1 blocks: 2 x 16 x 32 x 1 = 1024)
-  static const long long min_bricks = getenv("FLOWSCI_WINO4_MIN") ? atoll(getenv("FLOWSCI_WINO4_MIN")) : 512;
+  static const long long min_bricks = FS_AB_ENV_LL("FLOWSCI_WINO4_MIN", 512);
   return (long long)p.B * fs::cdiv(p.Do, 4) * fs::cdiv(p.Ho, 2) * (p.Wo / 64) >= min_bricks;
 }
 

@@ -623,10 +623,18 @@ extern "C" int fs_debug_wrw_stamps(unsigned long long* out) {
 }
 #endif
 
+// `plan` != nullptr: write the FS_WRW_KERNEL_* id the call dispatches to and launch nothing (fs_conv3d_wrw_kernel_id)
+#define FS_WRW_PICK(id, ...)        \
+  do {                              \
+    if (plan != nullptr) { *plan = (id); return FS_OK; } \
+    return __VA_ARGS__;             \
+  } while (0)
+
 static int conv3d_wrw_impl(const float* g, const float* src, const float* const* srcv, const long long* sbsv, float* dw,
                            int B, int Cg, int Cs, int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride,
-                           int pad, fs_stream_t stream) {
-  FS_REQUIRE_PTR(g); FS_REQUIRE_PTR(dw);
+                           int pad, fs_stream_t stream, int* plan = nullptr) {
+  FS_REQUIRE_PTR(g);
+  if (plan == nullptr) FS_REQUIRE_PTR(dw);
   if (srcv == nullptr) FS_REQUIRE_PTR(src);
   if (B < 1 || Cg < 1 || Cs < 1 || Do < 1 || Ho < 1 || Wo < 1 || Di < 1 || Hi < 1 || Wi < 1)
     return FS_ERR_SHAPE;
@@ -658,33 +666,43 @@ static int conv3d_wrw_impl(const float* g, const float* src, const float* const*
   // DMA-staged kernel: 16-byte pieces (W % 4 == 0 on both grids, 16-byte aligned tensors), a full brick column,
   // pad <= stride, 31-bit byte offsets inside one (b, chunk) slab.  `FLOWSCI_WRW_REG=1`: the register-staged
   // kernel everywhere (scripts/wrwbench.py compares the two).
-  static const bool reg_only = getenv("FLOWSCI_WRW_REG") != nullptr;
+  static const bool reg_only = FS_AB_ENV("FLOWSCI_WRW_REG");
   const bool dma_ok = !reg_only && pad <= stride && (Wo >= KW || Wo == 16) && Wo % 4 == 0 && Wi % 4 == 0 &&
                       (((uintptr_t)g | (srcv ? (uintptr_t)0 : (uintptr_t)src)) & 15) == 0 && ms_aligned &&
                       (long long)64 * Do * Ho * Wo * 4 < (1ll << 31) && (long long)16 * Di * Hi * Wi * 4 < (1ll << 31);
   // per-channel planes: only the loader-wave kernel of IFBlock's conv0[0] (k = 4, <= 32 gradient channels)
   if (srcv != nullptr) {
-    if (dma_ok && kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) return launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st);
+    if (dma_ok && kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st));
     return FS_ERR_UNSUPPORTED;
   }
   // the 64 -> 64 k3 layers of the 64^3 trunk: the Winograd F(4,3) form (convwrwwino4.hpp), or F(2,3) (convwrwwino.hpp)
-  if (dma_ok && wrw_wino4_ok(p, g, src, kernel, stride)) return launch_wrw_wino4(g, src, dw, p, st);
-  if (dma_ok && wrw_wino_ok(p, g, src, kernel, stride)) return launch_wrw_wino(g, src, dw, p, st);
+  if (dma_ok && wrw_wino4_ok(p, g, src, kernel, stride)) FS_WRW_PICK(FS_WRW_KERNEL_WINO43, launch_wrw_wino4(g, src, dw, p, st));
+#ifdef FS_ABLATION
+  if (dma_ok && wrw_wino_ok(p, g, src, kernel, stride)) FS_WRW_PICK(FS_WRW_KERNEL_WINO23, launch_wrw_wino(g, src, dw, p, st));
+#endif
   if (dma_ok) {
-    if (kernel == 3 && Cg > 32 && Cs >= 8 && Wo == 16) return launch_dma<3, 1, 16, 2, 1, 4, 3, 1, 16>(g, src, dw, p, st);
-    if (kernel == 3 && Cg > 32 && Cs >= 8) return launch_dma<3, 1, 16, 2, 1, 4, 3, 1>(g, src, dw, p, st);
-    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo == 16) return launch_dma<4, 2, 8, 2, 1, 2, 4, 0, 16>(g, src, dw, p, st);
-    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo >= KW) return launch_dma<4, 2, 8, 2, 1, 2, 4, 0>(g, src, dw, p, st);
-    if (kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) return launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st);
+    if (kernel == 3 && Cg > 32 && Cs >= 8 && Wo == 16) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<3, 1, 16, 2, 1, 4, 3, 1, 16>(g, src, dw, p, st));
+    if (kernel == 3 && Cg > 32 && Cs >= 8) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<3, 1, 16, 2, 1, 4, 3, 1>(g, src, dw, p, st));
+    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo == 16) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 8, 2, 1, 2, 4, 0, 16>(g, src, dw, p, st));
+    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 8, 2, 1, 2, 4, 0>(g, src, dw, p, st));
+    if (kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st));
     // 1-2 source channels (the mask head: 128 columns, one 32-column tile per matrix wave): bound by the G stream
-    if (kernel == 4 && Cg <= 32 && Wo >= KW) return launch_dma<4, 2, 2, 1, 2, 2, 1, 0>(g, src, dw, p, st);
+    if (kernel == 4 && Cg <= 32 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 2, 1, 2, 2, 1, 0>(g, src, dw, p, st));
   }
-  if (kernel == 3) return launch_brick<3, 1, 8, 1, 4>(g, src, dw, p, st);
+  if (kernel == 3) FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<3, 1, 8, 1, 4>(g, src, dw, p, st));
   // k = 4: 64 columns per source channel.  NC = 4 gives every wave two 32-column tiles, NC = 2 one;
   // pick the chunking with less padded matrix work (Cs = 1, 2, 5, 6: the IFNet heads / block0 input)
   const int cost2 = (Cs + 1) / 2, cost4 = 2 * ((Cs + 3) / 4);
-  if (cost2 < cost4) return launch_brick<4, 2, 2, 1, 2>(g, src, dw, p, st);
-  return launch_brick<4, 2, 4, 1, 2>(g, src, dw, p, st);
+  if (cost2 < cost4) FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<4, 2, 2, 1, 2>(g, src, dw, p, st));
+  FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<4, 2, 4, 1, 2>(g, src, dw, p, st));
+}
+
+extern "C" int fs_conv3d_wrw_kernel_id(const float* g, const float* src, int B, int Cg, int Cs, int Do, int Ho, int Wo,
+                                       int Di, int Hi, int Wi, int kernel, int stride, int pad) {
+  int id = -1;
+  const int rc = conv3d_wrw_impl(g, src, nullptr, nullptr, nullptr, B, Cg, Cs, Do, Ho, Wo, Di, Hi, Wi, kernel, stride, pad,
+                                 nullptr, &id);
+  return rc == FS_OK ? id : -rc;
 }
 
 extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B, int Cg, int Cs, int Do,

@@ -125,6 +125,7 @@ __device__ __forceinline__ void ww_loader_waves(const float* __restrict__ G, con
 // 0.78 ms as built; matrix waves + epilogue alone 0.79 -> the MFMA work at the kernel's clock is 0.57; loaders +
 // epilogue alone 0.26; the direct kernel 0.96.  Letting the compiler interleave operand reads and transforms with the
 // MFMAs (no sched_barrier, or sched_group_barrier MFMA / DS / VALU triples) changes nothing.
+#ifdef FS_ABLATION  // the F(2,3) kernel: superseded by convwrwwino4.hpp on every shape (measurement builds only)
 template <int DBG>
 __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __restrict__ G,
                                                                 const float* __restrict__ Src,
@@ -261,8 +262,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino_kernel(const float* __
   }
 }
 
+#endif  // FS_ABLATION
+
 inline bool wrw_wino_ok(const WP& w, const float* g, const float* src, int kernel, int stride) {
-  static const bool off = getenv("FLOWSCI_WRW_NO_WINO") != nullptr;
+  static const bool off = FS_AB_ENV("FLOWSCI_WRW_NO_WINO");
   if (off || kernel != 3 || stride != 1 || w.pad != 1 || w.nsrc != 0) return false;
   if (w.Cg != 64 || w.Cs != 64) return false;
   if (w.Do != w.Di || w.Ho != w.Hi || w.Wo != w.Wi || w.Wo % 64 != 0 || w.Ho % WW_TY != 0) return false;
@@ -272,6 +275,7 @@ inline bool wrw_wino_ok(const WP& w, const float* g, const float* src, int kerne
   return (long long)w.B * w.Do * (w.Ho / WW_TY) * (w.Wo / 64) >= 1024;
 }
 
+#ifdef FS_ABLATION
 inline int launch_wrw_wino(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st) {
   WWP p;
   p.B = w.B; p.D = w.Do; p.H = w.Ho; p.W = w.Wo;
@@ -281,10 +285,11 @@ inline int launch_wrw_wino(const float* G, const float* Src, float* dW, const WP
   long long spw = (p.bricks + slabs - 1) / slabs;
   p.spw = (int)spw;
   const long long gx = (p.bricks + spw - 1) / spw;
-  static const int dbg = getenv("FLOWSCI_WINO_DBG") ? atoi(getenv("FLOWSCI_WINO_DBG")) : 0;
+  static const int dbg = (int)FS_AB_ENV_LL("FLOWSCI_WINO_DBG", 0);
   if (dbg == 1) hipLaunchKernelGGL(conv3d_wrw_wino_kernel<1>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   else if (dbg == 2) hipLaunchKernelGGL(conv3d_wrw_wino_kernel<2>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   else hipLaunchKernelGGL(conv3d_wrw_wino_kernel<0>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
+#endif  // FS_ABLATION

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino4_kernel(const float* _
 }
 
 inline bool wrw_wino4_ok(const WP& w, const float* g, const float* src, int kernel, int stride) {
-  static const bool off = getenv("FLOWSCI_WRW_NO_WINO4") != nullptr;
+  static const bool off = FS_AB_ENV("FLOWSCI_WRW_NO_WINO4");
   return !off && wrw_wino_ok(w, g, src, kernel, stride);  // same shapes, same bricks
 }
 
@@ -163,10 +163,13 @@ inline int launch_wrw_wino4(const float* G, const float* Src, float* dW, const W
   long long spw = (p.bricks + slabs - 1) / slabs;
   p.spw = (int)spw;
   const long long gx = (p.bricks + spw - 1) / spw;
-  static const int dbg = getenv("FLOWSCI_WINO_DBG") ? atoi(getenv("FLOWSCI_WINO_DBG")) : 0;
+#ifdef FS_ABLATION  // instantiations that SKIP work (wrong results by design): measurement builds only
+  static const int dbg = (int)FS_AB_ENV_LL("FLOWSCI_WINO_DBG", 0);
   if (dbg == 1) hipLaunchKernelGGL(conv3d_wrw_wino4_kernel<1>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   else if (dbg == 2) hipLaunchKernelGGL(conv3d_wrw_wino4_kernel<2>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
-  else hipLaunchKernelGGL(conv3d_wrw_wino4_kernel<0>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
+  else
+#endif
+    hipLaunchKernelGGL(conv3d_wrw_wino4_kernel<0>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -472,7 +472,7 @@ extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, flo
                          grad_in, p);
   } else if (ws != nullptr) {
     // x2: one fused pass; FLOWSCI_INTERP_SEPARABLE=1: the three separable launches it replaced (A/B)
-    static const bool separable = getenv("FLOWSCI_INTERP_SEPARABLE") != nullptr;
+    static const bool separable = FS_AB_ENV("FLOWSCI_INTERP_SEPARABLE");
     const long long tiles2 = (long long)((p.Wi + 31) / 32) * ((p.Hi + 7) / 8) * ((p.Di + 3) / 4) * p.nBC;
     // (x2: 0.83 -> 0.38 ms for a [2,6,256^3] gradient; x4: the fused form's stride-4 row gathers make it slower than
     // the separable passes, 0.64 vs 0.45 ms, so that scale keeps them)

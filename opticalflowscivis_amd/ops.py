@@ -68,15 +68,16 @@ def enable_kernel_timing(on=True, only=None):
 
 
 def kernel_timings():
-    """{entry point: [(ms, algorithmic HBM bytes, matrix-core flops EXECUTED, flops of the direct formulation) per
-    launch]} recorded so far (synchronises).  The two flop counts differ for the Winograd convolutions only (2/3)."""
+    """{entry point: [(ms, algorithmic HBM bytes, matrix-core flops EXECUTED, flops of the direct formulation, kernel
+    symbol or None) per launch]} recorded so far (synchronises).  The two flop counts differ for the Winograd
+    convolutions only (1/3, 1/2); the kernel symbol is known where the entry point's dispatch can be asked for it."""
     if _timing is None:
         return {}
     torch.cuda.synchronize()
-    return {k: [(a.elapsed_time(b), nb, fl, fe) for a, b, nb, fl, fe in v] for k, v in _timing.items()}
+    return {k: [(a.elapsed_time(b), nb, fl, fe, sym) for a, b, nb, fl, fe, sym in v] for k, v in _timing.items()}
 
 
-def _call(name, *args, algo_bytes=0, algo_flops=0, record_as=None, equiv_flops=None):
+def _call(name, *args, algo_bytes=0, algo_flops=0, record_as=None, equiv_flops=None, kernel=None):
     """Launch a C-ABI entry point.  `algo_bytes` / `algo_flops` = compulsory HBM bytes / useful flops of
     this launch, only used by the optional timing records (`record_as`: file the record
     under another entry point's name -- the *_prelu variants are the same kernels with one more store)."""
@@ -91,10 +92,10 @@ def _call(name, *args, algo_bytes=0, algo_flops=0, record_as=None, equiv_flops=N
     e1.record()
     _lib.check(code, name)
     _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops,
-                                                      algo_flops if equiv_flops is None else equiv_flops))
+                                                      algo_flops if equiv_flops is None else equiv_flops, kernel))
 
 
-def _call_rc(name, *args, algo_bytes=0, algo_flops=0, record_as=None, allow=(), equiv_flops=None):
+def _call_rc(name, *args, algo_bytes=0, algo_flops=0, record_as=None, allow=(), equiv_flops=None, kernel=None):
     """_call for entry points that may answer with a status in `allow` (FS_ERR_UNSUPPORTED: "no such kernel for
     this shape, take the unfused path"): returns the status instead of raising on those."""
     fn = getattr(_lib.lib(), name)
@@ -107,7 +108,7 @@ def _call_rc(name, *args, algo_bytes=0, algo_flops=0, record_as=None, allow=(), 
         e1.record()
         if rc == 0:
             _timing.setdefault(record_as or name, []).append((e0, e1, algo_bytes, algo_flops,
-                                                              algo_flops if equiv_flops is None else equiv_flops))
+                                                              algo_flops if equiv_flops is None else equiv_flops, kernel))
     if rc not in allow:
         _lib.check(rc, name)
     return rc
@@ -1469,12 +1470,12 @@ def corr3d(f1, f2, max_displacement=4):
 # weights change only at its end (the optimiser step): leaving it makes every slab stale.  That explicit epoch is the
 # rule; tensor version counters are checked as well, but they cannot be the rule: torch's fused AdamW updates
 # parameters without bumping them.  Outside such a block (a bare IFNet, the convgrad modules in someone else's
-# model) every convolution prepares its weights itself, as before.  FLOWSCI_WPREP_PER_LAUNCH=1: never keep slabs.
+# model) every convolution prepares its weights itself, as before.  FLOWSCI_WPREP_PER_LAUNCH=1 (ablation mode): never keep slabs.
 import contextlib as _contextlib
 import os as _os
 import weakref as _weakref
 
-_PREP_ON = _os.environ.get("FLOWSCI_WPREP_PER_LAUNCH") != "1"
+_PREP_ON = _lib.ablation_env("FLOWSCI_WPREP_PER_LAUNCH") != "1"
 _prep_epoch = 0
 _prep_depth = 0
 _prep_tables = {}
@@ -1497,18 +1498,28 @@ def prepared_weights():
         _prep_depth -= 1
         invalidate_prepared_weights()
         if _prep_depth == 0 and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
-            for tab in _prep_tables.values():  # layers met for the first time in this block join the batch table
+            for tab in _prep_tables.values():  # layers met for the first time in this block join the batch table,
+                tab._evict()                   # slabs no block has used for a while leave it
                 if tab.dirty:
                     tab.upload()
 
 
 class _PrepEntry:
-    __slots__ = ("wref", "ws", "jobs", "stamp")
+    __slots__ = ("wref", "ws", "jobs", "stamp", "used", "pinned")
+
+
+_PREP_KEEP_EPOCHS = 8      # a slab not used for this many weight epochs (optimiser steps / inference calls) is dropped
+_PREP_MAX_JOBS = 65535     # fs_conv3d_wprep_batch's grid limit
 
 
 class _PrepTable:
     def __init__(self, device):
         self.device, self.entries, self.dirty, self.dev_jobs, self.njobs = device, {}, False, None, 0
+        # what a HIP-graph capture has baked in as raw pointers -- job tables (the captured fs_conv3d_wprep_batch
+        # launch reads `dev_jobs.data_ptr()`) and slabs (the captured convolutions read `ws`) -- must never go back
+        # to the caching allocator while the graph may be replayed; a graph has no destructor hook here, so they are
+        # kept for the life of the process (a table is 48 B per job, a slab 1-2 MB per layer and shape)
+        self.captured = []
 
     def _live(self):
         live = []
@@ -1521,11 +1532,23 @@ class _PrepTable:
                 live.append((e, w))
         return live
 
+    def _evict(self):
+        """Variable-size inference / evaluation meets a new geometry per call: slabs that no block has used for
+        _PREP_KEEP_EPOCHS epochs leave the table (and the batch launch) unless a captured graph reads them."""
+        for k, e in list(self.entries.items()):
+            if not e.pinned and _prep_epoch - e.used > _PREP_KEEP_EPOCHS:
+                del self.entries[k]
+                self.dirty = True
+
     def upload(self):
         """(Re)build the device copy of the job table -- a pinned host buffer and an H2D copy: not capturable, so
-        prepared_weights() does it when a block ends, never inside a HIP-graph capture."""
+        prepared_weights() does it when a block ends, never inside a HIP-graph capture.  The previous table is
+        simply dropped unless a capture referenced it (`captured`)."""
+        self._evict()
         live = self._live()
         jobs = [j for e, _ in live for j in e.jobs]
+        if len(jobs) > _PREP_MAX_JOBS:  # more than one launch can take: every convolution prepares its own weights
+            jobs = []
         if jobs:
             arr = (_lib.FsWprepJob * len(jobs))(*jobs)
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
@@ -1544,11 +1567,16 @@ class _PrepTable:
         live = self._live()
         if self.dirty:  # an entry died between the upload and now
             return False
-        if self.njobs:
-            with torch.cuda.device(self.device):
-                _call("fs_conv3d_wprep_batch", self.dev_jobs.data_ptr(), self.njobs,
-                      torch.cuda.current_stream(self.device).cuda_stream,
-                      algo_bytes=8 * sum(j.total for e, _ in live for j in e.jobs))
+        if not self.njobs:
+            return False  # nothing registered, or too many jobs for one launch: per-launch preparation
+        if torch.cuda.is_current_stream_capturing():
+            self.captured.append(self.dev_jobs)       # the graph replays this launch with this table's address
+            for e, _ in live:
+                e.pinned = True
+        with torch.cuda.device(self.device):
+            _call("fs_conv3d_wprep_batch", self.dev_jobs.data_ptr(), self.njobs,
+                  torch.cuda.current_stream(self.device).cuda_stream,
+                  algo_bytes=8 * sum(j.total for e, _ in live for j in e.jobs))
         for e, w in live:
             e.stamp = (w._version, _prep_epoch)
         return True
@@ -1562,11 +1590,19 @@ def _prepared(w, nfloats, key, plan):
     tab = _prep_tables.get((w.device.type, w.device.index))
     if tab is None:
         tab = _prep_tables[(w.device.type, w.device.index)] = _PrepTable(w.device)
+    global _last_prep
     k = (w.data_ptr(), tuple(w.shape)) + key
     e = tab.entries.get(k)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if e is not None and e.wref() is not None:
+        e.used = _prep_epoch
+        if capturing and not e.pinned:  # a captured convolution reads this slab by address from now on
+            e.pinned = True
+            tab.captured.append(e.ws)
+    _last_prep = e
     if e is None or e.wref() is None:
-        e = _PrepEntry()
-        e.wref, e.stamp = _weakref.ref(w), None
+        e = _last_prep = _PrepEntry()
+        e.wref, e.stamp, e.used, e.pinned = _weakref.ref(w), None, _prep_epoch, capturing
         e.ws = torch.empty(max(int(nfloats), 1), device=w.device, dtype=torch.float32)
         buf = (_lib.FsWprepJob * 4)()
         n = int(plan(buf, 4, e.ws))
@@ -1575,6 +1611,8 @@ def _prepared(w, nfloats, key, plan):
         e.jobs = [_lib.FsWprepJob.from_buffer_copy(buf[i]) for i in range(n)]
         tab.entries[k] = e
         tab.dirty = True
+        if capturing:
+            tab.captured.append(e.ws)
         # first use: the convolution re-lays the weights into the (now persistent) slab itself, as the classic path does;
         # from the next stale epoch on the slab is part of the device's one batch launch
         e.stamp = (w._version, _prep_epoch)
@@ -1585,6 +1623,17 @@ def _prepared(w, nfloats, key, plan):
         e.stamp = (w._version, _prep_epoch)
         return w.data_ptr(), e.ws
     return 0, e.ws
+
+
+_last_prep = None
+
+
+def _prep_not_written():
+    """The entry point that was handed the last `_prepared` slab answered FS_ERR_UNSUPPORTED: it may have returned
+    before its own re-layout ran (csrc/convfwd.hip rejects > 12 source planes first), so the entry's "current" stamp
+    does not describe the slab -- the fallback call with the same key must lay the weights out itself."""
+    if _last_prep is not None:
+        _last_prep.stamp = None
 
 
 _wino_seen = {}
@@ -1603,6 +1652,13 @@ def _fwd_k3_macs(xptr, B, Cin, Cout, dhw, wmode):
                                                 *key[4:7], 3, 1, 1, int(wmode))
         _wino_seen[key] = {4: 18.0, 5: 13.5, 6: 9.0}.get(buf[0].kind, 27.0) if n == 1 else 27.0
     return _wino_seen[key]
+
+
+def _fwd_k3_symbol(macs, W):
+    """Kernel symbol of a k3 s1 p1 fs_conv3d_fwd* call whose dispatch executes `macs` multiply-adds per (output, input
+    channel) -- the names `rocprofv3 --kernel-trace --stats` prints (csrc/convwino2d.hpp::launch_wino2d: 16 x-tiles per
+    row on rows of 64 voxels, 8 on rows of 32); None for the direct kernels (several instantiations by shape)."""
+    return "conv3d_wino2d_ws_kernel<0, %d>" % (16 if int(W) % 64 == 0 else 8) if macs == 9.0 else None
 
 
 def _prepared_fwd(w, xptr, B, Cin, Cout, in_dhw, out_dhw, k, stride, pad, wmode):
@@ -1650,32 +1706,36 @@ def conv3d_wrw(g, src, k, stride, pad):
         raise ValueError("batch mismatch")
     dw = g.new_zeros(Cg, Cs, k, k, k)
     fq = 2 * g.numel() * Cs * int(k) ** 3
-    wino = conv3d_wrw_takes_winograd(B, Cg, Cs, g.shape[2:], src.shape[2:], k, stride, pad, g.data_ptr() % 16,
-                                     src.data_ptr() % 16)
+    kid = conv3d_wrw_kernel_id(g.data_ptr(), src.data_ptr(), B, Cg, Cs, g.shape[2:], src.shape[2:], k, stride, pad)
     with torch.cuda.device(g.device):
         _call("fs_conv3d_wrw", g.data_ptr(), src.data_ptr(), dw.data_ptr(), B, Cg, Cs, g.shape[2],
               g.shape[3], g.shape[4], src.shape[2], src.shape[3], src.shape[4], int(k), int(stride),
               int(pad), _stream(g), algo_bytes=4 * (g.numel() + src.numel()),
-              algo_flops=(fq * 2 // 3 if _os.environ.get("FLOWSCI_WRW_NO_WINO4") is not None else fq // 2) if wino else fq,
-              equiv_flops=fq)
+              algo_flops={WRW_KERNEL_WINO43: fq // 2, WRW_KERNEL_WINO23: fq * 2 // 3}.get(kid, fq), equiv_flops=fq,
+              kernel="conv3d_wrw_wino4_kernel<0>" if kid == WRW_KERNEL_WINO43 else None)
     return dw
+
+
+WRW_KERNEL_BRICK, WRW_KERNEL_DMA, WRW_KERNEL_WINO23, WRW_KERNEL_WINO43 = 0, 1, 2, 3  # include/flowsci_hip.h FS_WRW_KERNEL_*
+
+
+def conv3d_wrw_kernel_id(g_ptr, src_ptr, B, Cg, Cs, g_dhw, src_dhw, k, stride, pad):
+    """The kernel fs_conv3d_wrw dispatches this call to (WRW_KERNEL_*): the library's own answer
+    (fs_conv3d_wrw_kernel_id; nothing is launched, the pointers are inspected for alignment only)."""
+    kid = int(_lib.lib().fs_conv3d_wrw_kernel_id(int(g_ptr), int(src_ptr), int(B), int(Cg), int(Cs),
+                                                 *(int(v) for v in g_dhw), *(int(v) for v in src_dhw), int(k), int(stride),
+                                                 int(pad)))
+    if kid < 0:
+        _lib.check(-kid, "fs_conv3d_wrw_kernel_id")
+    return kid
 
 
 def conv3d_wrw_takes_winograd(B, Cg, Cs, g_dhw, src_dhw, k, stride, pad, g_misalign=0, src_misalign=0):
     """Does fs_conv3d_wrw run this call in a Winograd domain (F(4,3), csrc/convwrwwino4.hpp: half the direct form's
-    multiply-adds; F(2,3), csrc/convwrwwino.hpp, two thirds, with FLOWSCI_WRW_NO_WINO4 set)?  Mirrors `wrw_wino_ok`
-    there (the weight gradient has no re-layout plan to ask): the 64 -> 64 k3 s1 p1 layers with rows
-    of 64 x, an even number of y rows, >= 1024 position bricks, 16-byte aligned operands.  Only the flop accounting
-    of the timing records depends on it."""
-    import os
-    if os.environ.get("FLOWSCI_WRW_NO_WINO") is not None or os.environ.get("FLOWSCI_WRW_REG") is not None:
-        return False
-    D, H, W = (int(v) for v in g_dhw)
-    if (int(k), int(stride), int(pad)) != (3, 1, 1) or Cg != 64 or Cs != 64 or tuple(int(v) for v in src_dhw) != (D, H, W):
-        return False
-    if W % 64 or H % 2 or g_misalign or src_misalign or 64 * D * H * W * 4 >= 2 ** 31:
-        return False
-    return B * D * (H // 2) * (W // 64) >= 1024
+    multiply-adds)?  Asked of the library's dispatch: the 64 -> 64 k3 s1 p1 layers with rows of 64 x, an even number
+    of y rows, >= 1024 position bricks, 16-byte aligned operands."""
+    return conv3d_wrw_kernel_id(0x1000 + g_misalign, 0x1000 + src_misalign, B, Cg, Cs, g_dhw, src_dhw, k, stride,
+                                pad) in (WRW_KERNEL_WINO23, WRW_KERNEL_WINO43)
 
 
 FS_ERR_UNSUPPORTED = 5
@@ -1735,6 +1795,7 @@ def conv3d_fwd_prelu_ms(pieces, w, bias, prelu_weight, k, stride, pad):
                       _stream(x0), algo_bytes=xbytes + 8 * y.numel(), algo_flops=2 * y.numel() * Cin * int(k) ** 3,
                       record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
     if rc == FS_ERR_UNSUPPORTED:
+        _prep_not_written()
         return None
     return y, z
 
@@ -1798,8 +1859,9 @@ def conv3d_deconv_grad_input_dprelu(gy, w, act_y, prelu_weight):
             rc = L.fs_conv3d_fwd_dprelu(*args)
             e1.record()
             if rc == 0:
-                _timing.setdefault("fs_conv3d_fwd", []).append((e0, e1, nb, fl, fl))
+                _timing.setdefault("fs_conv3d_fwd", []).append((e0, e1, nb, fl, fl, None))
     if rc == FS_ERR_UNSUPPORTED:
+        _prep_not_written()
         return None
     _lib.check(rc, "fs_conv3d_fwd_dprelu")
     return out, ga, gb
@@ -1829,13 +1891,15 @@ def conv3d_k3_grad_input_dprelu(gy, w, act_y, prelu_weight):
     ga, gb = torch.empty_like(a), act_y.new_empty(Cx)
     part = act_y.new_empty(npart)
     wp, ws = _prepared_fwd(w, gy.data_ptr(), B, Cg, Cx, (D, H, W), (D, H, W), 3, 1, 1, 1)
+    macs = _fwd_k3_macs(gy.data_ptr(), B, Cg, Cx, (D, H, W), 1)
     with torch.cuda.device(gy.device):
         rc = _call_rc("fs_conv3d_fwd_dprelu", gy.data_ptr(), wp, act_y.data_ptr(), a.data_ptr(), a.numel(),
                       out.data_ptr(), ga.data_ptr(), gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, Cg, Cx, D, H, W,
                       D, H, W, 3, 1, 1, _stream(gy), algo_bytes=4 * (gy.numel() + 2 * out.numel()),
-                      algo_flops=int(2 * out.numel() * Cg * _fwd_k3_macs(gy.data_ptr(), B, Cg, Cx, (D, H, W), 1)),
+                      algo_flops=int(2 * out.numel() * Cg * macs), kernel=_fwd_k3_symbol(macs, W),
                       equiv_flops=2 * out.numel() * Cg * 27, record_as="fs_conv3d_fwd", allow=(FS_ERR_UNSUPPORTED,))
     if rc == FS_ERR_UNSUPPORTED:
+        _prep_not_written()
         return None
     return out, ga, gb
 
@@ -1885,9 +1949,10 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
     y = x.new_empty((B, Cout, Do, Ho, Wo))
     wp, ws = _prepared_fwd(w, x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), (Do, Ho, Wo), k, stride, pad, wmode)
     nb, fq = 4 * (x.numel() + y.numel()), 2 * y.numel() * Cin * int(k) ** 3
-    fl = fq
+    fl, sym = fq, None
     if int(k) == 3 and int(stride) == 1 and int(pad) == 1:  # the Winograd forms execute fewer multiply-adds
-        fl = int(2 * y.numel() * Cin * _fwd_k3_macs(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), wmode))
+        macs = _fwd_k3_macs(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), wmode)
+        fl, sym = int(2 * y.numel() * Cin * macs), _fwd_k3_symbol(macs, Wi)
     if addend is not None:
         addend = _need_cuda_f32("addend", addend, 5)
         if addend.shape != y.shape:
@@ -1897,12 +1962,12 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
         if prelu_weight is None and addend is not None:
             _call("fs_conv3d_fwd_add", x.data_ptr(), wp, _ptr(bias), addend.data_ptr(), y.data_ptr(),
                   ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode),
-                  _stream(x), algo_bytes=nb, algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_fwd")
+                  _stream(x), algo_bytes=nb, algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_fwd", kernel=sym)
             return y
         if prelu_weight is None:
             _call("fs_conv3d_fwd", x.data_ptr(), wp, _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
                   Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride), int(pad), int(wmode), _stream(x),
-                  algo_bytes=nb, algo_flops=fl, equiv_flops=fq)
+                  algo_bytes=nb, algo_flops=fl, equiv_flops=fq, kernel=sym)
             return y
         if wmode:
             raise ValueError("the fused PReLU epilogue is forward-only (wmode 0)")
@@ -1913,7 +1978,8 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
         _call("fs_conv3d_fwd_prelu", x.data_ptr(), wp, _ptr(bias), a.data_ptr(), _ptr(addend),
               y.data_ptr(), z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, int(k), int(stride),
               int(pad),
-              a.numel(), _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_fwd")
+              a.numel(), _stream(x), algo_bytes=nb + 4 * y.numel(), algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_fwd",
+              kernel=sym)
     return y, z
 
 

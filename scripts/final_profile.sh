@@ -6,7 +6,7 @@
 # Results land in gpurun_out/final/; copy what is to be judged into profiles/.
 set -e
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/final
 rm -rf $O && mkdir -p $O
 python bench.py --no-cpu-baseline --no-configs > $O/bench_events.json 2> $O/bench_events.log
@@ -24,11 +24,15 @@ rm -rf $O/kt
 tail -1 $O/bench.json | cut -c1-400
 head -12 $O/last_step.txt
 # the C2 / C3 steps stand-alone + their kernel stats
-bash scripts/prof_configs.sh > $O/prof_configs.log 2>&1 || true
+bash scripts/prof_configs.sh > $O/prof_configs.log 2>&1 || echo "prof_configs.sh FAILED (see $O/prof_configs.log)"
 # train.py at the bench's size (device-generated triplets)
 python -m opticalflowscivis_amd.flow3d.train --dataset droplet3d --size 256 --samples 24 --batch_size 2 --epoch 2 --mode train \
     --log_every 4 --log_path /tmp/tl256 > $O/train256.txt 2>&1 || true
-# the Winograd-domain trunk kernels against the direct ones, and the weight gradient's ablation builds
+# the Winograd-domain trunk kernels against the direct ones, and the weight gradient's ablation builds: these switches
+# exist only in the measurement build of the library (make ablation), loaded through FLOWSCI_HIP_LIBRARY
+AB=$PWD/opticalflowscivis_amd/csrc/ablation/libflowsci_hip_ab.so
+if [ -f "$AB" ]; then
+export FLOWSCI_HIP_LIBRARY=$AB
 { python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO2D=1 python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO4=1 python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO=1 python tests/tools/wino_bench.py;
   python tests/tools/wino_wrw_bench.py; FLOWSCI_WRW_NO_WINO4=1 python tests/tools/wino_wrw_bench.py; FLOWSCI_WRW_NO_WINO=1 python tests/tools/wino_wrw_bench.py;
   FLOWSCI_WINO_DBG=1 python tests/tools/wino_wrw_bench.py; FLOWSCI_WINO_DBG=2 python tests/tools/wino_wrw_bench.py;
@@ -38,3 +42,5 @@ python -m opticalflowscivis_amd.flow3d.train --dataset droplet3d --size 256 --sa
 FLOWSCI_FWD_NO_WINO=1 FLOWSCI_WRW_NO_WINO=1 python -m pytest tests/test_gpu_losses.py tests/test_gpu_scale.py -q -k "conv or res_unit or head or 256" \
     > $O/direct_kernels_tests.log 2>&1 || true
 tail -3 $O/direct_kernels_tests.log
+unset FLOWSCI_HIP_LIBRARY
+fi

@@ -35,7 +35,8 @@ def kernel_sources_sha256():
 
 RULES = [  # (substring of the kernel name, entry point, counts as a launch of the entry point)
     ("conv3d_fwd_kernel", "fs_conv3d_fwd", True), ("conv3d_fwd_ws_kernel", "fs_conv3d_fwd", True),
-    ("conv3d_wino_ws_kernel", "fs_conv3d_fwd", True),
+    ("conv3d_wino_ws_kernel", "fs_conv3d_fwd", True), ("conv3d_wino2d_ws_kernel", "fs_conv3d_fwd", True),
+    ("conv3d_wino4_ws_kernel", "fs_conv3d_fwd", True),
     ("wprep_one_kernel", "fs_conv3d_fwd", False), ("wprep_batch_kernel", "fs_conv3d_wprep_batch", True),
     ("conv3d_wrw_", "fs_conv3d_wrw", True),
     ("convtr_", "fs_conv3d_tr", True),
@@ -45,6 +46,8 @@ RULES = [  # (substring of the kernel name, entry point, counts as a launch of t
     ("merge_fwd_kernel", "fs_merge_fwd", True), ("merge_bwd_kernel", "fs_merge_bwd", True),
     ("distill3_fwd_kernel", "fs_distill_fwd", True), ("distill3_bwd_kernel", "fs_distill_bwd", True),
 ]
+# kernel SYMBOLS bench.py's `roofline` may name (ops.py labels their launches): traffic per launch of the symbol itself
+SYMBOLS = ["conv3d_wino2d_ws_kernel<0, 16>", "conv3d_wino2d_ws_kernel<0, 8>", "conv3d_wrw_wino4_kernel<0>"]
 WARP_BWD_ORDER = ["fs_warp3d_pair_bwd", "fs_warp3d_pair_bwd_acc3", "fs_upsample_warp3d_pair_bwd3",
                   "fs_upsample_warp3d_pair_bwd3"]
 
@@ -63,6 +66,10 @@ def last_step(path, counter):
     nwarp = 0
     for r in seg:
         name, val = r["Kernel_Name"], float(r["Counter_Value"])
+        for sym in SYMBOLS:
+            if sym in name:
+                out["symbol:" + sym][0] += val
+                out["symbol:" + sym][1] += 1
         if "warp3d_bwd_kernel" in name:
             ep = WARP_BWD_ORDER[nwarp % 4]
             nwarp += 1
@@ -81,9 +88,14 @@ def main():
     fetch = last_step(sys.argv[1], "FETCH_SIZE")
     write = last_step(sys.argv[2], "WRITE_SIZE")
     bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
-    kern = {}
+    kern, syms = {}, {}
     for ep in sorted(set(fetch) | set(write)):
         n = max(fetch[ep][1], write[ep][1], 1)
+        if ep.startswith("symbol:"):
+            f_kb, w_kb = fetch[ep][0] / n, write[ep][0] / n
+            syms[ep[7:]] = {"launches_per_step": n, "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
+                            "hbm_bytes_corrected": (2.0 * f_kb + w_kb) * 1024.0}
+            continue
         f_kb, w_kb = fetch[ep][0] / n, write[ep][0] / n
         rec = {"launches_per_step": n, "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
                "hbm_bytes_corrected": (2.0 * f_kb + w_kb) * 1024.0}
@@ -96,7 +108,7 @@ def main():
                % bench["config"]["workload"],
                "correction": "FETCH_SIZE x2 (gfx950 half-count of wide coalesced reads), WRITE_SIZE x1, KB units",
                "kernel_sources_sha256": kernel_sources_sha256(),
-               "kernels": kern}, sys.stdout, indent=1)
+               "kernels": kern, "symbols": syms}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

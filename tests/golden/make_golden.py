@@ -9,6 +9,7 @@ Usage (each group imports a different reference package layout, so one process p
     python tests/golden/make_golden.py flow3d_e2e   # Flow-3D Model.update / inference
     python tests/golden/make_golden.py flow2d_e2e   # Flow-2D Model.update / inference
     python tests/golden/make_golden.py flow3d_256   # Flow-3D Model.update at the BASELINE size (B=1, 256^3; ~35 GB, minutes)
+    python tests/golden/make_golden.py flow3d_256_traj  # the same, eight AdamW steps (training drift; ~10 min)
     python tests/golden/make_golden.py upflow_e2e   # UPFlow_net forward losses / flows / grads
     python tests/golden/make_golden.py upflow_levels  # per pyramid level: decode_level_res inputs / outputs / grads
     python tests/golden/make_golden.py rife_next    # Flow-2D LapLoss
@@ -302,6 +303,54 @@ def flow3d_256():
     print("wrote", name, "; losses", losses, os.path.getsize(os.path.join(OUT, name)) // 1024, "KB")
 
 
+def flow3d_256_traj():
+    """Training drift at the BASELINE size: the reference's `train()` is repeated `Model.update` on the running
+    weights (Flow-3D/train.py:165-169).  Same model / triplet / learning rate as `flow3d_256`, EIGHT AdamW steps
+    (B = 1, 256^3, seed 1234; ~1 min per step on 8 cores).  Stored: the four losses of every step, every
+    parameter's sum before and after steps 4 and 8, PSNR of every step's prediction.  The first two rows equal
+    `flow3d_256.npz::update_losses` (same process, same seed) -- asserted here before anything is written."""
+    _install_stubs()
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path[:0] = [REF + "/Flow-3D", REF]
+    import model.RIFE as R
+    import model.warplayer as WL
+    R.device = torch.device("cpu")
+    WL.device = torch.device("cpu")
+    spec = importlib.util.spec_from_file_location(
+        "flowsci_synthetic", os.path.join(repo, "opticalflowscivis_amd", "data", "synthetic.py"))
+    syn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(syn)
+    S = int(os.environ.get("FLOW3D_256_SIZE", "256"))
+    NSTEP = int(os.environ.get("FLOW3D_TRAJ_STEPS", "8"))
+    torch.manual_seed(1234)
+    m = _quiet(R.Model, local_rank=-1)
+    data = syn.droplet3d_batch(1, S, seed=1234)
+    imgs, gt = data[:, :2], data[:, 2:3]
+    store = dict(size=np.int64(S), steps=np.int64(NSTEP),
+                 data_sums=np.array([float(data[0, c].double().sum()) for c in range(3)]))
+    psum = lambda: np.array([float(p.detach().double().sum()) for p in m.flownet.parameters()])
+    store["param_sums"] = psum()
+    losses, psnrs = [], []
+    import time
+    for step in range(NSTEP):
+        t0 = time.time()
+        pred, info = _quiet(m.update, imgs, gt, learning_rate=1e-4, training=True)
+        losses.append([float(info[k].detach()) for k in ("loss_l1", "loss_tea", "loss_distill", "loss_G")])
+        psnrs.append(float(syn.psnr(pred.detach(), gt)))
+        print("step", step, "%.1f s" % (time.time() - t0), losses[-1], psnrs[-1], flush=True)
+        del pred, info
+        if step + 1 in (NSTEP // 2, NSTEP):
+            store["param_sums_after%d" % (step + 1)] = psum()
+    store["update_losses"] = np.array(losses)
+    store["psnr"] = np.array(psnrs)
+    if S == 256:
+        two = np.load(os.path.join(OUT, "flow3d_256.npz"))["update_losses"]
+        assert np.array_equal(two, store["update_losses"][:2]), (two, store["update_losses"][:2])
+    name = "flow3d_256_traj.npz" if S == 256 else "flow3d_%d_traj_probe.npz" % S
+    np.savez_compressed(os.path.join(OUT, name), **store)
+    print("wrote", name, "; losses", losses, os.path.getsize(os.path.join(OUT, name)) // 1024, "KB")
+
+
 def flow2d_e2e():
     _install_stubs()
     sys.path[:0] = [REF + "/Flow-2D", REF]
@@ -576,7 +625,7 @@ def ckpt():
           "loads its own unprefixed file:", int(store["ref_loads_plain"]))
 
 
-GROUPS = dict(flow3d_256=flow3d_256, ckpt=ckpt, rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
+GROUPS = dict(flow3d_256=flow3d_256, flow3d_256_traj=flow3d_256_traj, ckpt=ckpt, rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
               upflow_e2e=upflow_e2e, upflow_levels=upflow_levels)
 
 if __name__ == "__main__":
@@ -584,7 +633,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if which == "all":
         for g in GROUPS:
-            if g == "flow3d_256" and os.environ.get("GOLDEN_WITH_256") != "1":
+            if g in ("flow3d_256", "flow3d_256_traj") and os.environ.get("GOLDEN_WITH_256") != "1":
                 continue  # ~35 GB of host memory and minutes: opt in
             if g == "ckpt":
                 for nd in ("3", "2"):

@@ -121,11 +121,20 @@ def test_wino_input_gradient_and_prelu_backward_vs_fp64(ops, B, cg, cx, size):
 
 
 @pytest.mark.parametrize("env,kind", [({"FLOWSCI_FWD_NO_WINO2D": "1"}, 5), ({"FLOWSCI_FWD_NO_WINO4": "1"}, 4)])
-def test_superseded_1d_kernels_in_a_fresh_process(env, kind):
-    """The dispatch switches are read once per process: F(4,3) (kind 5) and F(2,3) (kind 4) along x only, same checks."""
+def test_superseded_1d_kernels_in_the_ablation_build(env, kind):
+    """The product library holds ONE kernel per job and reads no environment variable; the 1-D forms it superseded --
+    F(4,3) (kind 5) and F(2,3) (kind 4) along x only -- live in the ablation build (`make ablation`), whose dispatch
+    switches are read once per process: same checks there, in a fresh process."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ab = os.path.join(root, "opticalflowscivis_amd", "csrc", "ablation", "libflowsci_hip_ab.so")
+    if not os.path.exists(ab):
+        pytest.skip("ablation build absent (make -C opticalflowscivis_amd/csrc ablation)")
+    # the product library itself must not react to the switch: same slab kind (6) with it set
+    r0 = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "wino_check.py"), "6"],
+                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r0.returncode == 0 and "kind=6" in r0.stdout, r0.stdout[-2000:] + r0.stderr[-2000:]
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "wino_check.py"), str(kind)],
-                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, FLOWSCI_HIP_LIBRARY=ab, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ("kind=%d" % kind) in r.stdout and "OK" in r.stdout
 

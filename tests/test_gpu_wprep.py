@@ -120,3 +120,62 @@ def test_no_stale_slab_after_any_weight_change(monkeypatch):
     ref.flownet.load_state_dict(m.flownet.state_dict())
     assert same()
     assert eager == eager  # finite
+
+
+def test_graph_replay_survives_a_changed_job_table(monkeypatch):
+    """the captured fs_conv3d_wprep_batch launch holds the job table's ADDRESS.  Work at a new size
+    (a second geometry per layer) re-builds the table; the captured table -- and every slab a captured convolution
+    reads -- must stay alive and valid, so a later replay still steps exactly like the per-launch path."""
+    from opticalflowscivis_amd import ops
+    imgs, gt = _batch(6)
+    m = _model(seed=21)
+    m.update(imgs, gt, learning_rate=1e-3, training=True)   # registers the training geometry: the capture below batches
+    step = m.graphed_update(imgs, gt)
+    tab = ops._prep_tables[("cuda", 0)]
+    assert tab.captured, "the capture must have pinned its job table and slabs"
+    old_table = tab.dev_jobs
+    # the table changes: inference at another size registers new geometries, a second model registers new weights
+    big, _ = _batch(7, S=48)
+    _infer(m, big)
+    other = _model(seed=22)
+    _infer(other, imgs)
+    del other
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 16,), float("nan"), device=DEV) for _ in range(64)]  # recycle whatever was freed
+    assert tab.dev_jobs is not old_table and any(t is old_table for t in tab.captured)
+    # reference: the same weights stepped eagerly without prepared slabs
+    ref = _model(seed=23)
+    ref.flownet.load_state_dict(m.flownet.state_dict())
+    ref.optimG.load_state_dict(m.optimG.state_dict())
+    m.train()
+    got = [float(step(imgs, gt, 1e-3)[1]["loss_G"].detach()) for _ in range(3)]
+    monkeypatch.setattr(ops, "_PREP_ON", False)
+    ref.train()
+    want = [float(ref.update(imgs, gt, learning_rate=1e-3, training=True)[1]["loss_G"].detach()) for _ in range(3)]
+    monkeypatch.setattr(ops, "_PREP_ON", True)
+    del junk
+    for a, b in zip(got, want):
+        assert a == a and abs(a - b) <= 2e-4 * abs(b), (got, want)
+    assert abs(got[0] - got[2]) > 1e-5 * abs(got[0])  # the replayed steps did move the weights
+
+
+def test_unused_slabs_are_evicted_and_oversize_tables_fall_back(monkeypatch):
+    """variable-size inference must not grow the slab cache without bound; a table too large for one
+    launch falls back to per-launch preparation instead of raising."""
+    from opticalflowscivis_amd import ops
+    m = _model(seed=31)
+    for S in (32, 48):
+        _infer(m, _batch(8, S)[0])
+    tab = ops._prep_tables[("cuda", 0)]
+    n_two = len(tab.entries)
+    small = _batch(8, 32)[0]
+    for _ in range(ops._PREP_KEEP_EPOCHS + 3):
+        _infer(m, small)
+    live = [e for e in tab.entries.values() if e.wref() is not None and not e.pinned]
+    assert all(ops._prep_epoch - e.used <= ops._PREP_KEEP_EPOCHS + 1 for e in live)
+    assert len(tab.entries) < n_two
+    want = _infer(m, small)
+    monkeypatch.setattr(ops, "_PREP_MAX_JOBS", 3)
+    tab.dirty = True
+    got = _infer(m, small)   # table "too large": every convolution prepares its own weights
+    assert torch.equal(got[1], want[1])

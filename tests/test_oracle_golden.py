@@ -177,3 +177,16 @@ def test_normalize_features(golden):
             g1, g2 = torch.autograd.grad((o1 * T(g[tag + "G1"])).sum() + (o2 * T(g[tag + "G2"])).sum(), [f1, f2])
             close(g1, g[tag + "g1"], 1e-5, 1e-5)
             close(g2, g[tag + "g2"], 1e-5, 1e-5)
+
+
+def test_trajectory_fixture_continues_the_two_step_fixture(golden):
+    """flow3d_256_traj.npz (eight reference steps at 256^3) starts with exactly the two steps of flow3d_256.npz: same
+    process recipe, same seed, same input -- the reference's CPU path is deterministic here."""
+    two, traj = golden("flow3d_256"), golden("flow3d_256_traj")
+    assert int(traj["steps"]) == 8 and traj["update_losses"].shape == (8, 4)
+    np.testing.assert_array_equal(traj["update_losses"][:2], two["update_losses"])
+    np.testing.assert_array_equal(traj["param_sums"], two["param_sums"])
+    np.testing.assert_array_equal(traj["data_sums"], two["data_sums"])
+    assert np.all(np.isfinite(traj["param_sums_after4"])) and np.all(np.isfinite(traj["param_sums_after8"]))
+    # training does move: loss_G falls by ~40 % over the eight steps
+    assert traj["update_losses"][7, 3] < 0.7 * traj["update_losses"][0, 3]
