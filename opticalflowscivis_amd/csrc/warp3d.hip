@@ -448,6 +448,252 @@ __global__ __launch_bounds__(NT, UPS ? 4 : 1) void warp3d_fwd_kernel(W3Fwd io, c
   }
 }
 
+// ---- round 4: the plain forward warp as a software pipeline (warp3d_fwd_ring_kernel) ------------------------------
+// One workgroup per CU: 8 compute waves + 2 mover waves, a ring of NF flow-tile stages in LDS.
+//   * movers: bring the flow tiles of slices k+1 .. k+NF-1 global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR
+//     stop, no ds_write pass, non-temporal: the flow is read once) and stream the output tile of slice k-1 from LDS to
+//     global (16-byte stores, 128-byte rows); counted vmcnt waits: only slice k+2 must have landed at barrier k.
+//   * compute waves: lane = h, wave = one float4 column (4 consecutive w).  The flow of a thread's 4 voxels is ONE
+//     ds_read_b128 per plane; the gathers of slice k+1 are issued BEFORE slice k is blended (two register sets that
+//     hold the RAW pairs: nothing touches a loaded value in the half that issues it), so they fly across the barrier
+//     and a whole iteration; the output tile goes to LDS with one ds_write_b128.
+// ONE barrier per slice.  LDS tile layout: a plane tile is 64 h x 8 float4 (4 consecutive w each); float4 slot (h, q)
+// sits at index h * 8 + (q ^ swz(h)), swz(h) = (h ^ h >> 3) & 7 -- conflict-free for all four access patterns (b128
+// column reads with lane = h, b128 row reads / writes with 8 lanes per row, the movers' linear slot order), found by
+// enumeration.  The DMA writes LDS linearly (slot = 64 j + lane), so the swizzle is applied on the GLOBAL side: lane ->
+// (row, logical column) of the tile; 8 lanes still cover one 128-byte row.  Values are bit-identical to the round-3
+// kernel (same arithmetic on the same operands; scripts/w3bench.py prints CRCs).
+// What it bought, and what bounds the family (profiles/r04_w3_pmc.txt, profiles/r04_w3_ablation.txt): 0.362 -> 0.348 ms
+// per pair launch in the micro-benchmark -- NOT the 0.26 the latency picture predicted.  The round-3 reading ("no unit
+// saturated, so barrier-separated phases") was incomplete: the CU's vector L1 sustains ~64 line requests in flight
+// (x 128 B / ~700-900 cycles of L2 / HBM latency under load = ~10 B/clk/CU, which summed over 256 CUs IS the HBM rate),
+// the backward kernel already averages 56 in flight (TCP_TCC_READ_REQ_LATENCY / cycles) and sits at that bound; the
+// forward kernel averaged 38 because every gather wave-instruction costs the texture-address path ~26 cycles (64 lanes
+// x 8 unaligned bytes) and TA work -- 128 gather + 24 tile + 8 store instructions per tile-slice, ~3 900 cycles -- adds to
+// rather than hides behind the streaming: ablations of the v1 pipeline: flow DMA alone 0.154 ms (5.2 TB/s), + output
+// stores 0.227, + compute without gathers 0.263, + gathers from an L2-resident 64 KB source 0.366, real gathers 0.404;
+// insensitive to workgroups per CU (1 vs 2), d-chunk, and cache policy.  Fewer TA instructions would need the gather
+// SOURCE staged in LDS (a flow-dependent window: DESIGN.md §5), not a different schedule.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int TQ = TW / 4;        // float4 slots per tile row
+constexpr int TSLOTS = TH * TQ;   // 512 float4 = 8 KB per plane tile
+constexpr int NCW = 8;            // compute waves of a workgroup
+constexpr int NMW = 2;            // mover waves
+constexpr int NT2 = 64 * (NCW + NMW);
+
+__device__ __forceinline__ int t_swz(int h) { return (h ^ (h >> 3)) & 7; }
+__device__ __forceinline__ int t_slot(int h, int q) { return h * TQ + (q ^ t_swz(h)); }
+
+// A mover lane's share of a plane tile: slots 64 j + lane of instruction j (4 per mover wave).  VEC: one 16-byte
+// piece per slot; otherwise (W % 4 != 0 or unaligned tensors) four dword pieces per slot -- the same LDS image.
+template <bool VEC>
+struct MoverLane {
+  static constexpr int NJ = TSLOTS / 64 / NMW;        // slot groups (64 slots each) per mover wave: 4
+  static constexpr int NV = VEC ? NJ : 4 * NJ;        // DMA instructions per plane and mover wave
+  unsigned voff[NV];                                  // byte offset inside a [H][W] plane (slice-invariant)
+  int hq[NJ], wq[NJ];                                 // unclamped (h, w) of the lane's slot in group j (stores)
+  int m;
+
+  __device__ __forceinline__ void init(const W3P& p, int m_, int lane, int h0, int w0) {
+    m = m_;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const int s = 64 * (NJ * m + i) + lane, hr = s / TQ, q = (s % TQ) ^ t_swz(hr);
+      hq[i] = h0 + hr; wq[i] = w0 + 4 * q;
+      if (VEC) voff[i] = ((unsigned)min(hq[i], p.H - 1) * (unsigned)p.W + (unsigned)min(wq[i], p.W - 4)) * 4u;
+    }
+    if (!VEC) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {  // dword pieces: instruction i covers slots 16 i .. 16 i + 15 of this wave's share
+        const int s = 64 * NJ * m + 16 * i + (lane >> 2), hr = s / TQ, q = (s % TQ) ^ t_swz(hr);
+        voff[i] = ((unsigned)min(h0 + hr, p.H - 1) * (unsigned)p.W + (unsigned)min(w0 + 4 * q + (lane & 3), p.W - 1)) * 4u;
+      }
+    }
+  }
+  // global plane (one d-slice of one channel) -> LDS plane tile; completion: the issuing wave's vmcnt
+  template <int AUX>
+  __device__ __forceinline__ void dma(const float* plane, float4* tile) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)plane, (short)0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (VEC) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(tile + 64 * (NJ * m + i)), 16, voff[i], 0, 0, AUX);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(tile + 64 * NJ * m + 16 * i), 4, voff[i], 0, 0, AUX);
+    }
+#endif
+  }
+  // LDS plane tile -> registers (the lane's NJ slots)
+  __device__ __forceinline__ void get(const float4* tile, float4 (&v)[NJ]) const {
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) v[i] = tile[64 * (NJ * m + i) + (threadIdx.x & 63)];
+  }
+  // registers -> global plane (guarded)
+  __device__ __forceinline__ void put(float* plane, const W3P& p, const float4 (&v)[NJ]) const {
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      if (hq[i] >= p.H) continue;
+      float* dst = plane + (size_t)hq[i] * p.W + wq[i];
+      if (VEC) {
+        if (wq[i] < p.W) *reinterpret_cast<float4*>(dst) = v[i];
+      } else {
+        if (wq[i] + 0 < p.W) dst[0] = v[i].x;
+        if (wq[i] + 1 < p.W) dst[1] = v[i].y;
+        if (wq[i] + 2 < p.W) dst[2] = v[i].z;
+        if (wq[i] + 3 < p.W) dst[3] = v[i].w;
+      }
+    }
+  }
+};
+
+// ---- v2: a ring of NF flow stages + software-pipelined compute waves -------------------------------------------
+// PMC of v1 (profiles/r04_w3_pmc.txt): the CU's vector L1 holds ~38 line requests in flight on average at ~700
+// cycles each -- the per-CU fill rate (outstanding lines x 128 B / latency) is what bounds the kernel, and it is bursty:
+// all compute waves compute addresses together, then gather together.  v2 keeps the queue fed: the movers run NF - 1
+// slices ahead (counted vmcnt waits), and a compute wave issues the gathers of slice k + 1 BEFORE it blends slice k
+// (two register sets), so its gathers fly across the barrier and a whole iteration.
+__device__ __forceinline__ void w3_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct GState {  // gathers in flight for one slice: 4 voxels of a thread.  The RAW pairs: nothing may touch a loaded
+  Pair r[4][4];  // value before `back` (a select on it would make the wave wait for the load where it was issued)
+  unsigned dx[4];
+  float ax[4], ay[4], az[4];
+};
+
+__device__ __forceinline__ Pair ld_pair_raw(const float* __restrict__ base, unsigned off, unsigned dx) {
+  return *reinterpret_cast<const Pair*>(reinterpret_cast<const char*>(base) + (dx ? off : off - 4u));
+}
+
+template <bool VEC, int AUX, int NF>
+__global__ __launch_bounds__(NT2, 2) void warp3d_fwd_ring_kernel(W3Fwd io, const float* __restrict__ flow, W3P p) {
+  static_assert(NF >= 3 && NF <= 5, "ring depth");
+  const float* __restrict__ in = io.in[blockIdx.y];
+  float* __restrict__ out = io.out[blockIdx.y];
+  __shared__ float4 sF[NF][3][TSLOTS];
+  __shared__ float4 sO[2][TSLOTS];
+
+  int b, d0, h0, w0;
+  decode_tile(p, b, d0, h0, w0);
+  const int HW = p.H * p.W;
+  const size_t vol = (size_t)p.D * HW;
+  const size_t ivol = (size_t)p.Di * p.Hi * p.Wi;
+  const float* fb = flow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol;
+  const int n = min(d0 + p.dc, p.D) - d0;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // (C > 1: the image channels of a slice are stages of the same pipeline; the flow ring advances per slice)
+  const int C = p.C, nst = n * C;
+
+  if (wv >= NCW) {
+    // ---------------- movers ----------------
+    MoverLane<VEC> mv;
+    mv.init(p, wv - NCW, lane, h0, w0);
+    constexpr int PER = 3 * MoverLane<VEC>::NV;  // DMA instructions per slice and mover wave
+    auto load_slice = [&](int k) {
+      const float* f = fb + (size_t)(d0 + k) * HW;
+      mv.template dma<AUX>(f, sF[k % NF][0]);
+      mv.template dma<AUX>(f + vol, sF[k % NF][1]);
+      mv.template dma<AUX>(f + 2 * vol, sF[k % NF][2]);
+    };
+    auto store_stage = [&](int s) {
+      const int k = s / C, c = s - k * C;
+      float4 v[MoverLane<VEC>::NJ];
+      mv.get(sO[s & 1], v);
+      mv.put(out + ((size_t)b * C + c) * vol + (size_t)(d0 + k) * HW, p, v);
+    };
+    // wait until at most `younger` slices' DMA instructions (issued after the one that must have landed) are pending;
+    // stores in between only make the wait stricter
+    auto wait_younger = [&](int younger) {
+      if (VEC) {
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER <= 63 ? 3 * PER : 63) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER <= 63 ? 2 * PER : 63) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER <= 63 ? PER : 63) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dword-piece form issues 48 instructions per slice)
+      }
+    };
+    // prologue: slices 0 .. NF-2 requested, 0 and 1 landed
+    const int pre = min(n, NF - 1);
+    for (int k = 0; k < pre; ++k) load_slice(k);
+    wait_younger(max(pre - 2, 0));
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nst; ++s) {
+      const int k = s / C, c = s - k * C;
+      if (s > 0) store_stage(s - 1);
+      int issued_to = k + NF - 2;                       // last slice requested before this iteration
+      if (c == 0 && k + NF - 1 < n) {     // slice k - 1's buffer: its last reader ran an iteration ago
+        load_slice(k + NF - 1);
+        issued_to = k + NF - 1;
+      }
+      // before anyone is released, slice k + 2 (read by the compute waves in the next iteration) has landed
+      wait_younger(max(min(issued_to, n - 1) - (k + 2), 0));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    store_stage(nst - 1);
+    return;
+  }
+  // ---------------- compute waves ----------------
+  const int h = min(h0 + lane, p.H - 1);
+  const float lin_h = fs::linspace_pm1(h, p.H, p.stepH);
+  float lin_w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lin_w[i] = fs::linspace_pm1(min(w0 + 4 * wv + i, p.W - 1), p.W, p.stepW);
+  const int slot = t_slot(lane, wv);
+  auto front = [&](int s, GState& g) {  // stage s: flow from LDS, sample positions, gathers issued
+    const int k = s / C, c = s - k * C;
+    const float lin_d = fs::linspace_pm1(d0 + k, p.D, p.stepD);
+    const float4 f0 = sF[k % NF][0][slot], f1 = sF[k % NF][1][slot], f2 = sF[k % NF][2][slot];
+    const float fa[4] = {f0.x, f0.y, f0.z, f0.w}, fbv[4] = {f1.x, f1.y, f1.z, f1.w}, fc[4] = {f2.x, f2.y, f2.z, f2.w};
+    const float* __restrict__ vin = in + ((size_t)b * C + c) * ivol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const Samp3 sm = w3_sample<false>(p, lin_h, lin_d, lin_w[i], fa[i], fbv[i], fc[i]);
+      const unsigned o010 = sm.o000 + sm.dy, o100 = sm.o000 + sm.dz, o110 = o100 + sm.dy;
+      g.r[i][0] = ld_pair_raw(vin, sm.o000, sm.dx); g.r[i][1] = ld_pair_raw(vin, o010, sm.dx);
+      g.r[i][2] = ld_pair_raw(vin, o100, sm.dx); g.r[i][3] = ld_pair_raw(vin, o110, sm.dx);
+      g.dx[i] = sm.dx; g.ax[i] = sm.ax; g.ay[i] = sm.ay; g.az[i] = sm.az;
+    }
+  };
+  auto back = [&](int s, const GState& g) {  // stage s: blend, output tile to LDS
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool in = g.dx[i] != 0u;  // (far border: the pair was fetched one element down, see ld_pair)
+      const float c00 = lerp(in ? g.r[i][0].a : g.r[i][0].b, g.r[i][0].b, g.ax[i]);
+      const float c01 = lerp(in ? g.r[i][1].a : g.r[i][1].b, g.r[i][1].b, g.ax[i]);
+      const float c10 = lerp(in ? g.r[i][2].a : g.r[i][2].b, g.r[i][2].b, g.ax[i]);
+      const float c11 = lerp(in ? g.r[i][3].a : g.r[i][3].b, g.r[i][3].b, g.ax[i]);
+      o[i] = lerp(lerp(c00, c01, g.ay[i]), lerp(c10, c11, g.ay[i]), g.az[i]);
+    }
+    sO[s & 1][slot] = make_float4(o[0], o[1], o[2], o[3]);
+  };
+  GState ga, gb;
+  __builtin_amdgcn_s_barrier();  // slices 0 and 1 are in LDS
+  front(0, ga);
+  int s = 0;
+  // steady state: both `front`s unconditional -- a conditional issue would make the compiler's vmcnt bookkeeping
+  // assume the shorter path and wait for the gathers it has just issued
+  for (; s + 2 < nst; s += 2) {
+    front(s + 1, gb);
+    back(s, ga);
+    w3_lds_barrier();
+    front(s + 2, ga);
+    back(s + 1, gb);
+    w3_lds_barrier();
+  }
+  if (s + 1 < nst) {
+    front(s + 1, gb);
+    back(s, ga);
+    w3_lds_barrier();
+    back(s + 1, gb);
+    w3_lds_barrier();
+  } else {
+    back(s, ga);
+    w3_lds_barrier();
+  }
+}
+
 // up to three gradients reaching the flow from its other consumers: [B, >= flowC, D,H,W] tensors or channel
 // slices of wider ones (`bs` = batch stride in floats; the channel stride is always D*H*W)
 struct W3Add {
@@ -584,6 +830,7 @@ int make_params(W3P& p, int B, int C, const int* in_dhw, int D, int H, int W) {
   const int Di = in_dhw ? in_dhw[0] : D, Hi = in_dhw ? in_dhw[1] : H, Wi = in_dhw ? in_dhw[2] : W;
   if (B < 1 || C < 1 || D < 2 || H < 2 || W < 2 || Di < 2 || Hi < 2 || Wi < 2) return FS_ERR_SHAPE;
   if ((long long)D * H * W >= (1ll << 31)) return FS_ERR_SHAPE;
+  if ((long long)H * W * 4 >= (1ll << 31)) return FS_ERR_SHAPE;  // 31-bit byte offsets inside one [H][W] plane (tile DMA)
   // 32-bit byte offsets into one input volume, 24-bit index products
   if ((long long)Di * Hi * Wi * 4 >= (1ll << 32) || Wi >= (1 << 24) || (long long)Di * Hi >= (1 << 24))
     return FS_ERR_SHAPE;
@@ -591,7 +838,8 @@ int make_params(W3P& p, int B, int C, const int* in_dhw, int D, int H, int W) {
   p.Di = Di; p.Hi = Hi; p.Wi = Wi;
   p.tilesH = fs::cdiv(H, TH);
   p.tilesW = fs::cdiv(W, TW);
-  p.dc = 4;  // d-slices per workgroup: amortises the tile set-up, keeps >= 8 K workgroups at 256^3
+  static const int dc_env = (int)FS_AB_ENV_LL("FLOWSCI_W3_DC", 4);
+  p.dc = dc_env;  // d-slices per workgroup: amortises the tile set-up, keeps >= 8 K workgroups at 256^3
   p.nDC = fs::cdiv(D, p.dc);
   if ((long long)B * p.nDC * p.tilesH * p.tilesW >= (1ll << 31)) return FS_ERR_SHAPE;
   // fp32 like the reference: linspace step (end-start)/(steps-1); divisor (dim-1.0)/2.0
@@ -624,10 +872,19 @@ int launch_fwd(const W3Fwd& io, int npair, const float* flow, const UpP* up, W3P
     if (vec) hipLaunchKernelGGL((warp3d_fwd_kernel<512, true, true>), g, dim3(512), 0, st, io, flow, *up, p);
     else hipLaunchKernelGGL((warp3d_fwd_kernel<512, false, true>), g, dim3(512), 0, st, io, flow, *up, p);
   } else {
-    const UpP none = {};
     const bool vec = vec_ok(p, flow, io.out[0], io.out[1], nullptr);
-    if (vec) hipLaunchKernelGGL((warp3d_fwd_kernel<512, true, false>), g, dim3(512), 0, st, io, flow, none, p);
-    else hipLaunchKernelGGL((warp3d_fwd_kernel<512, false, false>), g, dim3(512), 0, st, io, flow, none, p);
+    // the ring kernel walks 16 slices per workgroup (one workgroup per CU; 2 048 workgroups at 2 x 256^3)
+    p.dc = (int)FS_AB_ENV_LL("FLOWSCI_W3_RING_DC", 16);
+    p.nDC = fs::cdiv(p.D, p.dc);
+    const dim3 gr((unsigned)((long long)p.B * p.nDC * p.tilesH * p.tilesW), npair);
+#ifdef FS_ABLATION
+    static const int ring = (int)FS_AB_ENV_LL("FLOWSCI_W3_RING", 0);  // 3..5: that many flow stages; +10: non-temporal DMA
+#define W3_RING_CASE(R, A) \
+    if (vec && ring == R + (A ? 10 : 0)) { hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, A, R>), gr, dim3(NT2), 0, st, io, flow, p); FS_LAUNCH_CHECK(); return FS_OK; }
+    W3_RING_CASE(3, 0) W3_RING_CASE(4, 0) W3_RING_CASE(5, 0) W3_RING_CASE(3, 2) W3_RING_CASE(5, 2)
+#endif
+    if (vec) hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, 2, 4>), gr, dim3(NT2), 0, st, io, flow, p);
+    else hipLaunchKernelGGL((warp3d_fwd_ring_kernel<false, 0, 3>), gr, dim3(NT2), 0, st, io, flow, p);
   }
   FS_LAUNCH_CHECK();
   return FS_OK;

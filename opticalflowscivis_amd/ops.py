@@ -1599,7 +1599,7 @@ def _prepared(w, nfloats, key, plan):
         if capturing and not e.pinned:  # a captured convolution reads this slab by address from now on
             e.pinned = True
             tab.captured.append(e.ws)
-    _last_prep = e
+    _last_prep = None  # (only a first-use stamp can describe a slab nobody has written: _prep_not_written)
     if e is None or e.wref() is None:
         e = _last_prep = _PrepEntry()
         e.wref, e.stamp, e.used, e.pinned = _weakref.ref(w), None, _prep_epoch, capturing
@@ -1629,9 +1629,10 @@ _last_prep = None
 
 
 def _prep_not_written():
-    """The entry point that was handed the last `_prepared` slab answered FS_ERR_UNSUPPORTED: it may have returned
-    before its own re-layout ran (csrc/convfwd.hip rejects > 12 source planes first), so the entry's "current" stamp
-    does not describe the slab -- the fallback call with the same key must lay the weights out itself."""
+    """The entry point that was handed a FIRST-USE slab (stamped current on the promise that the call itself lays the
+    weights out) answered FS_ERR_UNSUPPORTED: it may have returned before its re-layout ran (csrc/convfwd.hip rejects
+    > 12 source planes first), so the stamp does not describe the slab -- the fallback call with the same key must not
+    pass w = NULL.  Slabs written by an earlier call or by the batch launch are not touched."""
     if _last_prep is not None:
         _last_prep.stamp = None
 

@@ -132,8 +132,7 @@ def test_flow3d_training_drift_at_256_vs_reference_trajectory(golden):
     F(2,3) x F(4,3) forward / input gradient, weight-gradient kernel F(4,3)), so a threshold change cannot silently
     turn this into a test of the direct kernels, and that the step really launched them.
     Bands: the step is a chaotic map of its rounding errors -- AdamW's first updates are lr * sign(g) and the
-    distillation term grows 150x over the eight steps -- so the band widens with the step.  Measured drift of loss_G on
-    MI355X (this test prints it): see the assertion message / DESIGN.md §2; the band is 2x the measured worst."""
+    distillation term grows 150x over the eight steps -- so the band widens with the step (values below)."""
     from opticalflowscivis_amd import ops
     from opticalflowscivis_amd.data import synthetic
     from opticalflowscivis_amd.flow3d.model.RIFE import Model
@@ -168,13 +167,15 @@ def test_flow3d_training_drift_at_256_vs_reference_trajectory(golden):
             sums[step + 1] = psum()
     drift = np.array(drift)
     print("relative drift per step (l1, tea, distill, G):\n", drift, "\nPSNR drift dB:", psnr_d)
-    # loss_G: [band per step]; the distillation term is 1 % .. 70 % of loss_G and the most sensitive
-    band_G = [5e-4, 5e-4, 1e-3, 1e-3, 2e-3, 2e-3, 4e-3, 8e-3]
+    # Measured on MI355X (round 4, profiles/r04_traj_drift.txt): loss_l1 / loss_tea / loss_G agree with the reference to
+    # <= 4e-7 relative through step 4 and then separate ~10x per step (4e-6, 1.5e-5, 1.4e-4 at steps 6, 7, 8: the map
+    # amplifies rounding differences, the weight-gradient atomics make the last digits differ from run to run);
+    # loss_distill to <= 5.5e-5 at every step; PSNR to 7e-4 dB at step 8.  Bands: >= 2x the measured worst.
+    band = [2e-6, 2e-6, 2e-6, 2e-6, 4e-6, 2e-5, 6e-5, 5e-4]
     for step in range(n):
-        assert drift[step, 3] <= band_G[step], (step, drift[:, 3])
-        assert drift[step, 0] <= band_G[step] and drift[step, 1] <= band_G[step], (step, drift)
-        assert drift[step, 2] <= 20 * band_G[step], (step, drift[:, 2])
-        assert psnr_d[step] <= 0.01 + 2.5 * step * 0.01, (step, psnr_d)
+        assert max(drift[step, 0], drift[step, 1], drift[step, 3]) <= band[step], (step, drift)
+        assert drift[step, 2] <= 2e-4, (step, drift[:, 2])
+        assert psnr_d[step] <= (1e-4 if step < 6 else 5e-3), (step, psnr_d)
     np.testing.assert_allclose(sums[4], g["param_sums_after4"], rtol=1e-4, atol=2e-2)
     np.testing.assert_allclose(sums[8], g["param_sums_after8"], rtol=1e-4, atol=4e-2)
 
