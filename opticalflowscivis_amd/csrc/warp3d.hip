@@ -209,7 +209,8 @@ struct Mover {
   // issues its flow loads (they land under the store phase and the barrier) and `up_finish` blends the 8
   // corners from LDS, adds, writes the accumulated flow once and leaves the tile in registers in the layout
   // `load` produces.
-  static constexpr int PZ = 4, PY = TH / 2 + 2, PX = TW / 2 + 2, PXP = PX + 1;
+  // (PZ: source slices under dc = 4 x factor output slices -- 8 at factor 2, 16 at factor 4 -- plus the two halo slices)
+  static constexpr int PZ = 6, PY = TH / 2 + 2, PX = TW / 2 + 2, PXP = PX + 1;
   typedef float Brick[PZ][PY][PXP];
 
   __device__ static __forceinline__ int up_i0(int o, int n_in, float rs) {
@@ -861,14 +862,15 @@ bool vec_ok(const W3P& p, const void* a, const void* b, const void* c, const voi
 }
 
 int launch_fwd(const W3Fwd& io, int npair, const float* flow, const UpP* up, W3P& p, fs_stream_t stream) {
-  const unsigned grid = (unsigned)((long long)p.B * p.nDC * p.tilesH * p.tilesW);
   p.flowC = 3 * npair;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g(grid, npair);
-  // measured at 2 x 256^3: forward is fastest with 8 waves per workgroup (4 voxels per thread,
-  // 32 waves/CU), backward with 4 waves (8 voxels per thread: more gathers in flight per wave)
   if (up != nullptr) {
     const bool vec = vec_ok(p, up->prev, up->fout, io.out[0], io.out[1]);
+    // 4 x factor slices per workgroup: the low-resolution brick (staged once per workgroup) then carries 4 source slices + 2
+    // of halo instead of 2 + 2 -- its re-reads were the 1.26x HBM traffic of round 3 (profiles/r03_pmc_traffic.json)
+    p.dc = (int)FS_AB_ENV_LL("FLOWSCI_W3_UPS_DC", 4 * (up->rs < 0.3f ? 4 : 2));
+    p.nDC = fs::cdiv(p.D, p.dc);
+    const dim3 g((unsigned)((long long)p.B * p.nDC * p.tilesH * p.tilesW), npair);
     if (vec) hipLaunchKernelGGL((warp3d_fwd_kernel<512, true, true>), g, dim3(512), 0, st, io, flow, *up, p);
     else hipLaunchKernelGGL((warp3d_fwd_kernel<512, false, true>), g, dim3(512), 0, st, io, flow, *up, p);
   } else {
