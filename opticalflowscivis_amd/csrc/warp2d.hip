@@ -221,6 +221,48 @@ __global__ __launch_bounds__(256) void warp2d_bwd_kernel(W2Bwd io, const float* 
   }
 }
 
+// grad_in of the small planes (UPFlow's feature pyramid: <= 38 x 113) without global atomics: a workgroup OWNS the
+// planes (b, c0 .. c0+nc) -- whole planes fit in LDS -- scatters every pixel's four corner contributions into them
+// with LDS float adds and then adds the finished planes to grad_in with coalesced, non-atomic read-modify-writes (it
+// is the only writer of those planes in this launch).  Round 3's path issued four global float atomics per (pixel,
+// channel) -- 0.06 of the HBM roof on the dominant hot-path kernel of the C3 step; atomics execute at the memory side
+// at ~1.3 TB/s of added bytes chip-wide whatever their locality (MI355X_MICROARCH.md).  grad_flow comes from the
+// gather kernel above (WITH_GIN = false: deterministic, no atomics); this kernel only re-computes the sample
+// positions (flow reads hit L2) and streams grad_out.
+template <int MODE, bool MASK>
+__global__ __launch_bounds__(256) void warp2d_gin_plane_kernel(W2Bwd io, const float* __restrict__ flow,
+                                                               const float* __restrict__ start, W2P p, int NC, int CG) {
+  extern __shared__ float acc[];  // [nc][Hi * Wi]
+  const float* __restrict__ gout = io.gout[blockIdx.y];
+  float* __restrict__ gin = io.gin[blockIdx.y];
+  const int HW = p.H * p.W, HWi = p.Hi * p.Wi;
+  const int b = blockIdx.x / CG, c0 = (blockIdx.x - b * CG) * NC;
+  const int nc = min(NC, p.C - c0);
+  for (int i = threadIdx.x; i < nc * HWi; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const float* fb = flow + ((size_t)b * p.flowC + 2 * blockIdx.y) * HW;
+  const float* gb = gout + ((size_t)b * p.C + c0) * HW;
+  for (int r = threadIdx.x; r < HW; r += 256) {
+    const int y = r / p.W, x = r - y * p.W;
+    const Samp2 s = w2_sample<MODE>(p, b, x, y, fb[r], fb[HW + r], start);
+    const float mk = MASK ? w2_mask(s) : 1.0f;
+    const int o00 = s.y0 * p.Wi + s.x0, o10 = s.y0 * p.Wi + s.x1;
+    const int o01 = s.y1 * p.Wi + s.x0, o11 = s.y1 * p.Wi + s.x1;
+    const float w00 = s.bx * s.by, w10 = s.ax * s.by, w01 = s.bx * s.ay, w11 = s.ax * s.ay;
+    for (int c = 0; c < nc; ++c) {
+      const float g = gb[(size_t)c * HW + r] * mk;
+      float* a = acc + c * HWi;
+      if (s.v00) atomicAdd(a + o00, g * w00);
+      if (s.v10) atomicAdd(a + o10, g * w10);
+      if (s.v01) atomicAdd(a + o01, g * w01);
+      if (s.v11) atomicAdd(a + o11, g * w11);
+    }
+  }
+  __syncthreads();
+  float* go = gin + ((size_t)b * p.C + c0) * HWi;
+  for (int i = threadIdx.x; i < nc * HWi; i += 256) go[i] += acc[i];
+}
+
 // ---- forward-backward occlusion check + outgoing mask -------------------------
 // UPFlow/utils/tools.py:592-630 (_forward_backward_occ_check), :683-709 (torch_outgoing_occ_check),
 // :711-719 (torch_get_obj_occ_check), dispatch :560-590.  The reference runs two torch_warp calls
@@ -349,6 +391,22 @@ void launch_bwd(const W2Bwd& io, int npair, const float* flow, const float* star
   const dim3 g(grid_for(p, sl), npair);
 #define FS_W2_BWD(GIN, SLN) \
   hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, GIN, SLN>), g, dim3(256), 0, st, io, flow, start, gflow, p)
+  // planes that fit LDS: grad_in by plane-owning workgroups (no global atomics), grad_flow by the gather kernel
+  const long long plane = (long long)p.Hi * p.Wi * 4;
+  if (io.gin[0] != nullptr && plane <= 48 * 1024 && (long long)p.B * p.C < (1ll << 31)) {
+    if (gflow != nullptr) {
+      if (sl == 1) FS_W2_BWD(false, 1); else if (sl == 4) FS_W2_BWD(false, 4); else FS_W2_BWD(false, 16);
+    }
+    long long nc = 48 * 1024 / plane;                      // planes per workgroup: as many as fit ...
+    const long long fill = (long long)p.C * p.B / 512;     // ... but keep >= 512 workgroups when the layer allows
+    if (nc > fill) nc = fill;
+    if (nc > p.C) nc = p.C;
+    if (nc < 1) nc = 1;
+    const int CG = (int)((p.C + nc - 1) / nc);
+    hipLaunchKernelGGL((warp2d_gin_plane_kernel<MODE, MASK>), dim3((unsigned)(p.B * CG), npair), dim3(256),
+                       (size_t)(nc * plane), st, io, flow, start, p, (int)nc, CG);
+    return;
+  }
   if (io.gin[0] != nullptr) {
     if (sl == 1) FS_W2_BWD(true, 1); else if (sl == 4) FS_W2_BWD(true, 4); else FS_W2_BWD(true, 16);
   } else {
