@@ -1697,6 +1697,36 @@ def conv3d_wrw_fits(src_dhw, g_dhw):
     return 8 * _vol(src_dhw) * 4 < (1 << 32) and 64 * _vol(g_dhw) * 4 < (1 << 32)
 
 
+# The weight-gradient kernels finish with float atomics into a zero-filled dW: ~56 fill launches of a few KB .. 1.7 MB per
+# Flow-3D step (4 us each plus their dispatch gaps).  Inside a prepared_weights() block -- one optimiser step -- the dW
+# tensors are slices of ONE arena zeroed by a single memset; the arena is sized from what the previous step asked for and
+# lives as long as any gradient that points into it (a new one per step: nothing is ever re-zeroed in place).
+_dw_arena = {}   # device -> [epoch, tensor, offset (floats), floats asked for so far in this epoch]
+_dw_need = {}    # device -> floats the last complete epoch asked for
+
+
+def _dw_zeros(like, shape):
+    n = 1
+    for v in shape:
+        n *= int(v)
+    if _prep_depth == 0 or not _PREP_ON or torch.cuda.is_current_stream_capturing():
+        return like.new_zeros(shape)
+    dev = like.device
+    st = _dw_arena.get(dev)
+    if st is None or st[0] != _prep_epoch:
+        if st is not None:
+            _dw_need[dev] = st[3]
+        need = _dw_need.get(dev, 0)
+        st = _dw_arena[dev] = [_prep_epoch, like.new_zeros(need) if need else None, 0, 0]
+    pad = (n + 3) // 4 * 4  # slices stay 16-byte aligned
+    st[3] += pad
+    if st[1] is None or st[2] + pad > st[1].numel():
+        return like.new_zeros(shape)  # first step, or a step that asks for more than the last one did
+    out = st[1].narrow(0, st[2], n).view(shape)
+    st[2] += pad
+    return out
+
+
 def conv3d_wrw(g, src, k, stride, pad):
     """dW[Cg, Cs, k,k,k] = sum_{b,o} g[b,:,o] (x) src[b,:,o*stride + koff - pad]  (fs_conv3d_wrw)."""
     g = _need_cuda_f32("g", g, 5)
@@ -1705,7 +1735,7 @@ def conv3d_wrw(g, src, k, stride, pad):
     Cs = src.shape[1]
     if src.shape[0] != B:
         raise ValueError("batch mismatch")
-    dw = g.new_zeros(Cg, Cs, k, k, k)
+    dw = _dw_zeros(g, (Cg, Cs, k, k, k))
     fq = 2 * g.numel() * Cs * int(k) ** 3
     kid = conv3d_wrw_kernel_id(g.data_ptr(), src.data_ptr(), B, Cg, Cs, g.shape[2:], src.shape[2:], k, stride, pad)
     with torch.cuda.device(g.device):
@@ -1810,7 +1840,7 @@ def conv3d_wrw_ms(g, pieces, k, stride, pad):
     g = _need_cuda_f32("g", g, 5)
     B, Cg = g.shape[:2]
     Di, Hi, Wi = pieces[0].shape[2:]
-    dw = g.new_zeros(Cg, Cs, k, k, k)
+    dw = _dw_zeros(g, (Cg, Cs, k, k, k))
     with torch.cuda.device(g.device):
         rc = _call_rc("fs_conv3d_wrw_ms", g.data_ptr(), pv, sv, dw.data_ptr(), B, Cg, Cs, g.shape[2], g.shape[3], g.shape[4],
                    Di, Hi, Wi, int(k), int(stride), int(pad), _stream(g),

@@ -28,6 +28,13 @@ bash scripts/prof_configs.sh > $O/prof_configs.log 2>&1 || echo "prof_configs.sh
 # train.py at the bench's size (device-generated triplets)
 python -m opticalflowscivis_amd.flow3d.train --dataset droplet3d --size 256 --samples 24 --batch_size 2 --epoch 2 --mode train \
     --log_every 4 --log_path /tmp/tl256 > $O/train256.txt 2>&1 || true
+# the DDP + RCCL code path rehearsed with ONE rank (process group, DDP hooks, bucket views) next to the plain N = 1 step
+{ echo "# plain N = 1:"; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs --no-bench-parity 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ms_per_step %.3f  value %.3f  step_driver %s' % (d['ms_per_step'], d['value'], d['step_driver']))";
+  echo "# FLOWSCI_BENCH_FORCE_DDP=1 (RCCL process group of one rank, DistributedDataParallel):"; FLOWSCI_BENCH_FORCE_DDP=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs --no-bench-parity 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ms_per_step %.3f  value %.3f  step_driver %s  backend %s' % (d['ms_per_step'], d['value'], d['step_driver'], d['ranks']['backend']))"; } > $O/ddp_one_rank.txt 2>&1 || true
+cat $O/ddp_one_rank.txt
+# the trilinear-warp family stand-alone (ms, algorithmic GB/s, checksums) and the C2 / C3 hot-path kernel tables
+python scripts/w3bench.py 256 smooth 2>&1 | grep -v amdgpu.ids > $O/w3bench.txt || true
+python scripts/c3_kernels.py 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" > $O/c2_c3_kernels.txt || true
 # the Winograd-domain trunk kernels against the direct ones, and the weight gradient's ablation builds: these switches
 # exist only in the measurement build of the library (make ablation), loaded through FLOWSCI_HIP_LIBRARY
 AB=$PWD/opticalflowscivis_amd/csrc/ablation/libflowsci_hip_ab.so
