@@ -7,7 +7,9 @@
 set -e
 export TMPDIR=/tmp
 R=${1:-r04}
+PART=${2:-all}   # 1 = bench line, PMC traffic, kernel trace; 2 = everything after (a gpurun call is limited to 20 minutes)
 O=gpurun_out/final
+if [ "$PART" != 2 ]; then
 rm -rf $O && mkdir -p $O
 python bench.py --no-cpu-baseline --no-configs > $O/bench_events.json 2> $O/bench_events.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-configs > $O/f.log 2>&1
@@ -23,6 +25,9 @@ cp "$(find $O/kt -name '*kernel_stats.csv' | head -1)" $O/kernel_stats.csv
 rm -rf $O/kt
 tail -1 $O/bench.json | cut -c1-400
 head -12 $O/last_step.txt
+fi
+if [ "$PART" = 1 ]; then exit 0; fi
+mkdir -p $O
 # the C2 / C3 steps stand-alone + their kernel stats
 bash scripts/prof_configs.sh > $O/prof_configs.log 2>&1 || echo "prof_configs.sh FAILED (see $O/prof_configs.log)"
 # train.py at the bench's size (device-generated triplets)

@@ -180,6 +180,55 @@ def test_flow3d_training_drift_at_256_vs_reference_trajectory(golden):
     np.testing.assert_allclose(sums[8], g["param_sums_after8"], rtol=1e-4, atol=4e-2)
 
 
+def test_flow3d_b2_at_256_equals_its_b1_slices():
+    """the reference fixtures pin the 256^3 step at B = 1 (the build host cannot hold B = 2); the
+    bench runs B = 2.  This ties the B = 2 LAUNCH GEOMETRY of every kernel of the step (twice the bricks / tiles, batch
+    strides) to those pinned B = 1 runs: from the same weights, the forward of the two-sample batch equals the two
+    one-sample forwards per sample (flow 1e-5 px, frames 2e-5: the coarse blocks' layers pick other brick sizes at half
+    the batch, i.e. another summation order, nothing else differs), and
+    the parameter gradients of the batch loss are the mean of the two samples' gradients (batch-mean losses: 5e-4 of
+    each tensor's norm, the weight-gradient atomics' order is the noise).  A dropped sample or a wrong batch stride in
+    any forward / backward kernel is an O(1) error here."""
+    from opticalflowscivis_amd import ops
+    from opticalflowscivis_amd.data import synthetic
+    from opticalflowscivis_amd.flow3d.model.RIFE import Model
+    S = 256
+    assert _trunk_dispatch(2, S) == _trunk_dispatch(1, S) == (6, ops.WRW_KERNEL_WINO43)
+    data = synthetic.droplet3d_batch(2, S, seed=4321, device=DEV)
+    torch.manual_seed(1234)
+    m = Model(local_rank=-1, device=DEV)
+    params = [p for p in m.flownet.parameters()]
+
+    def grads(batch):
+        m.optimG.zero_grad(set_to_none=True)
+        m.train()
+        with ops.prepared_weights():
+            flow, mask, merged, flow_tea, merged_tea, loss_distill = m.flownet((batch[:, :2].contiguous(), batch[:, 2:3].contiguous()),
+                                                                               scale=[4, 2, 1])
+            gt = batch[:, 2:3].contiguous()
+            loss = ops.l1_loss(merged[2], gt) + ops.l1_loss(merged_tea, gt) + loss_distill * 0.1
+            loss.backward()
+        out = (flow[2].detach().clone(), merged[2].detach().clone(), float(loss.detach()),
+               [p.grad.detach().double().clone() for p in params])
+        return out
+
+    f2, m2, l2, g2 = grads(data)
+    acc = [torch.zeros_like(g) for g in g2]
+    lsum = 0.0
+    for i in range(2):
+        f1, m1, l1, g1 = grads(data[i:i + 1])
+        assert float((f2[i:i + 1] - f1).abs().max()) < 1e-5, i
+        assert float((m2[i:i + 1] - m1).abs().max()) < 2e-5, i
+        lsum += l1
+        for a, g in zip(acc, g1):
+            a += g
+        del f1, m1, g1
+    assert abs(l2 - lsum / 2) < 1e-5 * abs(l2)
+    worst = max(float((g - a / 2).norm()) / max(float(g.norm()), 1e-30) for g, a in zip(g2, acc))
+    print("B = 2 parameter gradients vs the mean of the B = 1 gradients: worst relative L2 error %.2e" % worst)
+    assert worst < 5e-4  # measured 9.8e-5
+
+
 def test_flow3d_step_vs_oracle_jets_c5():
     """BASELINE config C5's workload (5Jets-like smooth density field), per-GPU batch 2 at 64^3."""
     from opticalflowscivis_amd.data import synthetic
