@@ -41,7 +41,7 @@ RULES = [  # (substring of the kernel name, entry point, counts as a launch of t
     ("conv3d_wrw_", "fs_conv3d_wrw", True),
     ("convtr_", "fs_conv3d_tr", True),
     ("warp3d_fwd_kernel<512, true, true>", "fs_upsample_warp3d_pair_fwd", True),
-    ("warp3d_fwd_kernel<512, true, false>", "fs_warp3d_pair_fwd", True),
+    ("warp3d_fwd_kernel<512, true, false>", "fs_warp3d_pair_fwd", True), ("warp3d_fwd_ring_kernel", "fs_warp3d_pair_fwd", True),
     ("prelu_bwd_kernel", "fs_prelu_bwd", True), ("prelu_ga_kernel", "fs_prelu_bwd", False),
     ("merge_fwd_kernel", "fs_merge_fwd", True), ("merge_bwd_kernel", "fs_merge_bwd", True),
     ("distill3_fwd_kernel", "fs_distill_fwd", True), ("distill3_bwd_kernel", "fs_distill_bwd", True),
