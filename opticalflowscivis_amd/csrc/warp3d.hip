@@ -564,7 +564,8 @@ __device__ __forceinline__ Pair ld_pair_raw(const float* __restrict__ base, unsi
   return *reinterpret_cast<const Pair*>(reinterpret_cast<const char*>(base) + (dx ? off : off - 4u));
 }
 
-template <bool VEC, int AUX, int NF>
+// DBG (ablation build only; wrong results): 1 = every pair gather at an 8-byte ALIGNED address, 2 = dword gathers
+template <bool VEC, int AUX, int NF, int DBG = 0>
 __global__ __launch_bounds__(NT2, 2) void warp3d_fwd_ring_kernel(W3Fwd io, const float* __restrict__ flow, W3P p) {
   static_assert(NF >= 3 && NF <= 5, "ring depth");
   const float* __restrict__ in = io.in[blockIdx.y];
@@ -650,8 +651,28 @@ __global__ __launch_bounds__(NT2, 2) void warp3d_fwd_ring_kernel(W3Fwd io, const
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const Samp3 sm = w3_sample<false>(p, lin_h, lin_d, lin_w[i], fa[i], fbv[i], fc[i]);
-      const unsigned o010 = sm.o000 + sm.dy, o100 = sm.o000 + sm.dz, o110 = o100 + sm.dy;
-      g.r[i][0] = ld_pair_raw(vin, sm.o000, sm.dx); g.r[i][1] = ld_pair_raw(vin, o010, sm.dx);
+      unsigned o000 = sm.o000;
+      if (DBG == 1) o000 &= ~7u;
+      const unsigned o010 = o000 + sm.dy, o100 = o000 + sm.dz, o110 = o100 + sm.dy;
+      if (DBG == 2) {
+        g.r[i][0].a = ldb(vin, o000); g.r[i][1].a = ldb(vin, o010); g.r[i][2].a = ldb(vin, o100); g.r[i][3].a = ldb(vin, o110);
+        g.r[i][0].b = g.r[i][1].b = g.r[i][2].b = g.r[i][3].b = sm.ax;
+        g.dx[i] = sm.dx; g.ax[i] = sm.ax; g.ay[i] = sm.ay; g.az[i] = sm.az;
+        continue;
+      }
+      if (DBG == 3 || DBG == 4) {  // half / a quarter of the gather instructions
+        g.r[i][0] = ld_pair_raw(vin, o000, sm.dx);
+        g.r[i][1] = (DBG == 3) ? ld_pair_raw(vin, o110, sm.dx) : g.r[i][0];
+        g.r[i][2] = g.r[i][0]; g.r[i][3] = g.r[i][1];
+        g.dx[i] = sm.dx; g.ax[i] = sm.ax; g.ay[i] = sm.ay; g.az[i] = sm.az;
+        continue;
+      }
+      if (DBG == 5) {  // no gathers at all
+        g.r[i][0].a = sm.ax; g.r[i][0].b = __uint_as_float(o000 + o110); g.r[i][1] = g.r[i][2] = g.r[i][3] = g.r[i][0];
+        g.dx[i] = sm.dx; g.ax[i] = sm.ax; g.ay[i] = sm.ay; g.az[i] = sm.az;
+        continue;
+      }
+      g.r[i][0] = ld_pair_raw(vin, o000, sm.dx); g.r[i][1] = ld_pair_raw(vin, o010, sm.dx);
       g.r[i][2] = ld_pair_raw(vin, o100, sm.dx); g.r[i][3] = ld_pair_raw(vin, o110, sm.dx);
       g.dx[i] = sm.dx; g.ax[i] = sm.ax; g.ay[i] = sm.ay; g.az[i] = sm.az;
     }
@@ -884,6 +905,11 @@ int launch_fwd(const W3Fwd& io, int npair, const float* flow, const UpP* up, W3P
 #define W3_RING_CASE(R, A) \
     if (vec && ring == R + (A ? 10 : 0)) { hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, A, R>), gr, dim3(NT2), 0, st, io, flow, p); FS_LAUNCH_CHECK(); return FS_OK; }
     W3_RING_CASE(3, 0) W3_RING_CASE(4, 0) W3_RING_CASE(5, 0) W3_RING_CASE(3, 2) W3_RING_CASE(5, 2)
+    if (vec && ring == 101) { hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, 2, 4, 1>), gr, dim3(NT2), 0, st, io, flow, p); FS_LAUNCH_CHECK(); return FS_OK; }
+    if (vec && ring == 103) { hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, 2, 4, 3>), gr, dim3(NT2), 0, st, io, flow, p); FS_LAUNCH_CHECK(); return FS_OK; }
+    if (vec && ring == 104) { hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, 2, 4, 4>), gr, dim3(NT2), 0, st, io, flow, p); FS_LAUNCH_CHECK(); return FS_OK; }
+    if (vec && ring == 105) { hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, 2, 4, 5>), gr, dim3(NT2), 0, st, io, flow, p); FS_LAUNCH_CHECK(); return FS_OK; }
+    if (vec && ring == 102) { hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, 2, 4, 2>), gr, dim3(NT2), 0, st, io, flow, p); FS_LAUNCH_CHECK(); return FS_OK; }
 #endif
     if (vec) hipLaunchKernelGGL((warp3d_fwd_ring_kernel<true, 2, 4>), gr, dim3(NT2), 0, st, io, flow, p);
     else hipLaunchKernelGGL((warp3d_fwd_ring_kernel<false, 0, 3>), gr, dim3(NT2), 0, st, io, flow, p);
