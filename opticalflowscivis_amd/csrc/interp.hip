@@ -259,6 +259,62 @@ __global__ __launch_bounds__(256) void upsample3d_scale_add_v4_kernel(const floa
   }
 }
 
+// Exact / 2 and / 4 down-sampling, four consecutive outputs per thread (round 4).  The generic kernel above read its
+// 8 corners per output with 32 dword loads per thread (TA ~85 % busy, 0.36 of the HBM roof); here the 8 (factor 2) or 16
+// (factor 4) source floats of a row move as two float4 / four 8-byte loads (the pairs 4x+1, 4x+2 sit at 4-byte alignment).
+// Same arithmetic: for in = s * out every x lambda is exactly 1/2 and x0 = s * x + (s / 2 - 1) (ATen's
+// area_pixel_compute_source_index in fp32 is exact here), the z / y terms and the summation order are the generic
+// kernel's -- bit-identical to it and to F.interpolate (tests/test_gpu_resize.py).
+struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+
+template <int F>
+__global__ __launch_bounds__(256) void downsample3d_v4_kernel(const float* __restrict__ in, float4* __restrict__ out, IP p,
+                                                              float scale) {
+#pragma clang fp contract(off)
+  const int W4 = p.Wo >> 2;
+  const long long rows = p.nBC * p.Do * p.Ho;
+  const long long total = rows * W4;
+  const long long nin = (long long)p.Di * p.Hi * p.Wi;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long row = e / W4;
+    const int x4 = (int)(e - row * W4);
+    const int y = (int)(row % p.Ho);
+    const long long t = row / p.Ho;
+    const int z = (int)(t % p.Do);
+    const long long bc = t / p.Do;
+    int z0, zp, y0, yp;
+    float lz0, lz1, ly0, ly1;
+    fs::trilinear_axis(z, p.Di, p.rs, z0, zp, lz0, lz1);
+    fs::trilinear_axis(y, p.Hi, p.rs, y0, yp, ly0, ly1);
+    const float* s00 = in_plane(in, p, bc, nin) + ((long long)z0 * p.Hi + y0) * p.Wi + (long long)F * 4 * x4;
+    const float* rp[4] = {s00, s00 + yp * p.Wi, s00 + (long long)zp * p.Hi * p.Wi,
+                          s00 + (long long)zp * p.Hi * p.Wi + yp * p.Wi};
+    float a[4][4], b[4][4];  // [row][output]: the two x taps
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (F == 2) {
+        const float4 u = *reinterpret_cast<const float4*>(rp[r]), v = *reinterpret_cast<const float4*>(rp[r] + 4);
+        a[r][0] = u.x; b[r][0] = u.y; a[r][1] = u.z; b[r][1] = u.w;
+        a[r][2] = v.x; b[r][2] = v.y; a[r][3] = v.z; b[r][3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const F2 q = *reinterpret_cast<const F2*>(rp[r] + 4 * i + 1);
+          a[r][i] = q.a; b[r][i] = q.b;
+        }
+      }
+    }
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = lz0 * (ly0 * (0.5f * a[0][i] + 0.5f * b[0][i]) + ly1 * (0.5f * a[1][i] + 0.5f * b[1][i])) +
+                      lz1 * (ly0 * (0.5f * a[2][i] + 0.5f * b[2][i]) + ly1 * (0.5f * a[3][i] + 0.5f * b[3][i]));
+      o[i] = v * scale;
+    }
+    out[e] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // ---- 2-D bilinear resize (Flow-2D IFBlock) -------------------------------------------------------
 // out[bc, y, x] = scale * bilinear(in) with ATen's upsample_bilinear2d index arithmetic (align_corners=False,
 // scale factor given: source = rs * (dst + 0.5) - 0.5 clamped at 0).  One thread per output pixel.
@@ -548,7 +604,19 @@ static int downsample3d_impl(const float* in, const float* const* srcv, const lo
     }
   }
   const long long total = p.nBC * p.Do * p.Ho * p.Wo;
-  if ((p.Wo & 3) == 0 && ((uintptr_t)out & 15) == 0)
+  // 16-byte row pieces: rows start 16-byte aligned (Wi % 4 == 0, aligned planes); the / 2 and / 4 taps of four outputs
+  // are then two float4 / four 4-byte-aligned pairs per source row
+  bool al = (Win & 3) == 0 && ((long long)Hin * Win) % 4 == 0;
+  if (srcv == nullptr) al = al && ((uintptr_t)in & 15) == 0;
+  else for (int c = 0; c < C; ++c) al = al && ((uintptr_t)srcv[c] & 15) == 0 && sbsv[c] % 4 == 0;
+  if ((p.Wo & 3) == 0 && ((uintptr_t)out & 15) == 0 && al) {
+    if (factor == 2)
+      hipLaunchKernelGGL(downsample3d_v4_kernel<2>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, in,
+                         (float4*)out, p, scale);
+    else
+      hipLaunchKernelGGL(downsample3d_v4_kernel<4>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, in,
+                         (float4*)out, p, scale);
+  } else if ((p.Wo & 3) == 0 && ((uintptr_t)out & 15) == 0)
     hipLaunchKernelGGL(upsample3d_scale_add_v4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream,
                        in, (const float4*)nullptr, (float4*)out, p, scale);
   else
