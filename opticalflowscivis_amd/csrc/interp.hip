@@ -133,19 +133,22 @@ __global__ __launch_bounds__(256) void interp3d_down_adjoint_exact(const float* 
 
 // Same, four consecutive x per thread (Wi % 4 == 0): the row test and the index arithmetic are paid
 // once per float4 store -- the scalar version is bound by its integer divisions, not by HBM.
+// IT: index type of the element decomposition -- unsigned when the float4 count fits 31 bits (three 64-bit divisions
+// per store made this streaming kernel VALU-bound: a vector instruction issuing in 86 % of its cycles, round-3 PMC)
+template <typename IT>
 __global__ __launch_bounds__(256) void interp3d_down_adjoint_exact_v4(const float* __restrict__ gout,
                                                                      float4* __restrict__ gin, IP p, float scale) {
-  const int W4 = p.Wi >> 2;
-  const long long rows = p.nBC * p.Di * p.Hi;
-  const long long total = rows * W4;
+  const IT W4 = (IT)(p.Wi >> 2);
+  const IT rows = (IT)(p.nBC * p.Di * p.Hi);
+  const IT total = rows * W4;
   const int lo = p.s / 2 - 1, hi = p.s / 2;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long row = e / W4;
+  for (IT e = (IT)blockIdx.x * 256 + threadIdx.x; e < total; e += (IT)gridDim.x * 256) {
+    const IT row = e / W4;
     const int x4 = (int)(e - row * W4);
-    const int y = (int)(row % p.Hi);
-    const long long t = row / p.Hi;
-    const int z = (int)(t % p.Di);
-    const long long bc = t / p.Di;
+    const int y = (int)(row % (IT)p.Hi);
+    const IT t = row / (IT)p.Hi;
+    const int z = (int)(t % (IT)p.Di);
+    const long long bc = (long long)(t / (IT)p.Di);
     const int ry = y % p.s, rz = z % p.s;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((ry == lo || ry == hi) && (rz == lo || rz == hi)) {
@@ -517,8 +520,11 @@ extern "C" int fs_interp3d_bwd_scaled(const float* grad_out, float* grad_in, flo
   hipStream_t st = (hipStream_t)stream;
   if (!upsample) {
     const bool exact = Din == Dout * factor && Hin == Hout * factor && Win == Wout * factor;
-    if (exact && (Win & 3) == 0 && ((uintptr_t)grad_in & 15) == 0)
-      hipLaunchKernelGGL(interp3d_down_adjoint_exact_v4, dim3(grid_for(total / 4)), dim3(256), 0, st, grad_out,
+    if (exact && (Win & 3) == 0 && ((uintptr_t)grad_in & 15) == 0 && total / 4 + (1ll << 28) < (1ll << 32))
+      hipLaunchKernelGGL(interp3d_down_adjoint_exact_v4<unsigned>, dim3(grid_for(total / 4)), dim3(256), 0, st, grad_out,
+                         (float4*)grad_in, p, scale);
+    else if (exact && (Win & 3) == 0 && ((uintptr_t)grad_in & 15) == 0)
+      hipLaunchKernelGGL(interp3d_down_adjoint_exact_v4<long long>, dim3(grid_for(total / 4)), dim3(256), 0, st, grad_out,
                          (float4*)grad_in, p, scale);
     else if (exact)
       hipLaunchKernelGGL(interp3d_down_adjoint_exact, dim3(grid_for(total)), dim3(256), 0, st, grad_out,
