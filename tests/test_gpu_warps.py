@@ -374,3 +374,62 @@ def test_empty_batch_is_a_no_op(ops):
     # mismatched batches are still an error, not silently empty
     with pytest.raises(ValueError):
         ops.warp3d(torch.zeros(0, 2, 4, 5, 6, device=DEV), torch.zeros(1, 3, 4, 5, 6, device=DEV))
+
+
+def test_warp3d_ragged_sweep_vs_oracle(ops):
+    """Round 4: the forward pair runs as a ring pipeline (mover waves + LDS-DMA tiles, 16 slices per workgroup, gathers
+    one slice ahead) with a 16-byte and a dword form of the tile DMA.  Seeded sweep over extents that hit every corner of
+    it: fewer slices than ring stages (D = 2, 3), D not a multiple of 16, H / W below, at and just above one 64 x 32 tile,
+    W % 4 != 0 (dword pieces) and W % 4 == 0 (16-byte pieces), several image channels (stages of one pipeline), sampled
+    volumes whose extent differs from the flow's.  Forward vs the oracle everywhere; flow gradient on a subset."""
+    rng = np.random.RandomState(20260104)
+    shapes = [(1, 1, 2, 5, 8), (1, 2, 3, 64, 32), (2, 1, 17, 65, 33), (1, 1, 33, 7, 36), (1, 3, 5, 70, 12),
+              (1, 1, 16, 64, 64), (2, 2, 18, 3, 4), (1, 1, 40, 129, 31)]
+    for _ in range(6):
+        shapes.append((int(rng.randint(1, 3)), int(rng.randint(1, 3)), int(rng.randint(2, 40)), int(rng.randint(2, 140)),
+                       int(rng.randint(2, 70))))
+    for n, (B, C, D, H, W) in enumerate(shapes):
+        g = torch.Generator().manual_seed(n)
+        mixed = n % 5 == 4
+        ishape = (B, C, D + 2, H + 1, W + 3) if mixed else (B, C, D, H, W)
+        x = torch.rand(ishape, generator=g)
+        f = (torch.rand(B, 3, D, H, W, generator=g) * 2 - 1) * 3.0
+        ref = owarps.warp3d_ref(x, f)
+        out = ops.warp3d(x.to(DEV), f.to(DEV))
+        assert maxerr(out, ref) < OUT_ATOL, (B, C, D, H, W, mixed)
+        # the pair launch (both members in one grid) on the same data
+        f6 = torch.cat((f, -f), 1)
+        o0, o1 = ops.warp_pair(x.to(DEV), x.flip(0).to(DEV) if B > 1 else x.to(DEV), f6.to(DEV))
+        assert torch.equal(o0, out)
+        if n % 3 == 0:
+            fr = f.clone().requires_grad_()
+            G = torch.randn(ref.shape, generator=g)
+            (gfr,) = torch.autograd.grad((owarps.warp3d_ref(x, fr) * G).sum(), [fr])
+            fd = f.to(DEV).requires_grad_()
+            (gf,) = torch.autograd.grad((ops.warp3d(x.to(DEV), fd) * G.to(DEV)).sum(), [fd])
+            assert frac_bad(gf, gfr, GRAD_ATOL) < 2e-3, (B, C, D, H, W)  # (small volumes: a few boundary voxels weigh more)
+
+
+def test_warp2d_plane_owner_grad_in_sweep(ops):
+    """Round 4: grad_in of planes that fit LDS comes from plane-owning workgroups (no global atomics), larger planes keep
+    the atomic kernel: both against the oracle, at channel counts that do not divide the planes-per-workgroup choice,
+    masked and unmasked, and across the 48 KB switch (110 x 110 floats fit, 111 x 111 do not)."""
+    cases = [(2, 5, 7, 9, True), (3, 33, 19, 57, True), (1, 7, 110, 110, False), (1, 3, 111, 111, False),
+             (32, 9, 3, 8, True), (2, 1, 38, 113, False)]
+    for n, (B, C, H, W, mask) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + n)
+        x = torch.rand(B, C, H, W, generator=g)
+        f = (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * 2.5
+        G = torch.randn(B, C, H, W, generator=g)
+        if mask:  # borderline pixels (validity decided by fp32 rounding, DESIGN.md §2) leave the upstream gradient on both sides
+            G = G * (~owarps.pwc_mask_borderline(x, f))
+        xr, fr = x.clone().requires_grad_(), f.clone().requires_grad_()
+        ref = owarps.warp2d_pwc_ref(xr, fr, mask)
+        gxr, gfr = torch.autograd.grad((ref * G).sum(), [xr, fr])
+        xd, fd = x.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+        out = ops.warp2d_pwc(xd, fd, mask)
+        gx, gf = torch.autograd.grad((out * G.to(DEV)).sum(), [xd, fd])
+        if not mask:
+            assert maxerr(out, ref) < OUT_ATOL
+        assert frac_bad(gx, gxr, GRAD_ATOL) == 0.0, (B, C, H, W)
+        assert frac_bad(gf, gfr, GRAD_ATOL) < 1e-4
