@@ -11,8 +11,9 @@ estimator, context network, unsupervised losses) with the per-frame-pair hot pat
 
 Convolutions are stock torch.nn (MIOpen).  Module tree and construction order follow the
 reference (upflow.py:327-366), so checkpoints and seeds are interchangeable.  The self-guided
-upsampling variant (`if_sgu_upsample`, off in the reference's own training config,
-scripts/simple_train.py:327) is not built.
+upsampling variant (`if_sgu_upsample`, upflow.py:21-92; off in the reference's own training config,
+scripts/simple_train.py:327) is `network_tools.sgu_model`: its feature warp and its flow warp are the
+same two HIP ops (masked PWC warp, `tools.torch_warp`).
 """
 import collections
 
@@ -29,7 +30,59 @@ from .pwc_modules import (ContextNetwork_v2_, FeatureExtractor, FlowEstimatorDen
                           conv, initialize_msra, upsample2d_flow_as, upsample_flow)
 
 
+class _SguDenseEstimator(nn.Module):
+    """upflow.py:26-63 (`FlowEstimatorDense_temp`): five densely connected 3x3 convolutions + a linear head; returns
+    (features, head output).  Children conv1..conv5, conv_last as in the reference (state_dict keys)."""
+
+    def __init__(self, ch_in, f_channels, ch_out):
+        super().__init__()
+        n = ch_in
+        for i, f in enumerate(f_channels):
+            setattr(self, "conv%d" % (i + 1), conv(n, f))
+            n += f
+        self.num_feature_channel = n
+        self.conv_last = conv(n, ch_out, isReLU=False)
+
+    def forward(self, x):
+        for i in range(1, 6):
+            x = torch.cat([getattr(self, "conv%d" % i)(x), x], dim=1)
+        return x, self.conv_last(x)
+
+
 class network_tools:
+    class sgu_model(nn.Module):
+        """upflow.py:21-92: self-guided upsampling.  From the two 32-channel feature maps of a level (the second warped to
+        the first by the bilinearly up-sampled flow) a small dense estimator predicts an interpolation flow and a mask; the
+        output is `warp(flow, inter_flow) * (1 - mask) + flow * mask`.  Module tree (`warping_layer`,
+        `dense_estimator_mask`, `upsample_output_conv`) and construction order follow the reference, so seeds and
+        checkpoints carry over."""
+
+        def __init__(self):
+            super().__init__()
+            self.warping_layer = WarpingLayer_no_div()
+            self.dense_estimator_mask = _SguDenseEstimator(64, f_channels=(32, 32, 32, 16, 8), ch_out=3)
+            self.upsample_output_conv = nn.Sequential(conv(3, 16, kernel_size=3, stride=1, dilation=1),
+                                                      conv(16, 16, stride=2),
+                                                      conv(16, 32, kernel_size=3, stride=1, dilation=1),
+                                                      conv(32, 32, stride=2))
+
+        def forward(self, flow_init, feature_1, feature_2, output_level_flow=None):
+            if flow_init.shape[2:] != feature_1.shape[2:]:
+                flow_init = upsample2d_flow_as(flow_init, feature_1, mode="bilinear", if_rate=True)
+            feature_2_warp = self.warping_layer(feature_2, flow_init)  # HIP: warp + validity mask
+            _, x_out = self.dense_estimator_mask(torch.cat((feature_1, feature_2_warp), dim=1))
+            inter_flow = x_out[:, :2]
+            inter_mask = torch.sigmoid(x_out[:, 2:3])
+            if output_level_flow is not None:
+                inter_flow = upsample2d_flow_as(inter_flow, output_level_flow, mode="bilinear", if_rate=True)
+                inter_mask = upsample2d_flow_as(inter_mask, output_level_flow, mode="bilinear")
+                flow_init = output_level_flow
+            flow_up = tools.torch_warp(flow_init, inter_flow) * (1 - inter_mask) + flow_init * inter_mask  # HIP warp
+            return flow_init, flow_up, inter_flow, inter_mask
+
+        def output_conv(self, x):
+            return self.upsample_output_conv(x)
+
     @classmethod
     def normalize_features(cls, feature_list, normalize, center, moments_across_channels=True,
                            moments_across_images=True):
@@ -148,8 +201,6 @@ class UPFlow_net(tools.abstract_model):
     def __init__(self, conf):
         super().__init__()
         self.conf = conf
-        if conf.if_sgu_upsample:
-            raise NotImplementedError("self-guided upsampling (sgu_model) is not built")
         self.search_range = 4
         self.num_chs = [3, 16, 32, 64, 96, 128, 196]
         self.estimator_f_channels = (128, 128, 96, 64, 32)
@@ -166,7 +217,7 @@ class UPFlow_net(tools.abstract_model):
                                                    f_channels=self.context_f_channels)
         self.conv_1x1 = nn.ModuleList([conv(c, 32, kernel_size=1, stride=1, dilation=1)
                                        for c in (196, 128, 96, 64, 32)])
-        self.sgi_model = None
+        self.sgi_model = network_tools.sgu_model() if conf.if_sgu_upsample else None  # upflow.py:361-365
         self.occ_check_model = tools.occ_check_model(occ_type=conf.occ_type, occ_alpha_1=conf.alpha_1,
                                                      occ_alpha_2=conf.alpha_2,
                                                      obj_out_all=conf.occ_check_obj_out_all)
@@ -295,7 +346,15 @@ class UPFlow_net(tools.abstract_model):
             flows.append([flow_f, flow_b])
         flow_f_out = upsample2d_flow_as(flow_f, x1_raw, mode="bilinear", if_rate=True)
         flow_b_out = upsample2d_flow_as(flow_b, x1_raw, mode="bilinear", if_rate=True)
+        if self.conf.if_sgu_upsample:  # upflow.py:612-616: the 1/4-resolution flow guided up to full resolution
+            f1, f2 = self.sgi_model.output_conv(x1_raw), self.sgi_model.output_conv(x2_raw)
+            flow_f_out = self.self_guided_upsample(flow_f, f1, f2, output_level_flow=flow_f_out)
+            flow_b_out = self.self_guided_upsample(flow_b, f2, f1, output_level_flow=flow_b_out)
         return flow_f_out, flow_b_out, flows[::-1]
+
+    def self_guided_upsample(self, flow_up_bilinear, feature_1, feature_2, output_level_flow=None):
+        """upflow.py:677-679."""
+        return self.sgi_model(flow_up_bilinear, feature_1, feature_2, output_level_flow=output_level_flow)[1]
 
     def decode_level_res(self, level, flow_1, flow_2, feature_1, feature_1_1x1, feature_2, feature_2_1x1):
         """upflow.py:621-663: warp, (normalise,) correlate, estimate, refine."""
@@ -305,6 +364,9 @@ class UPFlow_net(tools.abstract_model):
         if level == 0:
             feature_2_warp, feature_1_warp = feature_2, feature_1
         else:
+            if conf.if_sgu_upsample:  # upflow.py:629-631
+                flow_1_up = self.self_guided_upsample(flow_1_up, feature_1_1x1, feature_2_1x1)
+                flow_2_up = self.self_guided_upsample(flow_2_up, feature_2_1x1, feature_1_1x1)
             feature_2_warp = self.warping_layer(feature_2, flow_1_up)   # HIP: warp + validity mask
             feature_1_warp = self.warping_layer(feature_1, flow_2_up)
         if (conf.if_norm_before_cost_volume and not conf.norm_moments_across_channels

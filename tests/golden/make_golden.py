@@ -11,6 +11,7 @@ Usage (each group imports a different reference package layout, so one process p
     python tests/golden/make_golden.py flow3d_256   # Flow-3D Model.update at the BASELINE size (B=1, 256^3; ~35 GB, minutes)
     python tests/golden/make_golden.py flow3d_256_traj  # the same, eight AdamW steps (training drift; ~10 min)
     python tests/golden/make_golden.py upflow_e2e   # UPFlow_net forward losses / flows / grads
+    python tests/golden/make_golden.py upflow_sgu   # UPFlow_net with the self-guided upsampling module on
     python tests/golden/make_golden.py upflow_levels  # per pyramid level: decode_level_res inputs / outputs / grads
     python tests/golden/make_golden.py rife_next    # Flow-2D LapLoss
     python tests/golden/make_golden.py upflow_next  # occ_check_model, normalize_features
@@ -424,6 +425,46 @@ def upflow_e2e():
     print("wrote upflow_e2e.npz; losses", dict(zip(keys, store["losses"])), "nparam", int(store["nparam"]))
 
 
+def upflow_sgu():
+    """UPFlow_net with the self-guided upsampling module on (`if_sgu_upsample=True`, UPFlow/model/upflow.py:21-92,
+    362-363, 612-616, 629-631, 677-679): forward + backward on a seeded pair, same recipe as `upflow_e2e` at 96 x 128."""
+    _install_stubs()
+    sys.path[:0] = [REF + "/UPFlow"]
+    import model.upflow as U
+    U.device = torch.device("cpu")
+    conf = U.UPFlow_net.config()
+    _quiet(conf.update, {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+                         'norm_moments_across_images': False, 'if_use_cor_pytorch': True,
+                         'if_sgu_upsample': True, 'photo_loss_census_weight': 1,
+                         'multi_scale_distillation_weight': 1})
+    torch.manual_seed(0)
+    net = _quiet(conf)
+    gen = torch.Generator().manual_seed(5)
+    H, W = 96, 128
+    base = torch.nn.functional.interpolate(torch.rand(2, 3, H // 8, W // 8 + 2, generator=gen), size=(H, W + 16),
+                                           mode="bicubic", align_corners=True).clamp(0, 1)
+    im1, im2 = base[:, :, :, :W].contiguous(), base[:, :, :, 3:W + 3].contiguous()
+    store = dict(im1=_np(im1), im2=_np(im2))
+    store["nparam"] = np.array(sum(p.numel() for p in net.parameters()))
+    store["param_names"] = np.array([n for n, _ in net.named_parameters()])
+    store["param_sums"] = np.array([float(p.detach().double().sum()) for p in net.parameters()])
+    out = _quiet(net, {'im1': im1.numpy(), 'im2': im2.numpy(), 'if_loss': True})
+    ld = out['loss_dict']
+    keys = ['photo_loss', 'smooth_loss', 'census_loss', 'msd_loss']
+    store["loss_keys"] = np.array(keys)
+    store["losses"] = np.array([float(ld[k]) for k in keys])
+    store["flow_f_out"] = _np(out['flow_f_out'])
+    store["flow_b_out"] = _np(out['flow_b_out'])
+    store["occ_fw"] = _np(out['occ_fw'])
+    store["im1_warp"] = _np(out['im1_warp'])
+    total = sum(ld[k] for k in keys)
+    total.backward()
+    store["grad_abs_sums"] = np.array([float(p.grad.detach().double().abs().sum()) if p.grad is not None else 0.0
+                                       for p in net.parameters()])
+    np.savez_compressed(os.path.join(OUT, "upflow_sgu.npz"), **store)
+    print("wrote upflow_sgu.npz; losses", dict(zip(keys, store["losses"])), "nparam", int(store["nparam"]))
+
+
 # ------------------------------------------------------------------------------------------
 def _proj(t, seed):
     """Two numbers that pin a gradient tensor without storing it: its dot product with a seeded Gaussian
@@ -626,7 +667,7 @@ def ckpt():
 
 
 GROUPS = dict(flow3d_256=flow3d_256, flow3d_256_traj=flow3d_256_traj, ckpt=ckpt, rife_ops=rife_ops, upflow_ops=upflow_ops, upflow_next=upflow_next, rife_next=rife_next, flow3d_e2e=flow3d_e2e, flow2d_e2e=flow2d_e2e,
-              upflow_e2e=upflow_e2e, upflow_levels=upflow_levels)
+              upflow_e2e=upflow_e2e, upflow_sgu=upflow_sgu, upflow_levels=upflow_levels)
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"

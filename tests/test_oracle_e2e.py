@@ -81,3 +81,34 @@ def test_upflow_mirror_on_oracle_ops_matches_reference(golden):
     gsum = np.array([float(p.grad.detach().double().abs().sum()) if p.grad is not None else 0.0
                      for p in net.parameters()])
     np.testing.assert_allclose(gsum, g["grad_abs_sums"], rtol=1e-5, atol=1e-9)
+
+
+def test_upflow_sgu_mirror_on_oracle_ops_matches_reference(golden):
+    """The self-guided upsampling variant (`if_sgu_upsample=True`, UPFlow/model/upflow.py:21-92, 612-616, 629-631): the
+    mirror's `sgu_model` -- same module tree, same construction order -- with the hot-path ops swapped for the oracle's
+    CPU restatements against the reference's own forward + backward (tests/golden/upflow_sgu.npz, seed 0, 96 x 128)."""
+    from opticalflowscivis_amd.upflow.model.upflow import UPFlow_net
+    from oracle.upflow_port import cpu_ops
+    g = golden("upflow_sgu")
+    conf = UPFlow_net.config()
+    conf.update({'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+                 'norm_moments_across_images': False, 'photo_loss_census_weight': 1,
+                 'multi_scale_distillation_weight': 1, 'if_sgu_upsample': True})
+    torch.manual_seed(0)
+    net = conf()
+    assert [n for n, _ in net.named_parameters()] == [str(n) for n in g["param_names"]]  # checkpoints carry over
+    assert sum(p.numel() for p in net.parameters()) == int(g["nparam"])
+    np.testing.assert_allclose(_psums(net), g["param_sums"], rtol=0, atol=1e-9)      # and so do seeds
+    with cpu_ops():
+        out = net({'im1': torch.from_numpy(g["im1"]), 'im2': torch.from_numpy(g["im2"]), 'if_loss': True})
+        keys = [str(k) for k in g["loss_keys"]]
+        got = np.array([float(out['loss_dict'][k].detach()) for k in keys])
+        np.testing.assert_allclose(got, g["losses"], rtol=1e-6)
+        assert float((out['flow_f_out'].detach() - torch.from_numpy(g["flow_f_out"])).abs().max()) < 1e-5
+        assert float((out['flow_b_out'].detach() - torch.from_numpy(g["flow_b_out"])).abs().max()) < 1e-5
+        assert float((out['occ_fw'] != torch.from_numpy(g["occ_fw"])).float().mean()) == 0.0
+        assert float((out['im1_warp'].detach() - torch.from_numpy(g["im1_warp"])).abs().max()) < 1e-6
+        sum(out['loss_dict'][k] for k in keys).backward()
+    gsum = np.array([float(p.grad.detach().double().abs().sum()) if p.grad is not None else 0.0
+                     for p in net.parameters()])
+    np.testing.assert_allclose(gsum, g["grad_abs_sums"], rtol=1e-5, atol=1e-9)
