@@ -42,6 +42,12 @@ def test_bench_json_contract():
     assert pw["rel"] <= pw["tolerance_rel"] == 5e-4
     assert abs(pw["loss_gpu"] - pw["loss_oracle"]) <= 5e-4 * abs(pw["loss_oracle"])
     assert rf["measured"].startswith("HIP events on the launch stream inside the timed region")
+    # round 4: `frac` is a fraction (executed flops or algorithmic bytes over the peak), the line says what could have
+    # changed dispatch, and which driver stepped the model; the bench-size witness belongs to the 256^3 workload only
+    assert 0 < rf["frac"] <= 1 and "entry_point" in rf
+    assert d["switches"] == {"library": "product", "env": {k: v for k, v in os.environ.items() if k.startswith("FLOWSCI_")}}
+    assert d["step_driver"].startswith("eager launches")
+    assert "parity_at_bench_size" not in d
 
 
 def test_bench_line_carries_the_other_single_gpu_configs():
