@@ -202,6 +202,9 @@ def parse():
                          "default so that N = 1 and N > 1 run the same code path; no per-kernel records)")
     ap.add_argument("--cpu-size", type=int, nargs="+", default=[64, 128],
                     help="edges of the bounded CPU samples (SURVEY 8d: 64^3 and 128^3); the last one is `value`")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="torch.use_deterministic_algorithms(True): the weight gradients take the workspace form without "
+                         "float atomics (fs_conv3d_wrw_det) -- the whole step is then bitwise reproducible")
     ap.add_argument("--no-bench-parity", action="store_true",
                     help="skip parity_at_bench_size (two steps at B=1 x 256^3 against tests/golden/flow3d_256.npz)")
     ap.add_argument("--no-configs", action="store_true",
@@ -606,6 +609,8 @@ def main():
     from opticalflowscivis_amd.data import synthetic
     from opticalflowscivis_amd.flow3d.model.RIFE import Model
 
+    if args.deterministic:
+        torch.use_deterministic_algorithms(True)
     torch.manual_seed(1234)  # same initial weights on every rank (DDP would broadcast anyway)
     model = Model(local_rank=local_rank if ddp else -1, device=dev)
     S, B = args.size, args.batch
@@ -738,6 +743,7 @@ def main():
             "loss_G": loss,
             # what in the environment could have changed dispatch or numerics (INTEGRATION.md "Switches")
             "switches": _lib_switches(),
+            "deterministic": bool(torch.are_deterministic_algorithms_enabled()),
             "step_driver": "hip-graph replay (Model.graphed_update)" if (args.graph and not ddp) else
                            "eager launches (Model.update%s)" % (" under DistributedDataParallel" if ddp else ""),
         }

@@ -40,7 +40,8 @@ enum {
  *        the number: fixed in round 3) and added the f1-f4 / conv3d entry points.
  *   310  round 3: fs_conv3d_fwd* / fs_conv3d_tr* accept w = NULL ("ws is prepared"), fs_conv3d_*_wprep_jobs,
  *        fs_conv3d_wprep_batch.
- *   320  round 4: fs_conv3d_wrw_kernel_id (which weight-gradient kernel a call dispatches to; nothing launched).
+ *   320  round 4: fs_conv3d_wrw_kernel_id (which weight-gradient kernel a call dispatches to; nothing launched);
+ *        fs_conv3d_wrw_det / fs_conv3d_wrw_det_ws_floats (workspace form without float atomics).
  *        The library reads no environment variable any more (measurement switches live in the -DFS_ABLATION build). */
 #define FS_ABI_VERSION 320
 int fs_version(void);
@@ -568,6 +569,22 @@ int fs_conv3d_fwd_prelu_ms(const float* const* src, const long long* batch_strid
 int fs_conv3d_wrw_ms(const float* g, const float* const* src, const long long* batch_strides, float* dw,
                      int B, int Cg, int Cs, int Do, int Ho, int Wo, int Di, int Hi, int Wi,
                      int kernel, int stride, int pad, fs_stream_t stream);
+
+/* Deterministic weight gradient (round 4).  fs_conv3d_wrw / _ms split the positions into runs whose partial tiles
+ * meet in dw through float atomics: the order of arrival decides the last bits.  Here every run STORES its partial
+ * tile into its own copy of dw inside a caller-owned workspace and one more launch adds the copies in run order:
+ * same kernels, same dispatch, bitwise reproducible from run to run; dw is overwritten (no zero fill).
+ *   fs_conv3d_wrw_det_ws_floats: floats of workspace this call needs (runs x Cg*Cs*k^3; its own dispatch, nothing
+ *   launched), or -(FS_ERR_*).  src_planes / batch_strides both NULL: one `src` tensor; both non-NULL: the
+ *   multi-source form of fs_conv3d_wrw_ms (`src` ignored).
+ * The Python binding takes this path when torch.are_deterministic_algorithms_enabled(). */
+long long fs_conv3d_wrw_det_ws_floats(const float* g, const float* src, const float* const* src_planes,
+                                      const long long* batch_strides, int B, int Cg, int Cs,
+                                      int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride, int pad);
+int fs_conv3d_wrw_det(const float* g, const float* src, const float* const* src_planes, const long long* batch_strides,
+                      float* dw, float* ws, long long ws_floats, int B, int Cg, int Cs,
+                      int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride, int pad,
+                      fs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight preparation in one launch per optimiser step.  fs_conv3d_fwd* / fs_conv3d_tr* re-lay their weights into

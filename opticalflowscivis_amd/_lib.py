@@ -119,6 +119,8 @@ SIGNATURES = {
     "fs_corr3d_bwd": [_f32p] * 5 + [_int] * 6 + [_stream],
     "fs_conv3d_wrw": [_f32p] * 3 + [_int] * 12 + [_stream],
     "fs_conv3d_wrw_kernel_id": [_f32p] * 2 + [_int] * 12,
+    "fs_conv3d_wrw_det_ws_floats": [_f32p, _f32p, _ptrv, _i64p] + [_int] * 12,
+    "fs_conv3d_wrw_det": [_f32p, _f32p, _ptrv, _i64p, _f32p, _f32p, _i64] + [_int] * 12 + [_stream],
     "fs_conv3d_fwd_prelu_ms": [_ptrv, _i64p] + [_f32p] * 6 + [_int] * 13 + [_stream],
     "fs_conv3d_wrw_ms": [_f32p, _ptrv, _i64p, _f32p] + [_int] * 12 + [_stream],
     "fs_wssim_fwd": [_f32p] * 5 + [_int] * 5 + [_stream],
@@ -131,6 +133,7 @@ SIGNATURES = {
                       _stream],
 }
 _RESTYPES = {"fs_error_string": ctypes.c_char_p, "fs_conv3d_fwd_ws_floats": ctypes.c_longlong,
+             "fs_conv3d_wrw_det_ws_floats": ctypes.c_longlong,
              "fs_conv3d_tr_ws_floats": ctypes.c_longlong, "fs_conv3d_fwd_dprelu_part_floats": ctypes.c_longlong,
              "fs_conv3d_fwd_dprelu_part_floats_k3": ctypes.c_longlong}
 

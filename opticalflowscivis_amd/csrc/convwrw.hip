@@ -66,7 +66,47 @@ struct WB {
   int nsrc;
   const float* src[12];
   long long sbs[12];
+  // deterministic mode (fs_conv3d_wrw_det): slab != 0 = floats per private copy of dW; run blockIdx.x STORES its partial
+  // tile into copy blockIdx.x of the workspace passed as `dW` (no atomics), wrw_reduce_kernel sums the copies in run order
+  long long slab;
 };
+
+// Deterministic weight gradients: every kernel below splits the positions into runs (blockIdx.x) whose partial tiles
+// overlap in dW.  Default: float atomics into a zero-filled dW (order of the adds = order of arrival: last-bit noise from
+// run to run).  With a workspace of (runs x |dW|) floats each run writes its own copy -- every (blockIdx.y, blockIdx.z) of a
+// run covers a disjoint part of dW, together all of it -- and one more launch adds the copies in run order.
+struct WDet {
+  float* ws;         // workspace, or nullptr with `need` set
+  long long cap;     // floats available in ws
+  long long* need;   // != nullptr: write the floats the dispatch would need and launch nothing
+};
+
+__global__ __launch_bounds__(256) void wrw_reduce_kernel(const float* __restrict__ ws, int runs, long long n,
+                                                         float* __restrict__ dW) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float a = ws[i];
+    for (int r = 1; r < runs; ++r) a += ws[(size_t)r * n + i];
+    dW[i] = a;
+  }
+}
+
+// host side of the deterministic mode, shared by the three launchers: returns < 0 to go on with the launch (the pointer
+// the kernel writes through is *out, p_slab its slab stride), or a status to return
+static inline int wrw_det_begin(const WDet* det, long long runs, long long dwf, float* dW, float** out, long long* p_slab) {
+  *out = dW; *p_slab = 0;
+  if (det == nullptr) return -1;
+  if (det->need != nullptr) { *det->need = runs * dwf; return FS_OK; }
+  if (det->ws == nullptr || runs * dwf > det->cap) return FS_ERR_ARG;
+  *out = det->ws; *p_slab = dwf;
+  return -1;
+}
+
+static inline void wrw_det_end(const WDet* det, long long runs, long long dwf, float* dW, hipStream_t st) {
+  if (det == nullptr || det->need != nullptr) return;
+  const long long blocks = (dwf + 255) / 256;
+  hipLaunchKernelGGL(wrw_reduce_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, det->ws, (int)runs,
+                     dwf, dW);
+}
 
 constexpr int pad_to(int n, int want) { return n + (((want - n) % 32) + 32) % 32; }
 
@@ -259,13 +299,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_wrw_brick_kernel(const float* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int g = g0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (g < p.Cg) atomicAdd(dW + (size_t)g * p.Cs * K3 + (size_t)c0 * K3 + j, acc[m][n][r]);
+        if (g < p.Cg) {
+          float* q = dW + (size_t)blockIdx.x * p.slab + (size_t)g * p.Cs * K3 + (size_t)c0 * K3 + j;
+          if (p.slab) *q = acc[m][n][r]; else atomicAdd(q, acc[m][n][r]);
+        }
       }
     }
 }
 
 template <int K, int S, int NC, int TZ, int TY>
-int launch_brick(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st) {
+int launch_brick(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st, const WDet* det = nullptr) {
   WB p;
   p.B = w.B; p.Cg = w.Cg; p.Cs = w.Cs; p.Do = w.Do; p.Ho = w.Ho; p.Wo = w.Wo;
   p.Di = w.Di; p.Hi = w.Hi; p.Wi = w.Wi; p.pad = w.pad;
@@ -284,10 +327,16 @@ int launch_brick(const float* G, const float* Src, float* dW, const WP& w, hipSt
   const long long gx = (p.bricks + p.spw - 1) / p.spw;
   if (gx >= (1ll << 31) || nchunks > 65535 || mtiles > 65535) return FS_ERR_SHAPE;
   dim3 grid((unsigned)gx, nchunks, mtiles);
+  constexpr int K3 = K * K * K;
+  float* out;
+  const long long dwf = (long long)p.Cg * p.Cs * K3;
+  const int drc = wrw_det_begin(det, gx, dwf, dW, &out, &p.slab);
+  if (drc >= 0) return drc;
   if (mt == 2)
-    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 2, TZ, TY>), grid, dim3(256), 0, st, G, Src, dW, p);
+    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 2, TZ, TY>), grid, dim3(256), 0, st, G, Src, out, p);
   else
-    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 1, TZ, TY>), grid, dim3(256), 0, st, G, Src, dW, p);
+    hipLaunchKernelGGL((conv3d_wrw_brick_kernel<K, S, NC, 1, TZ, TY>), grid, dim3(256), 0, st, G, Src, out, p);
+  wrw_det_end(det, gx, dwf, dW, st);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -577,7 +626,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int g = g0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (g < p.Cg) atomicAdd(dW + (size_t)g * p.Cs * K3 + (size_t)c0 * K3 + j, a[r]);
+      if (g < p.Cg) {
+        float* q = dW + (size_t)blockIdx.x * p.slab + (size_t)g * p.Cs * K3 + (size_t)c0 * K3 + j;
+        if (p.slab) *q = a[r]; else atomicAdd(q, a[r]);
+      }
     }
   };
 #pragma unroll
@@ -588,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
 }
 
 template <int K, int S, int NC, int MT, int TZ, int TY, int FULL, int HALF, int KWX = 32>
-int launch_dma(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st) {
+int launch_dma(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st, const WDet* det = nullptr) {
   WB p;
   p.B = w.B; p.Cg = w.Cg; p.Cs = w.Cs; p.Do = w.Do; p.Ho = w.Ho; p.Wo = w.Wo;
   p.Di = w.Di; p.Hi = w.Hi; p.Wi = w.Wi; p.pad = w.pad;
@@ -606,8 +658,14 @@ int launch_dma(const float* G, const float* Src, float* dW, const WP& w, hipStre
   p.spw = (int)(spw > (1 << 20) ? (1 << 20) : spw);
   const long long gx = (p.bricks + p.spw - 1) / p.spw;
   if (gx >= (1ll << 31) || nchunks > 65535 || mtiles > 65535) return FS_ERR_SHAPE;
+  constexpr int K3 = K * K * K;
+  float* out;
+  const long long dwf = (long long)p.Cg * p.Cs * K3;
+  const int drc = wrw_det_begin(det, gx, dwf, dW, &out, &p.slab);
+  if (drc >= 0) return drc;
   hipLaunchKernelGGL((conv3d_wrw_dma_kernel<K, S, NC, MT, TZ, TY, FULL, HALF, KWX>), dim3((unsigned)gx, nchunks, mtiles),
-                     dim3(512), 0, st, G, Src, dW, p);
+                     dim3(512), 0, st, G, Src, out, p);
+  wrw_det_end(det, gx, dwf, dW, st);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -632,7 +690,7 @@ extern "C" int fs_debug_wrw_stamps(unsigned long long* out) {
 
 static int conv3d_wrw_impl(const float* g, const float* src, const float* const* srcv, const long long* sbsv, float* dw,
                            int B, int Cg, int Cs, int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride,
-                           int pad, fs_stream_t stream, int* plan = nullptr) {
+                           int pad, fs_stream_t stream, int* plan = nullptr, const WDet* det = nullptr) {
   FS_REQUIRE_PTR(g);
   if (plan == nullptr) FS_REQUIRE_PTR(dw);
   if (srcv == nullptr) FS_REQUIRE_PTR(src);
@@ -672,29 +730,29 @@ static int conv3d_wrw_impl(const float* g, const float* src, const float* const*
                       (long long)64 * Do * Ho * Wo * 4 < (1ll << 31) && (long long)16 * Di * Hi * Wi * 4 < (1ll << 31);
   // per-channel planes: only the loader-wave kernel of IFBlock's conv0[0] (k = 4, <= 32 gradient channels)
   if (srcv != nullptr) {
-    if (dma_ok && kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st));
+    if (dma_ok && kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st, det));
     return FS_ERR_UNSUPPORTED;
   }
   // the 64 -> 64 k3 layers of the 64^3 trunk: the Winograd F(4,3) form (convwrwwino4.hpp), or F(2,3) (convwrwwino.hpp)
-  if (dma_ok && wrw_wino4_ok(p, g, src, kernel, stride)) FS_WRW_PICK(FS_WRW_KERNEL_WINO43, launch_wrw_wino4(g, src, dw, p, st));
+  if (dma_ok && wrw_wino4_ok(p, g, src, kernel, stride)) FS_WRW_PICK(FS_WRW_KERNEL_WINO43, launch_wrw_wino4(g, src, dw, p, st, det));
 #ifdef FS_ABLATION
-  if (dma_ok && wrw_wino_ok(p, g, src, kernel, stride)) FS_WRW_PICK(FS_WRW_KERNEL_WINO23, launch_wrw_wino(g, src, dw, p, st));
+  if (dma_ok && det == nullptr && wrw_wino_ok(p, g, src, kernel, stride)) FS_WRW_PICK(FS_WRW_KERNEL_WINO23, launch_wrw_wino(g, src, dw, p, st));
 #endif
   if (dma_ok) {
-    if (kernel == 3 && Cg > 32 && Cs >= 8 && Wo == 16) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<3, 1, 16, 2, 1, 4, 3, 1, 16>(g, src, dw, p, st));
-    if (kernel == 3 && Cg > 32 && Cs >= 8) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<3, 1, 16, 2, 1, 4, 3, 1>(g, src, dw, p, st));
-    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo == 16) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 8, 2, 1, 2, 4, 0, 16>(g, src, dw, p, st));
-    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 8, 2, 1, 2, 4, 0>(g, src, dw, p, st));
-    if (kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st));
+    if (kernel == 3 && Cg > 32 && Cs >= 8 && Wo == 16) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<3, 1, 16, 2, 1, 4, 3, 1, 16>(g, src, dw, p, st, det));
+    if (kernel == 3 && Cg > 32 && Cs >= 8) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<3, 1, 16, 2, 1, 4, 3, 1>(g, src, dw, p, st, det));
+    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo == 16) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 8, 2, 1, 2, 4, 0, 16>(g, src, dw, p, st, det));
+    if (kernel == 4 && Cg > 32 && Cs >= 4 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 8, 2, 1, 2, 4, 0>(g, src, dw, p, st, det));
+    if (kernel == 4 && Cg <= 32 && Cs >= 3 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 6, 1, 2, 2, 3, 0>(g, src, dw, p, st, det));
     // 1-2 source channels (the mask head: 128 columns, one 32-column tile per matrix wave): bound by the G stream
-    if (kernel == 4 && Cg <= 32 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 2, 1, 2, 2, 1, 0>(g, src, dw, p, st));
+    if (kernel == 4 && Cg <= 32 && Wo >= KW) FS_WRW_PICK(FS_WRW_KERNEL_DMA, launch_dma<4, 2, 2, 1, 2, 2, 1, 0>(g, src, dw, p, st, det));
   }
-  if (kernel == 3) FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<3, 1, 8, 1, 4>(g, src, dw, p, st));
+  if (kernel == 3) FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<3, 1, 8, 1, 4>(g, src, dw, p, st, det));
   // k = 4: 64 columns per source channel.  NC = 4 gives every wave two 32-column tiles, NC = 2 one;
   // pick the chunking with less padded matrix work (Cs = 1, 2, 5, 6: the IFNet heads / block0 input)
   const int cost2 = (Cs + 1) / 2, cost4 = 2 * ((Cs + 3) / 4);
-  if (cost2 < cost4) FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<4, 2, 2, 1, 2>(g, src, dw, p, st));
-  FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<4, 2, 4, 1, 2>(g, src, dw, p, st));
+  if (cost2 < cost4) FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<4, 2, 2, 1, 2>(g, src, dw, p, st, det));
+  FS_WRW_PICK(FS_WRW_KERNEL_BRICK, launch_brick<4, 2, 4, 1, 2>(g, src, dw, p, st, det));
 }
 
 extern "C" int fs_conv3d_wrw_kernel_id(const float* g, const float* src, int B, int Cg, int Cs, int Do, int Ho, int Wo,
@@ -710,6 +768,32 @@ extern "C" int fs_conv3d_wrw(const float* g, const float* src, float* dw, int B,
                              fs_stream_t stream) {
   FS_ENTER();
   return conv3d_wrw_impl(g, src, nullptr, nullptr, dw, B, Cg, Cs, Do, Ho, Wo, Di, Hi, Wi, kernel, stride, pad, stream);
+}
+
+// Deterministic form: the same kernels with a caller-owned workspace instead of float atomics (see WDet above); dw is
+// overwritten (no zero fill needed).  fs_conv3d_wrw_det_ws_floats: the workspace the call needs (its own dispatch, nothing
+// launched), or -(FS_ERR_*).  `src_planes` / `batch_strides` non-NULL: the multi-source form (fs_conv3d_wrw_ms's arguments).
+extern "C" long long fs_conv3d_wrw_det_ws_floats(const float* g, const float* src, const float* const* src_planes,
+                                                 const long long* batch_strides, int B, int Cg, int Cs, int Do, int Ho,
+                                                 int Wo, int Di, int Hi, int Wi, int kernel, int stride, int pad) {
+  long long need = 0;
+  WDet det = {nullptr, 0, &need};
+  float dummy;
+  const int rc = conv3d_wrw_impl(g, src, src_planes, batch_strides, &dummy, B, Cg, Cs, Do, Ho, Wo, Di, Hi, Wi, kernel, stride,
+                                 pad, nullptr, nullptr, &det);
+  return rc == FS_OK ? need : -(long long)rc;
+}
+
+extern "C" int fs_conv3d_wrw_det(const float* g, const float* src, const float* const* src_planes,
+                                 const long long* batch_strides, float* dw, float* ws, long long ws_floats, int B, int Cg,
+                                 int Cs, int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kernel, int stride, int pad,
+                                 fs_stream_t stream) {
+  FS_ENTER();
+  FS_REQUIRE_PTR(ws);
+  if ((src_planes == nullptr) != (batch_strides == nullptr)) return FS_ERR_NULLPTR;
+  WDet det = {ws, ws_floats, nullptr};
+  return conv3d_wrw_impl(g, src, src_planes, batch_strides, dw, B, Cg, Cs, Do, Ho, Wo, Di, Hi, Wi, kernel, stride, pad, stream,
+                         nullptr, &det);
 }
 
 // fs_conv3d_wrw over a source that is never concatenated: channel c of the [B, Cs, Di,Hi,Wi] source is the plane

@@ -40,6 +40,7 @@ struct WWP {
   int by;            // bricks along y (H / 2)
   long long bricks;  // B * D * by * (W / 64)
   int spw;           // bricks per workgroup
+  long long slab;    // deterministic mode: floats per private copy of dW (0: float atomics), see convwrw.hip WDet
 };
 
 // The loader waves (4-7) of the Winograd-domain weight-gradient kernels: per position brick, the RAW gradient rows

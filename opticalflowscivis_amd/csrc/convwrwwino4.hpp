@@ -145,7 +145,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino4_kernel(const float* _
   for (int i = t; i < NDG; i += 256) {
     const int co = i / 288, r2 = i - co * 288;
     const int ci = r2 / 9, k9 = r2 - ci * 9;
-    atomicAdd(dW + ((size_t)co * 64 + c0 + ci) * 27 + kz * 9 + k9, dg[i]);
+    float* q = dW + (size_t)blockIdx.x * p.slab + ((size_t)co * 64 + c0 + ci) * 27 + kz * 9 + k9;
+    if (p.slab) *q = dg[i]; else atomicAdd(q, dg[i]);
   }
 }
 
@@ -154,7 +155,7 @@ inline bool wrw_wino4_ok(const WP& w, const float* g, const float* src, int kern
   return !off && wrw_wino_ok(w, g, src, kernel, stride);  // same shapes, same bricks
 }
 
-inline int launch_wrw_wino4(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st) {
+inline int launch_wrw_wino4(const float* G, const float* Src, float* dW, const WP& w, hipStream_t st, const WDet* det = nullptr) {
   WWP p;
   p.B = w.B; p.D = w.Do; p.H = w.Ho; p.W = w.Wo;
   p.by = w.Ho / WW_TY;
@@ -163,6 +164,12 @@ inline int launch_wrw_wino4(const float* G, const float* Src, float* dW, const W
   long long spw = (p.bricks + slabs - 1) / slabs;
   p.spw = (int)spw;
   const long long gx = (p.bricks + spw - 1) / spw;
+  float* out;
+  const long long dwf = 64ll * 64 * 27;
+  const int drc = wrw_det_begin(det, gx, dwf, dW, &out, &p.slab);
+  if (drc >= 0) return drc;
+  float* const real = dW;
+  dW = out;
 #ifdef FS_ABLATION  // instantiations that SKIP work (wrong results by design): measurement builds only
   static const int dbg = (int)FS_AB_ENV_LL("FLOWSCI_WINO_DBG", 0);
   if (dbg == 1) hipLaunchKernelGGL(conv3d_wrw_wino4_kernel<1>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
@@ -170,6 +177,7 @@ inline int launch_wrw_wino4(const float* G, const float* Src, float* dW, const W
   else
 #endif
     hipLaunchKernelGGL(conv3d_wrw_wino4_kernel<0>, dim3((unsigned)gx, 6, 1), dim3(512), 0, st, G, Src, dW, p);
+  wrw_det_end(det, gx, dwf, real, st);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -1727,6 +1727,26 @@ def _dw_zeros(like, shape):
     return out
 
 
+def _conv3d_wrw_det(g, src_ptr, pv, sv, geo, nbytes, flops, equiv, allow_unsupported=False):
+    """fs_conv3d_wrw_det: the same kernels with every run of positions storing its partial tile into its own copy of dW
+    (a workspace of runs x |dW| floats) and one more launch adding the copies in run order -- no float atomics, bitwise
+    reproducible.  Taken when torch.are_deterministic_algorithms_enabled()."""
+    L = _lib.lib()
+    need = int(L.fs_conv3d_wrw_det_ws_floats(g.data_ptr(), src_ptr, pv, sv, *geo))
+    if need == -FS_ERR_UNSUPPORTED and allow_unsupported:
+        return None
+    if need < 0:
+        _lib.check(-need, "fs_conv3d_wrw_det_ws_floats")
+    B, Cg, Cs = geo[:3]
+    k = geo[9]
+    dw = g.new_empty(Cg, Cs, k, k, k)
+    ws = g.new_empty(max(need, 1))
+    with torch.cuda.device(g.device):
+        _call("fs_conv3d_wrw_det", g.data_ptr(), src_ptr, pv, sv, dw.data_ptr(), ws.data_ptr(), need, *geo, _stream(g),
+              algo_bytes=nbytes, algo_flops=flops, equiv_flops=equiv, record_as="fs_conv3d_wrw")
+    return dw
+
+
 def conv3d_wrw(g, src, k, stride, pad):
     """dW[Cg, Cs, k,k,k] = sum_{b,o} g[b,:,o] (x) src[b,:,o*stride + koff - pad]  (fs_conv3d_wrw)."""
     g = _need_cuda_f32("g", g, 5)
@@ -1735,9 +1755,13 @@ def conv3d_wrw(g, src, k, stride, pad):
     Cs = src.shape[1]
     if src.shape[0] != B:
         raise ValueError("batch mismatch")
-    dw = _dw_zeros(g, (Cg, Cs, k, k, k))
     fq = 2 * g.numel() * Cs * int(k) ** 3
     kid = conv3d_wrw_kernel_id(g.data_ptr(), src.data_ptr(), B, Cg, Cs, g.shape[2:], src.shape[2:], k, stride, pad)
+    geo = (B, Cg, Cs, g.shape[2], g.shape[3], g.shape[4], src.shape[2], src.shape[3], src.shape[4], int(k), int(stride), int(pad))
+    if torch.are_deterministic_algorithms_enabled():
+        return _conv3d_wrw_det(g, src.data_ptr(), None, None, geo, 4 * (g.numel() + src.numel()),
+                               {WRW_KERNEL_WINO43: fq // 2, WRW_KERNEL_WINO23: fq * 2 // 3}.get(kid, fq), fq)
+    dw = _dw_zeros(g, (Cg, Cs, k, k, k))
     with torch.cuda.device(g.device):
         _call("fs_conv3d_wrw", g.data_ptr(), src.data_ptr(), dw.data_ptr(), B, Cg, Cs, g.shape[2],
               g.shape[3], g.shape[4], src.shape[2], src.shape[3], src.shape[4], int(k), int(stride),
@@ -1840,6 +1864,10 @@ def conv3d_wrw_ms(g, pieces, k, stride, pad):
     g = _need_cuda_f32("g", g, 5)
     B, Cg = g.shape[:2]
     Di, Hi, Wi = pieces[0].shape[2:]
+    if torch.are_deterministic_algorithms_enabled():
+        geo = (B, Cg, Cs, g.shape[2], g.shape[3], g.shape[4], Di, Hi, Wi, int(k), int(stride), int(pad))
+        fq = 2 * g.numel() * Cs * int(k) ** 3
+        return _conv3d_wrw_det(g, 0, pv, sv, geo, 4 * (g.numel() + B * Cs * Di * Hi * Wi), fq, fq, allow_unsupported=True)
     dw = _dw_zeros(g, (Cg, Cs, k, k, k))
     with torch.cuda.device(g.device):
         rc = _call_rc("fs_conv3d_wrw_ms", g.data_ptr(), pv, sv, dw.data_ptr(), B, Cg, Cs, g.shape[2], g.shape[3], g.shape[4],
