@@ -552,6 +552,8 @@ struct MoverLane {
 // all compute waves compute addresses together, then gather together.  v2 keeps the queue fed: the movers run NF - 1
 // slices ahead (counted vmcnt waits), and a compute wave issues the gathers of slice k + 1 BEFORE it blends slice k
 // (two register sets), so its gathers fly across the barrier and a whole iteration.
+// the workgroup barrier of the ring kernel: LDS operations of this wave done, barrier, and -- the "memory" clobber -- no LDS
+// or global access of the compiler's moved across it (the bare s_barrier builtin is not a memory barrier to the compiler)
 __device__ __forceinline__ void w3_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct GState {  // gathers in flight for one slice: 4 voxels of a thread.  The RAW pairs: nothing may touch a loaded
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(NT2, 2) void warp3d_fwd_ring_kernel(W3Fwd io, const
     const int pre = min(n, NF - 1);
     for (int k = 0; k < pre; ++k) load_slice(k);
     wait_younger(max(pre - 2, 0));
-    __builtin_amdgcn_s_barrier();
+    w3_lds_barrier();
     for (int s = 0; s < nst; ++s) {
       const int k = s / C, c = s - k * C;
       if (s > 0) store_stage(s - 1);
@@ -629,8 +631,7 @@ __global__ __launch_bounds__(NT2, 2) void warp3d_fwd_ring_kernel(W3Fwd io, const
       }
       // before anyone is released, slice k + 2 (read by the compute waves in the next iteration) has landed
       wait_younger(max(min(issued_to, n - 1) - (k + 2), 0));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      w3_lds_barrier();
     }
     store_stage(nst - 1);
     return;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(NT2, 2) void warp3d_fwd_ring_kernel(W3Fwd io, const
     sO[s & 1][slot] = make_float4(o[0], o[1], o[2], o[3]);
   };
   GState ga, gb;
-  __builtin_amdgcn_s_barrier();  // slices 0 and 1 are in LDS
+  w3_lds_barrier();  // slices 0 and 1 are in LDS
   front(0, ga);
   int s = 0;
   // steady state: both `front`s unconditional -- a conditional issue would make the compiler's vmcnt bookkeeping
