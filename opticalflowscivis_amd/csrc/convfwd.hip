@@ -62,6 +62,9 @@ struct FP {
   int nsrc;
   const float* src[12];
   long long sbs[12];
+#ifdef FS_ABLATION
+  int ab = 0;  // measurement switches of the kernel a launch takes (FLOWSCI_WINO2D_AB)
+#endif
 };
 
 // the weight re-layout Wt[ci][tap][co] (FS_WPREP_FWD) lives in wprep.hpp
@@ -787,7 +790,7 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     if (plan != nullptr) return FS_OK;
     const int rc = launch_wino2d(x, ws, bias, y, p, st);
     if (rc != FS_OK || dp == nullptr) return rc;
-    return dp_finish(64, 1);
+    return dp_finish(64, wino2d_part_rows());
   }
 #ifdef FS_ABLATION
   // ... F(4,3) (convwino4.hpp: half the direct form's multiply-adds) where its 4 x 2 x 64 bricks fill the chip
@@ -999,3 +1002,9 @@ extern "C" int fs_conv3d_fwd_dprelu(const float* x, const float* w, const float*
   return conv3d_fwd_impl(x, w, nullptr, nullptr, 0, nullptr, grad_act_y, nullptr, ws, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo,
                          kernel, stride, pad, kernel == 3 ? 1 : 0, stream, &dp);
 }
+
+#ifdef FS_W2_STAMPS
+extern "C" int fs_debug_w2_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs_w2_dbg), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
+}
+#endif

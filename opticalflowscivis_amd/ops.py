@@ -1659,7 +1659,7 @@ def _fwd_k3_symbol(macs, W):
     """Kernel symbol of a k3 s1 p1 fs_conv3d_fwd* call whose dispatch executes `macs` multiply-adds per (output, input
     channel) -- the names `rocprofv3 --kernel-trace --stats` prints (csrc/convwino2d.hpp::launch_wino2d: 16 x-tiles per
     row on rows of 64 voxels, 8 on rows of 32); None for the direct kernels (several instantiations by shape)."""
-    return "conv3d_wino2d_ws_kernel<0, %d>" % (16 if int(W) % 64 == 0 else 8) if macs == 9.0 else None
+    return "conv3d_wino2d_ps_kernel<0, %d>" % (16 if int(W) % 64 == 0 else 8) if macs == 9.0 else None
 
 
 def _prepared_fwd(w, xptr, B, Cin, Cout, in_dhw, out_dhw, k, stride, pad, wmode):

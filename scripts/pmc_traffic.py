@@ -35,7 +35,7 @@ def kernel_sources_sha256():
 
 RULES = [  # (substring of the kernel name, entry point, counts as a launch of the entry point)
     ("conv3d_fwd_kernel", "fs_conv3d_fwd", True), ("conv3d_fwd_ws_kernel", "fs_conv3d_fwd", True),
-    ("conv3d_wino_ws_kernel", "fs_conv3d_fwd", True), ("conv3d_wino2d_ws_kernel", "fs_conv3d_fwd", True),
+    ("conv3d_wino_ws_kernel", "fs_conv3d_fwd", True), ("conv3d_wino2d_ws_kernel", "fs_conv3d_fwd", True), ("conv3d_wino2d_ps_kernel", "fs_conv3d_fwd", True),
     ("conv3d_wino4_ws_kernel", "fs_conv3d_fwd", True),
     ("wprep_one_kernel", "fs_conv3d_fwd", False), ("wprep_batch_kernel", "fs_conv3d_wprep_batch", True),
     ("conv3d_wrw_", "fs_conv3d_wrw", True),
@@ -47,7 +47,7 @@ RULES = [  # (substring of the kernel name, entry point, counts as a launch of t
     ("distill3_fwd_kernel", "fs_distill_fwd", True), ("distill3_bwd_kernel", "fs_distill_bwd", True),
 ]
 # kernel SYMBOLS bench.py's `roofline` may name (ops.py labels their launches): traffic per launch of the symbol itself
-SYMBOLS = ["conv3d_wino2d_ws_kernel<0, 16>", "conv3d_wino2d_ws_kernel<0, 8>", "conv3d_wrw_wino4_kernel<0>"]
+SYMBOLS = ["conv3d_wino2d_ps_kernel<0, 16>", "conv3d_wino2d_ps_kernel<0, 8>", "conv3d_wrw_wino4_kernel<0>"]
 WARP_BWD_ORDER = ["fs_warp3d_pair_bwd", "fs_warp3d_pair_bwd_acc3", "fs_upsample_warp3d_pair_bwd3",
                   "fs_upsample_warp3d_pair_bwd3"]
 

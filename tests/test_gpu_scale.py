@@ -158,7 +158,7 @@ def test_flow3d_training_drift_at_256_vs_reference_trajectory(golden):
             rec = ops.kernel_timings()
             ops.enable_kernel_timing(False)
             syms = {r[4] for rs in rec.values() for r in rs if r[4]}
-            assert "conv3d_wino2d_ws_kernel<0, 16>" in syms and "conv3d_wrw_wino4_kernel<0>" in syms, syms
+            assert "conv3d_wino2d_ps_kernel<0, 16>" in syms and "conv3d_wrw_wino4_kernel<0>" in syms, syms
         got = [float(info[k].detach()) for k in names]
         drift.append([abs(a - b) / abs(b) for a, b in zip(got, g["update_losses"][step])])
         psnr_d.append(abs(synthetic.psnr(pred.detach(), gt) - float(g["psnr"][step])))

@@ -11,10 +11,11 @@ torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-x = torch.randn(B, 64, D, H, 64, device="cuda")
-w = torch.randn(64, 64, 3, 3, 3, device="cuda") / (64 * 27) ** 0.5
+CIN = int(os.environ.get("WINO_BENCH_CIN", "64"))  # fewer input channels = fewer periods per brick: separates the per-brick fixed cost
+x = torch.randn(B, CIN, D, H, 64, device="cuda")
+w = torch.randn(64, CIN, 3, 3, 3, device="cuda") / (CIN * 27) ** 0.5
 b = torch.randn(64, device="cuda")
-for wmode in (0, 1):
+for wmode in ((0, 1) if CIN == 64 else (0,)):
     for _ in range(3):
         y = ops.conv3d_fwd(x, w, b if wmode == 0 else None, 3, 1, 1, wmode)
     torch.cuda.synchronize()
@@ -27,7 +28,7 @@ for wmode in (0, 1):
     ww = w if wmode == 0 else w.transpose(0, 1).flip(2, 3, 4)
     ref = F.conv3d(x[:1, :, :10].double(), ww.double(), (b.double() if wmode == 0 else None), 1, 1)[:, :, 1:9]
     err = float((y[:1, :, 1:9].double() - ref).abs().max()) / float(ref.abs().max())
-    fl = 2 * y.numel() * 64 * 27
+    fl = 2 * y.numel() * CIN * 27
     print("B=%d %dx%dx64 wmode %d: %.3f ms/launch (incl. the weight re-layout launch) = %.1f TFLOP/s direct-equivalent; max err vs fp64 %.2e "
           "[FLOWSCI_FWD_NO_WINO=%s FLOWSCI_FWD_NO_WINO4=%s FLOWSCI_FWD_NO_WINO2D=%s]" % (B, D, H, wmode, ms, fl / ms / 1e9, err, os.environ.get("FLOWSCI_FWD_NO_WINO", ""),
                                                                  os.environ.get("FLOWSCI_FWD_NO_WINO4", ""), os.environ.get("FLOWSCI_FWD_NO_WINO2D", "")), flush=True)
