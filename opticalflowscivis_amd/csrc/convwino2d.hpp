@@ -420,6 +420,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ps_kernel(const float* _
   }
 
   // ---- matrix waves: wave = (channel tile m, y-component pair typ); MFMA column = (z row col >> 4, x-tile col & 15)
+#ifdef FS_ABLATION
+  if (p.ab & 2) __builtin_amdgcn_s_setprio(3);
+#endif
   const int m = wv >> 1, typ = wv & 1;
   const int col = lane & 31, kh = lane >> 5;
   const int bBo = kh * W2_VCH + (col >> 4) * W2_ZP + 2 * typ * 96 + (col & 15);
@@ -569,12 +572,26 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ps_kernel(const float* _
       W2_ACC(2, w2t);
       __builtin_amdgcn_s_barrier();
       W2_ACC(3, w2t);
+      float4 pvq[4];
+      float c0q[4], c1q[4];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int cl = 8 * ((8 * rnd + i) >> 2) + (i & 3);
         const int co = m * 32 + 4 * kh + cl;
         const unsigned off = co < p.Cout ? loff : DMA_OOB;
-        const float4 pv = ex[((wv ^ 1) * 8 + i) * 64 + lane];
+        // the partner's values and the per-channel values of four channels are read together (one LDS latency per four
+        // channels instead of one per channel)
+        if ((i & 3) == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int ck = m * 32 + 4 * kh + 8 * ((8 * rnd + i + k) >> 2) + ((i + k) & 3);
+            pvq[k] = ex[((wv ^ 1) * 8 + i + k) * 64 + lane];
+            c0q[k] = cvec[(dy != nullptr ? 128 : 0) + ck];
+            c1q[k] = cvec[64 + ck];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 pv = pvq[i & 3];
         const float4 u = xa[i], w = xb[i];
         const float4 v = typ == 0 ? make_float4((u.x + w.x) + pv.x, (u.y + w.y) + pv.y, (u.z + w.z) + pv.z, (u.w + w.w) + pv.w)
                                   : make_float4((pv.x - u.x) - w.x, (pv.y - u.y) - w.y, (pv.z - u.z) - w.z, (pv.w - u.w) - w.w);
@@ -582,7 +599,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ps_kernel(const float* _
         if (dy != nullptr) {
           // fused PReLU backward: g * prelu'(act_y) stored; the sums of the slope and bias gradient terms over the wave's
           // 32 columns (one partial row per brick and y row; masked lanes read act_y = 0 and add 0 to both)
-          const float sl = cvec[128 + co];
+          const float sl = c0q[i & 3];
           const float g4v[4] = {v.x, v.y, v.z, v.w};
           float o4[4], sa = 0.f, sb = 0.f;
 #pragma unroll
@@ -602,10 +619,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ps_kernel(const float* _
           const u32x2 sv = {__float_as_uint(sa), __float_as_uint(sb)};
           __builtin_amdgcn_raw_buffer_store_b64(sv, rP, poff + cl * 8, 0, 0);
         } else {
-          const float bv = cvec[co];
+          const float bv = c0q[i & 3];
           const float4 w4 = make_float4(v.x + bv, v.y + bv, v.z + bv, v.w + bv);
           if (Zp != nullptr) {
-            const float sv = cvec[64 + co];
+            const float sv = c1q[i & 3];
             const u32x4 yo = {__float_as_uint(w4.x), __float_as_uint(w4.y), __float_as_uint(w4.z), __float_as_uint(w4.w)};
             const u32x4 zo = {__float_as_uint((w4.x > 0.f ? w4.x : sv * w4.x) + y4[0]), __float_as_uint((w4.y > 0.f ? w4.y : sv * w4.y) + y4[1]),
                               __float_as_uint((w4.z > 0.f ? w4.z : sv * w4.z) + y4[2]), __float_as_uint((w4.w > 0.f ? w4.w : sv * w4.w) + y4[3])};
