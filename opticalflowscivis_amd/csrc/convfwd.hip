@@ -433,6 +433,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
     for (int j = 0; j < NP; j += 2) {
       if (j + 1 < NP) lds_ops(j + 1, a1, b1);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef FS_ABLATION
+      if (p.ab & 8) continue;  // (measurement: operand reads without the MFMAs -- FLOWSCI_FWD_AB=8)
+#endif
       mma(a0, b0);
       if (j + 2 < NP) lds_ops(j + 2, a0, b0);
       __builtin_amdgcn_sched_barrier(0);
@@ -442,6 +445,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
     buf ^= 1;
   }
 
+#ifdef FS_ABLATION
+  if (p.ab & 4) return;  // (measurement: no epilogue -- FLOWSCI_FWD_AB=4)
+#endif
   if (p.dy != nullptr) {
     // ---- fused PReLU-backward epilogue: g * prelu'(act_y) stored instead of g, per-wave partial sums of the slope
     // gradient (g * act_y where act_y <= 0) and of the stored values (the producing layer's bias gradient).  Same 4 x 4
@@ -554,14 +560,26 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
     const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
     auto swap1 = [](float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, false)); };
     auto swap2 = [](float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, false)); };
+    // the per-channel values of all the lane's channels first: a load inside the store loop cannot be moved above the
+    // previous channel's stores by the compiler
+    float bvs[MT][4], svs[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int co = co0 + m * 32 + qi + 8 * j + 4 * kh;
         const bool cok = co < p.Cout;
-        const float bv = (bias != nullptr && cok) ? bias[co] : 0.f;
-        const float sv = (Zp != nullptr && cok) ? slope[p.nslope == 1 ? 0 : co] : 0.f;
+        bvs[m][j] = (bias != nullptr && cok) ? bias[co] : 0.f;
+        svs[m][j] = (Zp != nullptr && cok) ? slope[p.nslope == 1 ? 0 : co] : 0.f;
+      }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int co = co0 + m * 32 + qi + 8 * j + 4 * kh;
+        const bool cok = co < p.Cout;
+        const float bv = bvs[m][j];
+        const float sv = svs[m][j];
         // the addend (a residual unit's skip tensor / skip gradient) of this channel: its NT 16-byte loads first, in
         // flight together, instead of one load -> wait -> add -> store chain per row
         float4 apre[NT];
@@ -628,6 +646,10 @@ int launch_ws(const float* X, const float* Wt, const float* bias, float* Y, FP& 
   p.tiles = (long long)p.B * p.tz * p.ty * p.tx;
   const int mgroups = p.CoutP / (32 * MT);
   if (p.tiles >= (1ll << 31) || mgroups > 65535) return FS_ERR_SHAPE;
+#ifdef FS_ABLATION
+  static const int fwd_ab = (int)FS_AB_ENV_LL("FLOWSCI_FWD_AB", 0);  // 4: no epilogue, 8: no MFMAs (wrong results by design)
+  p.ab = fwd_ab;
+#endif
   hipLaunchKernelGGL((conv3d_fwd_ws_kernel<K, S, CI, MT, NT, TZ, TY, TW>), dim3((unsigned)p.tiles, mgroups),
                      dim3(512), 0, st, X, Wt, bias, Y, p);
   FS_LAUNCH_CHECK();

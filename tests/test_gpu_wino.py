@@ -139,6 +139,41 @@ def test_superseded_1d_kernels_in_the_ablation_build(env, kind):
     assert ("kind=%d" % kind) in r.stdout and "OK" in r.stdout
 
 
+def test_persistent_trunk_kernel_is_bit_identical_to_the_round3_kernel():
+    """Round 4 rebuilt the 2-D Winograd trunk kernel (persistent workgroups, hand-counted loader waits, packed transforms,
+    register-level Ay^T) with the SAME operations in the same order: every fused form it is launched in -- plain, PReLU,
+    PReLU + residual, input gradient, input gradient + addend, PReLU-backward epilogue; 64^3 and 32^3 bricks -- must give
+    the CRC-32 of the round-3 kernel, which the ablation build keeps (FLOWSCI_WINO2D_R3=1).  Two fresh processes
+    (scripts/wino2d_ab.py); the PReLU-backward form's two gradient VECTORS are sums in another order: 1e-5 relative."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ab = os.path.join(root, "opticalflowscivis_amd", "csrc", "ablation", "libflowsci_hip_ab.so")
+    if not os.path.exists(ab):
+        pytest.skip("ablation build absent (make -C opticalflowscivis_amd/csrc ablation)")
+    script = os.path.join(root, "scripts", "wino2d_ab.py")
+    env0 = {k: v for k, v in os.environ.items() if not k.startswith("FLOWSCI_")}
+    r_new = subprocess.run([sys.executable, script], env=env0, capture_output=True, text=True, timeout=600)
+    r_old = subprocess.run([sys.executable, script], env=dict(env0, FLOWSCI_HIP_LIBRARY=ab, FLOWSCI_WINO2D_R3="1"),
+                           capture_output=True, text=True, timeout=600)
+    assert r_new.returncode == 0 and r_old.returncode == 0, r_new.stderr[-2000:] + r_old.stderr[-2000:]
+
+    def rows(out):
+        d = {}
+        for line in out.splitlines():
+            f = line.split()
+            if len(f) >= 5 and f[0].endswith("^3") and f[3] == "ms":
+                crcs = [x for x in f[4:] if len(x) == 8 and all(c in "0123456789abcdef" for c in x)]
+                vals = [float(f[i + 1]) for i, x in enumerate(f) if x in ("ga", "gb")]
+                d[(f[0], f[1])] = (crcs, vals)
+        return d
+
+    a, b = rows(r_new.stdout), rows(r_old.stdout)
+    assert len(a) == 16 and a.keys() == b.keys(), (sorted(a), sorted(b))
+    for k in a:
+        assert a[k][0] == b[k][0] and len(a[k][0]) >= 1, (k, a[k], b[k])
+        for x, y in zip(a[k][1], b[k][1]):
+            assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), (k, x, y)
+
+
 def test_wino_is_not_taken_where_it_does_not_apply(ops):
     x = torch.randn(2, 64, 64, 64, 16, device=DEV)   # rows of 16
     w = torch.randn(64, 64, 3, 3, 3, device=DEV)
