@@ -256,6 +256,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino2d_ps_kernel(const float* _
     // the same operands as the scalar form: bit-identical results.
     f32x2_t ya[4], yb[4];    // By^T of the chunk in work: columns (d1, d2) and (d3, d4) of the four components ...
     float yl[4], yg[4];      // ... and d0, d5 (lives across the two half-steps)
+// (inline assembly is safe HERE because these results go to LDS: a packed result read by an MFMA needs wait states that only
+// the compiler's hazard pass inserts -- an asm version of the weight-gradient kernel's operand transforms computed wrong
+// sums, and its compiler-generated packed form gained nothing: convwrwwino4.hpp stays scalar)
 #define W2_PK_ADD(d, x, y) asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
 #define W2_PK_SUB(d, x, y) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y))
     auto ytrans = [&](auto SET) {
