@@ -322,6 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(const float* __re
 
   if (wave >= 4) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
+    __builtin_amdgcn_s_setprio(3);  // (a loader wave issues a handful of instructions per period: they should not queue behind the matrix wave's)
     // piece k of loader wave wv fills the 16-byte slots 256 (wv + 4 k) + 4 lane .. + 3 of an image
     const int gz0 = oz0 * S - p.pad, gy0 = oy0 * S - p.pad, gx0 = ox0 * S - XL;
     // x pieces: offset inside their channel and the channel (0 .. CI-1) of the chunk they belong to: a chunk's

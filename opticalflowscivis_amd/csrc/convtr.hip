@@ -423,6 +423,7 @@ template <int TZ, int TY, int CPW>
 __device__ __forceinline__ void tr_loader(const float* __restrict__ X, const float* __restrict__ Wt, const TP& p,
                                           float* lds, int wv, int lane, int b, int qz0, int qy0, int qx0) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
+  __builtin_amdgcn_s_setprio(3);  // (a loader wave issues a handful of instructions per period: they should not queue behind the matrix wave's)
   constexpr int CI = 4;
   constexpr int ZT = TZ + 2, YT = TY + 2, XP = 40;
   constexpr int PS = YT * XP, CHS = ZT * PS;
@@ -731,6 +732,7 @@ __global__ __launch_bounds__(512, 2) void convtr_p8_kernel(const float* __restri
 
   if (wave >= 4) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
+    __builtin_amdgcn_s_setprio(3);  // (a loader wave issues a handful of instructions per period: they should not queue behind the matrix wave's)
     constexpr int NXW = (NXL / 256 + 3) / 4, NWW = (NWL / 256 + 3) / 4;
     {  // the whole weight table (the layer's (Cin + 3) / 4 * 4 channels: the workspace holds no more), once
       __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, (short)0, (p.Cin + 3) / 4 * 4 * WSCI * 4,

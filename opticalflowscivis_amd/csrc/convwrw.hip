@@ -423,6 +423,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wrw_dma_kernel(const float* __r
 
   if (loader) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has neither the buffer-resource type nor the LDS-DMA builtin)
+    __builtin_amdgcn_s_setprio(3);  // (a loader wave issues a handful of instructions per period: they should not queue behind the matrix wave's)
     // ---- brick-invariant part of the staging.  Piece k of loader wave wv fills the 16-byte slots
     // 256 (wv + 4 k) + 4 lane .. + 3 of an image.
     // source image: byte offset from the brick origin and border class (bit 0/1: low / high z halo, 2/3: y,

@@ -50,6 +50,7 @@ template <int DBG>
 __device__ __forceinline__ void ww_loader_waves(const float* __restrict__ G, const float* __restrict__ Src, const WWP& p,
                                                 float* lds, int wv, int lane, int kz, int c0, long long s0, long long s1) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setprio(3);  // (a loader wave issues a handful of instructions per period: they should not queue behind the matrix wave's)
   constexpr int NGP = (WW_NG / 4 + 63) / 64, NSP = (WW_NS / 4 + 63) / 64;  // 16-byte pieces in wave-instructions
   constexpr int NGW = (NGP + 3) / 4, NSW = (NSP + 3) / 4;
   const size_t vol = (size_t)p.D * p.H * p.W;
