@@ -48,6 +48,9 @@ struct TP {
   // 32-channel slices of a wider output in ONE launch of the 32-row kernels (blockIdx.y = slice): floats between the
   // slices' re-laid-out weights; the output-side pointers move by 32 channels per slice
   long long wslice;
+#ifdef FS_ABLATION
+  int ab = 0;  // measurement switches (FLOWSCI_TR_AB: 4 = the loader-wave kernels skip their epilogue -- wrong results by design)
+#endif
 };
 
 // blockIdx.y-th 32-channel slice of a launch that covers several (block0's 128 -> 64 deconvolution: two half-empty
@@ -556,19 +559,24 @@ __global__ __launch_bounds__(512, 2) void convtr_mfma_ws_kernel(const float* __r
     buf ^= 1;
   }
 
+#ifdef FS_ABLATION
+  if (p.ab & 4) return;
+#endif
   const int qz = qz0 + wz, qy = qy0 + wy, qx = qx0 + col;
-  if (qz < p.Dq && qy < p.Hq && qx < p.Wq) {
+  if (qz < p.Dq && qy < p.Hq) {  // wave-uniform: every lane takes part in the lane exchange of store8_quad
     const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (co >= p.Cout) continue;
-      const float bv = bias ? bias[co] : 0.f;
+      const bool ok = co < p.Cout;
+      const int cc = ok ? co : 0;
+      const float bv = (bias && ok) ? bias[cc] : 0.f;
       float v[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = acc[c][r] + bv;
-      store8(Y + ((size_t)b * p.CoutT + co) * yvol, v, qz, qy, qx, p,
-             p.Z ? p.Z + ((size_t)b * p.CoutT + co) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : co] : 0.f);
+      // 16-byte stores (neighbouring positions swap a pair): the epilogue is store-issue-bound, 12-16 % of a launch
+      store8_quad(Y + ((size_t)b * p.CoutT + cc) * yvol, v, qz, qy, qx, ok, p,
+                  p.Z ? p.Z + ((size_t)b * p.CoutT + cc) * yvol : nullptr, p.Z ? p.slope[p.nslope == 1 ? 0 : cc] : 0.f);
     }
   }
 }
@@ -650,6 +658,9 @@ __global__ __launch_bounds__(512, 2) void convtr_mfma16_ws_kernel(const float* _
     buf ^= 1;
   }
 
+#ifdef FS_ABLATION
+  if (p.ab & 4) return;
+#endif
   const int qz = qz0 + wz, qy = qy0 + wy;
   if (qz < p.Dq && qy < p.Hq) {  // wave-uniform: every lane takes part in the lane exchange of store8_quad
     const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
@@ -1135,6 +1146,10 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   p.tz = fs::cdiv(p.Dq, 2); p.ty = fs::cdiv(p.Hq, 2); p.tx = fs::cdiv(p.Wq, 32);
   p.tiles = (long long)B * p.tz * p.ty * p.tx;
   if (p.tiles >= (1ll << 31)) return FS_ERR_SHAPE;
+#ifdef FS_ABLATION
+  static const int tr_ab = (int)FS_AB_ENV_LL("FLOWSCI_TR_AB", 0);
+  p.ab = tr_ab;
+#endif
   // loader-wave kernels: 16-byte pieces (Wi % 4 == 0, 16-byte aligned input and workspace), 31-bit byte offsets
   // inside a staged 4-channel chunk.  They also win when the launch cannot fill the chip (block0's 128 -> 64
   // deconvolution at 16^3: 128 bricks per 32-channel slice, 0.42 -> 0.29 ms): one 8-wave workgroup per CU overlaps
