@@ -25,9 +25,21 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino4_kernel(const float* _
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wv = wave & 3;
-  const int kz = blockIdx.y % 3, chalf = blockIdx.y / 3;  // column group: kz, source-channel half
+  // (run of bricks, column group) of this workgroup.  The six column groups of a run read the SAME gradient / source bricks;
+  // dispatched as (blockIdx.x, blockIdx.y) they landed on four XCDs (linear id % 8) and each XCD's L2 fetched the bricks
+  // for itself: 3.4x the algorithmic bytes from HBM (profiles/r04_pmc_traffic.json).  So the linear id is re-read as
+  // (XCD, slot) and an XCD takes a contiguous range of (run, group) tasks: the groups of a run share one L2.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int total = gridDim.x * 6, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int c = lin & 7, j = lin >> 3;
+    const int q8 = total >> 3, r8 = total & 7;                 // XCD c holds q8 + (c < r8) workgroups
+    const int task = c * q8 + (c < r8 ? c : r8) + j;           // its tasks: a contiguous range, group-major inside a run
+    bx = task / 6; by = task - bx * 6;
+  }
+  const int kz = by % 3, chalf = by / 3;  // column group: kz, source-channel half
   const int c0 = chalf * 32;
-  const long long s0 = (long long)blockIdx.x * p.spw;
+  const long long s0 = (long long)bx * p.spw;
   const long long s1 = min(s0 + (long long)p.spw, p.bricks);
 
   if (wave >= 4) {
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wrw_wino4_kernel(const float* _
   for (int i = t; i < NDG; i += 256) {
     const int co = i / 288, r2 = i - co * 288;
     const int ci = r2 / 9, k9 = r2 - ci * 9;
-    float* q = dW + (size_t)blockIdx.x * p.slab + ((size_t)co * 64 + c0 + ci) * 27 + kz * 9 + k9;
+    float* q = dW + (size_t)bx * p.slab + ((size_t)co * 64 + c0 + ci) * 27 + kz * 9 + k9;
     if (p.slab) *q = dg[i]; else atomicAdd(q, dg[i]);
   }
 }
