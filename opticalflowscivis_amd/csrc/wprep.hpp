@@ -121,13 +121,59 @@ __device__ __forceinline__ float wprep_elem(const FsWprepJob& j, int e) {
   }
 }
 
+// FS_WPREP_WINO2D by blocks (round 4): wprep_elem gathers an element's nine taps with lanes = output channels, i.e. nine
+// loads whose 64 lanes touch 64 different cache lines each (the step's 32 such slabs were most of a 0.28 ms launch).  Here
+// a block takes one (input channel, kz): the 64 x 9 taps are read with lanes running along the taps of a channel (a few
+// lines per load), parked in LDS, and every thread forms six of the block's 24 x 64 slab entries from there -- the
+// same arithmetic as wprep_elem (bit-identical slabs), coalesced stores.
+__device__ __forceinline__ void wprep_wino2d_blocks(const FsWprepJob& j, int first, int stride) {
+  __shared__ float g9[64 * 9 + 64];  // [co][ky*3+kx], pitch 10 (bank spread)
+  const int Cout = j.p[0], Cin = j.p[1], CinP = j.p[2], mode = j.p[3];
+  const float* __restrict__ w = j.w;
+  const int t = threadIdx.x;
+  for (int blk = first; blk < CinP * 3; blk += stride) {
+    const int ci = blk / 3, kz = blk - ci * 3;
+    __syncthreads();
+    for (int i = t; i < 64 * 9; i += 256) {
+      const int co = i / 9, k9 = i - co * 9;
+      const int tap = kz * 9 + k9;
+      float v = 0.f;
+      if (co < Cout && ci < Cin) v = mode ? w[((size_t)ci * Cout + co) * 27 + (26 - tap)] : w[((size_t)co * Cin + ci) * 27 + tap];
+      g9[co * 10 + k9] = v;
+    }
+    __syncthreads();
+    const int co = t & 63, q = t >> 6;
+    float* __restrict__ dst = j.ws + (size_t)ci * FS_WINO2D_UCH + kz * 1536 + co;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {      // slab entries (ty, tx) = 6 q + k of the block's 24
+      const int e = 6 * q + k, ty = e / 6, tx = e - ty * 6;
+      float u[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float g[3] = {g9[co * 10 + ky * 3], g9[co * 10 + ky * 3 + 1], g9[co * 10 + ky * 3 + 2]};
+        u[ky] = wprep_g43(g, tx);
+      }
+      const float v = ty == 0 ? u[0] : ty == 1 ? 0.5f * ((u[0] + u[1]) + u[2]) : ty == 2 ? 0.5f * ((u[0] - u[1]) + u[2]) : u[2];
+      dst[ty * 384 + tx * 64] = (co < Cout && ci < Cin) ? v : 0.f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wprep_one_kernel(FsWprepJob j) {
+  if (j.kind == FS_WPREP_WINO2D && j.total == j.p[2] * FS_WINO2D_UCH) {
+    wprep_wino2d_blocks(j, blockIdx.x, gridDim.x);
+    return;
+  }
   for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256) j.ws[e] = wprep_elem(j, e);
 }
 
 // blockIdx.y = job, blockIdx.x strides over its elements
 __global__ __launch_bounds__(256) void wprep_batch_kernel(const FsWprepJob* __restrict__ jobs) {
   const FsWprepJob j = jobs[blockIdx.y];
+  if (j.kind == FS_WPREP_WINO2D && j.total == j.p[2] * FS_WINO2D_UCH) {
+    wprep_wino2d_blocks(j, blockIdx.x, gridDim.x);
+    return;
+  }
   for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256) j.ws[e] = wprep_elem(j, e);
 }
 
