@@ -60,7 +60,11 @@ def _is_wino(ops, x, w, cin, cout, size, wmode):
                                              # the 2-D form's 2 x 2 x 64 bricks: ragged in z and y, few channels, two x bricks
                                              (2, 64, 64, (63, 33, 64)), (2, 12, 24, (64, 32, 64)), (2, 64, 64, (66, 34, 64)),
                                              # rows of 32 (2 x 4 x 32 bricks): whole, ragged, three x bricks
-                                             (2, 64, 64, (32, 32, 32)), (2, 64, 48, (31, 30, 32)), (2, 16, 64, (32, 18, 96))])
+                                             (2, 64, 64, (32, 32, 32)), (2, 64, 48, (31, 30, 32)), (2, 16, 64, (32, 18, 96)),
+                                             # persistent workgroups (round 4): runs of 4 and 12 bricks in the patch order (one / three
+                                             # z-steps per XCD), a run of 5 in the linear order, more bricks than an even split
+                                             (1, 16, 64, (64, 64, 64)), (3, 8, 64, (64, 64, 64)), (2, 8, 64, (40, 64, 64)),
+                                             (1, 8, 64, (38, 66, 64))])
 def test_wino_forward_epilogues_vs_fp64(ops, B, cin, cout, size):
     g = torch.Generator().manual_seed(cin * 100 + size[0])
     x = torch.randn((B, cin) + size, generator=g)
