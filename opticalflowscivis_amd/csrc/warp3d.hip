@@ -849,6 +849,8 @@ __global__ __launch_bounds__(NT) void warp3d_bwd_kernel(W3Bwd io, const float* _
   }
 }
 
+#include "warp3d_rc.hpp"
+
 int make_params(W3P& p, int B, int C, const int* in_dhw, int D, int H, int W) {
   const int Di = in_dhw ? in_dhw[0] : D, Hi = in_dhw ? in_dhw[1] : H, Wi = in_dhw ? in_dhw[2] : W;
   if (B < 1 || C < 1 || D < 2 || H < 2 || W < 2 || Di < 2 || Hi < 2 || Wi < 2) return FS_ERR_SHAPE;
@@ -897,6 +899,22 @@ int launch_fwd(const W3Fwd& io, int npair, const float* flow, const UpP* up, W3P
     else hipLaunchKernelGGL((warp3d_fwd_kernel<512, false, true>), g, dim3(512), 0, st, io, flow, *up, p);
   } else {
     const bool vec = vec_ok(p, flow, io.out[0], io.out[1], nullptr);
+    // round 5: ring pipeline with the gather source in an LDS row cache (warp3d_rc.hpp) wherever its window fits the volume
+    static const int rc_mode = (int)FS_AB_ENV_LL("FLOWSCI_W3_RC", 1);  // ablation build: 0 = round-4 kernels, 11.. = DBG forms
+    if (vec && rc_mode != 0 && rc::applicable(p, io.in[0], io.in[1])) {
+      p.dc = (int)FS_AB_ENV_LL("FLOWSCI_W3_RC_DC", rc::pick_dc(p, npair));
+      p.nDC = fs::cdiv(p.D, p.dc);
+      const dim3 gc((unsigned)((long long)p.B * p.nDC * p.tilesH * p.tilesW), npair);
+      const dim3 bc(64 * (NCW + 2));
+#ifdef FS_ABLATION
+      if (rc_mode == 11) { hipLaunchKernelGGL((rc::warp3d_rc_kernel<false, 2, 6, 1>), gc, bc, 0, st, io, W3Bwd{}, flow, nullptr, W3Add{}, p); FS_LAUNCH_CHECK(); return FS_OK; }
+      if (rc_mode == 12) { hipLaunchKernelGGL((rc::warp3d_rc_kernel<false, 2, 6, 2>), gc, bc, 0, st, io, W3Bwd{}, flow, nullptr, W3Add{}, p); FS_LAUNCH_CHECK(); return FS_OK; }
+      if (rc_mode == 13) { hipLaunchKernelGGL((rc::warp3d_rc_kernel<false, 2, 6, 3>), gc, bc, 0, st, io, W3Bwd{}, flow, nullptr, W3Add{}, p); FS_LAUNCH_CHECK(); return FS_OK; }
+#endif
+      hipLaunchKernelGGL((rc::warp3d_rc_kernel<false, 2, 6>), gc, bc, 0, st, io, W3Bwd{}, flow, nullptr, W3Add{}, p);
+      FS_LAUNCH_CHECK();
+      return FS_OK;
+    }
     // the ring kernel walks 16 slices per workgroup (one workgroup per CU; 2 048 workgroups at 2 x 256^3)
     p.dc = (int)FS_AB_ENV_LL("FLOWSCI_W3_RING_DC", 16);
     p.nDC = fs::cdiv(p.D, p.dc);
@@ -935,6 +953,21 @@ int launch_bwd(const W3Bwd& io, int npair, bool with_gin, const float* flow, flo
   hipStream_t st = (hipStream_t)stream;
   const bool vec = vec_ok(p, flow, gflow, io.gout[0], io.gout[1]) && vec_ok(p, gadd.a[0], gadd.a[1], gadd.a[2], nullptr) &&
                    gadd.bs[0] % 4 == 0 && gadd.bs[1] % 4 == 0 && gadd.bs[2] % 4 == 0 && io.gbs[0] % 4 == 0 && io.gbs[1] % 4 == 0;
+  static const int rc_mode = (int)FS_AB_ENV_LL("FLOWSCI_W3_RC", 1);
+  if (vec && rc_mode != 0 && !with_gin && gflow != nullptr && rc::applicable(p, io.in[0], io.in[1])) {
+    p.dc = (int)FS_AB_ENV_LL("FLOWSCI_W3_RC_DC", rc::pick_dc(p, npair));
+    p.nDC = fs::cdiv(p.D, p.dc);
+    const dim3 gc((unsigned)((long long)p.B * p.nDC * p.tilesH * p.tilesW), npair);
+    const dim3 bc(64 * (NCW + 4));
+#ifdef FS_ABLATION
+    if (rc_mode == 11) { hipLaunchKernelGGL((rc::warp3d_rc_kernel<true, 4, 5, 1>), gc, bc, 0, st, W3Fwd{}, io, flow, gflow, gadd, p); FS_LAUNCH_CHECK(); return FS_OK; }
+    if (rc_mode == 12) { hipLaunchKernelGGL((rc::warp3d_rc_kernel<true, 4, 5, 2>), gc, bc, 0, st, W3Fwd{}, io, flow, gflow, gadd, p); FS_LAUNCH_CHECK(); return FS_OK; }
+    if (rc_mode == 13) { hipLaunchKernelGGL((rc::warp3d_rc_kernel<true, 4, 5, 3>), gc, bc, 0, st, W3Fwd{}, io, flow, gflow, gadd, p); FS_LAUNCH_CHECK(); return FS_OK; }
+#endif
+    hipLaunchKernelGGL((rc::warp3d_rc_kernel<true, 4, 5>), gc, bc, 0, st, W3Fwd{}, io, flow, gflow, gadd, p);
+    FS_LAUNCH_CHECK();
+    return FS_OK;
+  }
   const dim3 g(grid, npair);
   if (vec) launch_bwd_t<256, true>(io, g, with_gin, flow, gflow, gadd, p, st);
   else launch_bwd_t<256, false>(io, g, with_gin, flow, gflow, gadd, p, st);

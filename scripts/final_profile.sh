@@ -43,6 +43,7 @@ python scripts/c3_kernels.py 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" > $O/c2_
 # the Winograd-domain trunk kernels against the direct ones, and the weight gradient's ablation builds: these switches
 # exist only in the measurement build of the library (make ablation), loaded through FLOWSCI_HIP_LIBRARY
 AB=$PWD/opticalflowscivis_amd/csrc/ablation/libflowsci_hip_ab.so
+make -C opticalflowscivis_amd/csrc ablation -j16 > $O/make_ablation.log 2>&1 || tail -5 $O/make_ablation.log  # (not part of build(); does not travel)
 if [ -f "$AB" ]; then
 export FLOWSCI_HIP_LIBRARY=$AB
 { python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO2D=1 python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO4=1 python tests/tools/wino_bench.py; FLOWSCI_FWD_NO_WINO=1 python tests/tools/wino_bench.py;

@@ -33,3 +33,20 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(scope="session")
+def ablation_lib():
+    """Path of the measurement build of the library (`make ablation`: superseded kernels + FLOWSCI_* switches), built on
+    first use -- it is not part of `build()` and does not travel to the GPU box.  Skips when hipcc is absent."""
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "opticalflowscivis_amd", "csrc")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("ablation build needs hipcc (make -C opticalflowscivis_amd/csrc ablation)")
+    r = subprocess.run(["make", "-C", csrc, "ablation", "-j", str(min(16, os.cpu_count() or 1))], capture_output=True,
+                       text=True, timeout=1200)
+    if r.returncode != 0:
+        pytest.fail("make ablation failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+    return os.path.join(csrc, "ablation", "libflowsci_hip_ab.so")

@@ -433,3 +433,80 @@ def test_warp2d_plane_owner_grad_in_sweep(ops):
             assert maxerr(out, ref) < OUT_ATOL
         assert frac_bad(gx, gxr, GRAD_ATOL) == 0.0, (B, C, H, W)
         assert frac_bad(gf, gfr, GRAD_ATOL) < 1e-4
+
+
+def _rc_flows(B, D, H, W, g):
+    """Flows that drive the row-cache kernels (csrc/warp3d_rc.hpp) through every path: inside the predicted window
+    (smooth, small), a constant shift (window origin far from the tile), white noise (every voxel on the global-gather
+    path), a jump along d (the row ring restarts), a ramp along d steeper than one row per slice, poisoned entries."""
+    ax = lambda n: torch.linspace(0, 6.28318, n)
+    d, h, w = ax(D).view(D, 1, 1), ax(H).view(1, H, 1), ax(W).view(1, 1, W)
+    smooth = torch.stack([1.5 * torch.sin(d) * torch.cos(h) + 0 * w, 1.2 * torch.cos(2 * w) + 0 * d + 0 * h,
+                          0.8 * torch.sin(h) * torch.sin(w) + 0 * d], 0).expand(B, 3, D, H, W).contiguous()
+    shift = torch.empty(B, 3, D, H, W)
+    shift[:, 0], shift[:, 1], shift[:, 2] = 9.25, -6.5, 11.75
+    noise = (torch.rand(B, 3, D, H, W, generator=g) * 2 - 1) * 3.0
+    jump = smooth.clone()
+    jump[:, 1, D // 2:] += 7.0
+    ramp = smooth.clone()
+    ramp[:, 1] += 2.5 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)
+    wild = smooth.clone()
+    flat = wild.view(-1)
+    idx = torch.randperm(flat.numel(), generator=g)[:48]
+    flat[idx] = torch.tensor([float("nan"), float("inf"), -float("inf"), 1e30, -1e30, 3e9]).repeat(8)
+    return {"smooth": smooth, "shift": shift, "noise": noise, "jump": jump, "ramp": ramp, "wild": wild}
+
+
+@pytest.mark.parametrize("shape,mixed", [((1, 40, 70, 72), False), ((2, 37, 64, 96), False), ((1, 45, 130, 76), True),
+                                         ((1, 3, 64, 72), False)])
+def test_warp3d_row_cache_kernels_vs_oracle_and_gather_kernels(ops, shape, mixed):
+    """Round 5: at C = 1 on volumes that hold the window (W_in >= 72, D_in >= 37, W_in % 4 == 0) forward and flow-gradient
+    backward of the trilinear warp run as the ring pipeline with the gather source in an LDS row cache.  Against the oracle
+    for every flow kind, and bit for bit against the gather kernels, which the same entry points still take at C = 2
+    (forward: a duplicated channel) and when grad_in is asked for (backward)."""
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + D * 10 + H)
+    ishape = (B, 1, D + 3, H + 1, W + 4) if mixed else (B, 1, D, H, W)
+    x = torch.rand(ishape, generator=g)
+    G = torch.randn(B, 1, D, H, W, generator=g)
+    for kind, f in _rc_flows(B, D, H, W, g).items():
+        xd, fd = x.to(DEV), f.to(DEV).requires_grad_()
+        out = ops.warp3d(xd, fd)
+        (gf,) = torch.autograd.grad((out * G.to(DEV)).sum(), [fd])
+        # the gather kernels on the same operands
+        out2 = ops.warp3d(torch.cat((xd, xd), 1), fd.detach())
+        xg, fg = xd.clone().requires_grad_(), f.to(DEV).requires_grad_()
+        _, gf2 = torch.autograd.grad((ops.warp3d(xg, fg) * G.to(DEV)).sum(), [xg, fg])
+        if kind == "wild":
+            ok = torch.isfinite(f).all(dim=1, keepdim=True).to(DEV)
+            assert torch.equal(out[ok], out2[:, :1][ok]), (kind, shape)
+            assert torch.equal(gf.nan_to_num()[ok.expand_as(gf)], gf2.nan_to_num()[ok.expand_as(gf)]), (kind, shape)
+            continue
+        assert torch.equal(out, out2[:, :1]) and torch.equal(out, out2[:, 1:]), (kind, shape)
+        assert torch.equal(gf, gf2), (kind, shape)
+        fr = f.clone().requires_grad_()
+        ref = owarps.warp3d_ref(x, fr)
+        (gfr,) = torch.autograd.grad((ref * G).sum(), [fr])
+        assert maxerr(out, ref) < OUT_ATOL, (kind, shape)
+        assert frac_bad(gf, gfr, GRAD_ATOL) < 2e-4, (kind, shape)
+
+
+def test_warp_pair_acc_row_cache_kernel_adds_three_strided_gradients(ops):
+    """The three-addend backward (fs_warp3d_pair_bwd_acc3: the dominant hot-path launch of the 256^3 step) on the row-cache
+    kernel: addends arrive as dense tensors and as a channel slice of a wider one; equals warp gradient + addends."""
+    g = torch.Generator().manual_seed(77)
+    B, D, H, W = 2, 38, 66, 80
+    i0, i1 = torch.rand(B, 1, D, H, W, generator=g).to(DEV), torch.rand(B, 1, D, H, W, generator=g).to(DEV)
+    f = _rc_flows(B, D, H, W, g)["smooth"]
+    f6 = torch.cat((f, -0.5 * f), 1).to(DEV).requires_grad_()
+    G0, G1 = torch.randn(B, 1, D, H, W, generator=g).to(DEV), torch.randn(B, 1, D, H, W, generator=g).to(DEV)
+    wide = torch.randn(B, 11, D, H, W, generator=g).to(DEV)
+    A = [torch.randn(B, 6, D, H, W, generator=g).to(DEV), wide[:, 5:11], torch.randn(B, 6, D, H, W, generator=g).to(DEV)]
+    w0, w1, (fa, fb, fc) = ops.warp_pair_acc(i0, i1, f6)
+    (gt,) = torch.autograd.grad([w0, w1, fa, fb, fc], [f6], [G0, G1] + A)
+    f6b = f6.detach().clone().requires_grad_()
+    o0, o1 = ops.warp_pair(i0, i1, f6b)
+    (gw,) = torch.autograd.grad([o0, o1], [f6b], [G0, G1])
+    assert torch.equal(w0, o0) and torch.equal(w1, o1)
+    exp = ((gw + A[0]) + A[1]) + A[2]  # (the kernel adds in the order autograd delivers the three gradients)
+    assert float((gt - exp).abs().max()) < 1e-5 * max(1.0, float(exp.abs().max()))

@@ -125,14 +125,12 @@ def test_wino_input_gradient_and_prelu_backward_vs_fp64(ops, B, cg, cx, size):
 
 
 @pytest.mark.parametrize("env,kind", [({"FLOWSCI_FWD_NO_WINO2D": "1"}, 5), ({"FLOWSCI_FWD_NO_WINO4": "1"}, 4)])
-def test_superseded_1d_kernels_in_the_ablation_build(env, kind):
+def test_superseded_1d_kernels_in_the_ablation_build(env, kind, ablation_lib):
     """The product library holds ONE kernel per job and reads no environment variable; the 1-D forms it superseded --
     F(4,3) (kind 5) and F(2,3) (kind 4) along x only -- live in the ablation build (`make ablation`), whose dispatch
     switches are read once per process: same checks there, in a fresh process."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    ab = os.path.join(root, "opticalflowscivis_amd", "csrc", "ablation", "libflowsci_hip_ab.so")
-    if not os.path.exists(ab):
-        pytest.skip("ablation build absent (make -C opticalflowscivis_amd/csrc ablation)")
+    ab = ablation_lib
     # the product library itself must not react to the switch: same slab kind (6) with it set
     r0 = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "wino_check.py"), "6"],
                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
@@ -143,16 +141,14 @@ def test_superseded_1d_kernels_in_the_ablation_build(env, kind):
     assert ("kind=%d" % kind) in r.stdout and "OK" in r.stdout
 
 
-def test_persistent_trunk_kernel_is_bit_identical_to_the_round3_kernel():
+def test_persistent_trunk_kernel_is_bit_identical_to_the_round3_kernel(ablation_lib):
     """Round 4 rebuilt the 2-D Winograd trunk kernel (persistent workgroups, hand-counted loader waits, packed transforms,
     register-level Ay^T) with the SAME operations in the same order: every fused form it is launched in -- plain, PReLU,
     PReLU + residual, input gradient, input gradient + addend, PReLU-backward epilogue; 64^3 and 32^3 bricks -- must give
     the CRC-32 of the round-3 kernel, which the ablation build keeps (FLOWSCI_WINO2D_R3=1).  Two fresh processes
     (scripts/wino2d_ab.py); the PReLU-backward form's two gradient VECTORS are sums in another order: 1e-5 relative."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    ab = os.path.join(root, "opticalflowscivis_amd", "csrc", "ablation", "libflowsci_hip_ab.so")
-    if not os.path.exists(ab):
-        pytest.skip("ablation build absent (make -C opticalflowscivis_amd/csrc ablation)")
+    ab = ablation_lib
     script = os.path.join(root, "scripts", "wino2d_ab.py")
     env0 = {k: v for k, v in os.environ.items() if not k.startswith("FLOWSCI_")}
     r_new = subprocess.run([sys.executable, script], env=env0, capture_output=True, text=True, timeout=600)
