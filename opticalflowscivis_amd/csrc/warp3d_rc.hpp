@@ -84,15 +84,19 @@ __device__ __forceinline__ int corner_of(float lin, float f, float r, float m) {
   return (int)(unsigned)floorf(i);
 }
 
+// wave-wide min / max as a wave-uniform value: four rotations inside every row of 16 lanes (DPP row_ror 8, 4, 2, 1), then
+// the four rows through v_readlane (scalar result; no LDS traffic, unlike ds_bpermute shuffles)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
+  v = min(v, dpp_i<0x128>(v)); v = min(v, dpp_i<0x124>(v)); v = min(v, dpp_i<0x122>(v)); v = min(v, dpp_i<0x121>(v));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-  return v;
+  v = max(v, dpp_i<0x128>(v)); v = max(v, dpp_i<0x124>(v)); v = max(v, dpp_i<0x122>(v)); v = max(v, dpp_i<0x121>(v));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the number of this wave's vector-memory instructions that may stay
@@ -218,13 +222,12 @@ __global__ __launch_bounds__(64 * (NCW + NMW_)) void warp3d_rc_kernel(W3Fwd fio,
     float* gfb = nullptr;
     float* outb = nullptr;
     const float* gab[3] = {nullptr, nullptr, nullptr};
-    int na = 0;
     if constexpr (BWD) {
       gob = bio.gout[blockIdx.y] + (size_t)b * (bio.gbs[blockIdx.y] ? (size_t)bio.gbs[blockIdx.y] : vol);
       gfb = gflow + ((size_t)b * p.flowC + 3 * blockIdx.y) * vol;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        if (gadd.a[i] != nullptr) { gab[i] = gadd.a[i] + (size_t)b * gadd.bs[i] + (size_t)(3 * blockIdx.y) * vol; ++na; }
+        if (gadd.a[i] != nullptr) { gab[i] = gadd.a[i] + (size_t)b * gadd.bs[i] + (size_t)(3 * blockIdx.y) * vol; }
     } else {
       outb = fio.out[blockIdx.y] + (size_t)b * vol;
     }
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(64 * (NCW + NMW_)) void warp3d_rc_kernel(W3Fwd fio,
       roff[jj] = (s < NP * NQ) ? (unsigned)pl * p.planeB + (unsigned)q * 16u : 0u;  // pad slots re-read slot 0 (never used)
     }
     const float* cbase = vin + ((size_t)zb * p.Hi * p.Wi + xb);
+    (void)cbase;
     auto load_row = [&](int y, int slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
       if (DBG == 3) return;
@@ -431,9 +435,16 @@ __global__ __launch_bounds__(64 * (NCW + NMW_)) void warp3d_rc_kernel(W3Fwd fio,
     const int lo = mail.lo[k & 1], nv = mail.nv[k & 1], sl = mail.sl[k & 1];
     int ymin = 0x7fffffff, ymax = 0;
     float o0[4], o1[4], o2[4];
+    // pass 1: sample positions, window test, all corner reads of the four voxels issued (cache reads unconditionally --
+    // a voxel outside the window reads slot 0 and is overwritten by pass 1b); pass 1b: global gathers of the voxels
+    // outside the window, all issued before any is used; pass 2: blend.  One wait per slice instead of one per voxel.
+    SampI<BWD> sv[4];
+    Pair r00[4], r01[4], r10[4], r11[4];  // (z, y) corner pairs along x
+    bool hitv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const SampI<BWD> s = sample_i<BWD>(p, lin_h, lin_d, lin_w[i], fa[i], fbv[i], fc[i]);
+      sv[i] = s;
       ymin = min(ymin, s.y0); ymax = max(ymax, s.y0);
       // the pair (x0, x0 + 1) starts one column lower on the far border (ld_pair's rule: the +1 weight is exactly 0)
       const int rxs = s.x0 - xb - (s.px ? 0 : 1), rz = s.z0 - zb, ry = s.y0 - lo;
@@ -441,29 +452,37 @@ __global__ __launch_bounds__(64 * (NCW + NMW_)) void warp3d_rc_kernel(W3Fwd fio,
                  (unsigned)ry < (unsigned)max(nv - (s.py ? 1 : 0), 0);
       if (DBG == 1) hit = false;
       if (DBG == 2 || DBG == 3) hit = true;
-      Pair r00, r01, r10, r11;  // (z, y) corner pairs along x
-      if (hit) {
-        int sy0 = sl + ry;
-        sy0 -= (sy0 >= R) ? R : 0;
-        int sy1 = sy0 + (s.py ? 1 : 0);
-        sy1 -= (sy1 >= R) ? R : 0;
-        unsigned c0 = (unsigned)sy0 * RSB + (unsigned)rz * PLB + (unsigned)rxs * 4u;
-        unsigned c1 = (unsigned)sy1 * RSB + (unsigned)rz * PLB + (unsigned)rxs * 4u;
-        if (DBG == 2 || DBG == 3) { c0 %= (unsigned)(R * RSB - 8); c1 %= (unsigned)(R * RSB - 8); c0 &= ~3u; c1 &= ~3u; }
-        const unsigned dzb = s.pz ? PLB : 0u;
-        r00 = lds_pair(c0);
-        r01 = lds_pair(c1);
-        r10 = lds_pair(c0 + dzb);
-        r11 = lds_pair(c1 + dzb);
-      } else {
+      hitv[i] = hit;
+      int sy0 = sl + ry;
+      sy0 -= (sy0 >= R) ? R : 0;
+      int sy1 = sy0 + (s.py ? 1 : 0);
+      sy1 -= (sy1 >= R) ? R : 0;
+      unsigned c0 = (unsigned)sy0 * RSB + (unsigned)rz * PLB + (unsigned)rxs * 4u;
+      unsigned c1 = (unsigned)sy1 * RSB + (unsigned)rz * PLB + (unsigned)rxs * 4u;
+      if (DBG == 2 || DBG == 3) { c0 %= (unsigned)(R * RSB - PLB - 8); c1 %= (unsigned)(R * RSB - PLB - 8); c0 &= ~3u; c1 &= ~3u; }
+      unsigned dzb = s.pz ? PLB : 0u;
+      if (!hit) { c0 = 0u; c1 = 0u; dzb = 0u; }
+      r00[i] = lds_pair(c0);
+      r01[i] = lds_pair(c1);
+      r10[i] = lds_pair(c0 + dzb);
+      r11[i] = lds_pair(c1 + dzb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!hitv[i]) {
+        const SampI<BWD>& s = sv[i];
         const unsigned o000 = (__umul24(__umul24((unsigned)s.z0, (unsigned)p.Hi) + (unsigned)s.y0, (unsigned)p.Wi) + (unsigned)s.x0) * 4u;
         const unsigned dx = s.px ? 4u : 0u, dy = s.py ? p.rowB : 0u, dz = s.pz ? p.planeB : 0u;
         const unsigned o010 = o000 + dy, o100 = o000 + dz, o110 = o100 + dy;
-        r00 = ld_pair_raw(vin, o000, dx); r01 = ld_pair_raw(vin, o010, dx);
-        r10 = ld_pair_raw(vin, o100, dx); r11 = ld_pair_raw(vin, o110, dx);
+        r00[i] = ld_pair_raw(vin, o000, dx); r01[i] = ld_pair_raw(vin, o010, dx);
+        r10[i] = ld_pair_raw(vin, o100, dx); r11[i] = ld_pair_raw(vin, o110, dx);
       }
-      const float v000 = s.px ? r00.a : r00.b, v001 = r00.b, v010 = s.px ? r01.a : r01.b, v011 = r01.b;
-      const float v100 = s.px ? r10.a : r10.b, v101 = r10.b, v110 = s.px ? r11.a : r11.b, v111 = r11.b;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const SampI<BWD>& s = sv[i];
+      const float v000 = s.px ? r00[i].a : r00[i].b, v001 = r00[i].b, v010 = s.px ? r01[i].a : r01[i].b, v011 = r01[i].b;
+      const float v100 = s.px ? r10[i].a : r10[i].b, v101 = r10[i].b, v110 = s.px ? r11[i].a : r11[i].b, v111 = r11[i].b;
       const float c00 = lerp(v000, v001, s.ax), c01 = lerp(v010, v011, s.ax);
       const float c10 = lerp(v100, v101, s.ax), c11 = lerp(v110, v111, s.ax);
       if constexpr (BWD) {
@@ -500,7 +519,8 @@ inline bool applicable(const W3P& p, const void* in0, const void* in1) {
 }
 
 // slices per workgroup: long runs amortise the window set-up and the (dc + 1 + spread) / dc row over-fetch, but the
-// launch should still deal several workgroups to every CU
+// launch should still deal four workgroups to every CU (same-box repeats at 2 x 256^3, scripts/gpu/r5_w3dc.sh: forward 0.315 /
+// 0.292 / 0.290 ms at 16 / 32 / 64 slices, three-addend backward 0.933 / 0.947 / 0.971)
 inline int pick_dc(const W3P& p, int npair) {
   int dc = 64;
   while (dc > 8 && (long long)p.B * fs::cdiv(p.D, dc) * p.tilesH * p.tilesW * npair < 4 * 256) dc >>= 1;

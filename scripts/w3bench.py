@@ -33,6 +33,8 @@ def make_flow(kind, B, S, dev, ch=6, amp=1.0):
         return (torch.rand(B, ch, S, S, S, device=dev) * 2 - 1) * 4 * amp
     if kind == "zero":
         return torch.zeros(B, ch, S, S, S, device=dev)
+    if kind == "small":  # the flows of a freshly initialised IFNet: a fraction of a voxel, smooth
+        amp = amp * 0.1
     ax = torch.linspace(0, 6.28318, S, device=dev)
     a = 4 * torch.sin(ax).view(1, S, 1, 1) * torch.cos(ax).view(1, 1, S, 1).expand(B, S, S, S)
     b = 3 * torch.cos(ax * 2).view(1, 1, 1, S).expand(B, S, S, S) + 0 * ax.view(1, S, 1, 1)
@@ -63,15 +65,19 @@ def main():
     print("library:", lib, "| flow:", kind, "| %d x %d^3" % (B, S))
 
     # plain pair: forward 2 x 20 B/voxel, backward (flow gradient only) 2 x 32 B/voxel
+    # (only = fwd | bwd | acc3: that launch alone is timed -- one kernel per PMC run; plain = fwd + bwd; acc = + acc3)
     f = make_flow(kind, B, S, dev).requires_grad_()
     G0, G1 = torch.randn_like(i0), torch.randn_like(i1)
-    t = timeit(lambda: ops.warp_pair(i0, i1, f.detach()))
     o0, o1 = ops.warp_pair(i0, i1, f)
-    print("fs_warp3d_pair_fwd            %.4f ms %6.0f GB/s  %s" % (t, gb(40, t), sig(o0, o1)))
-    t = timeit(lambda: torch.autograd.grad([o0, o1], [f], [G0, G1], retain_graph=True))
-    (gf,) = torch.autograd.grad([o0, o1], [f], [G0, G1], retain_graph=True)
-    print("fs_warp3d_pair_bwd            %.4f ms %6.0f GB/s  %s" % (t, gb(64, t), sig(gf)))
-    if only == "plain":
+    if only in ("", "plain", "acc", "fwd"):
+        t = timeit(lambda: ops.warp_pair(i0, i1, f.detach()))
+        print("fs_warp3d_pair_fwd            %.4f ms %6.0f GB/s  %s" % (t, gb(40, t), sig(o0, o1)))
+    if only in ("", "plain", "acc", "bwd"):
+        t = timeit(lambda: torch.autograd.grad([o0, o1], [f], [G0, G1], retain_graph=True))
+        (gf,) = torch.autograd.grad([o0, o1], [f], [G0, G1], retain_graph=True)
+        print("fs_warp3d_pair_bwd            %.4f ms %6.0f GB/s  %s" % (t, gb(64, t), sig(gf)))
+        del gf
+    if only in ("plain", "fwd", "bwd"):
         return
     # three addends (block 2 of the step): + 3 x 24 B/voxel read
     w0, w1, (fa, fb, fc) = ops.warp_pair_acc(i0, i1, f)
@@ -81,6 +87,8 @@ def main():
     (gf,) = run()
     print("fs_warp3d_pair_bwd_acc3       %.4f ms %6.0f GB/s  %s" % (t, gb(64 + 72, t), sig(gf)))
     del w0, w1, fa, fb, fc, gf, o0, o1
+    if only in ("acc", "acc3"):
+        return
     # fused up-sample + accumulate + warp: factor 2 with a running flow, factor 4 without
     for factor, has_prev in ((2, True), (4, False)):
         s = S // factor
