@@ -198,8 +198,10 @@ def parse():
     ap.add_argument("--dataset", default="droplet3d", choices=["droplet3d", "jets3d"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step from one HIP graph (Model.graphed_update; single GPU only, off by "
-                         "default so that N = 1 and N > 1 run the same code path; no per-kernel records)")
+                    help="(default at N = 1 since round 5) replay the step from one HIP graph (Model.graphed_update)")
+    ap.add_argument("--eager", action="store_true",
+                    help="N = 1: time eager launches (Model.update) instead of the HIP-graph replay; N > 1 (DDP) is always "
+                         "eager.  The graph-replayed run reports the eager figure next to it either way (`step_drivers`)")
     ap.add_argument("--cpu-size", type=int, nargs="+", default=[64, 128],
                     help="edges of the bounded CPU samples (SURVEY 8d: 64^3 and 128^3); the last one is `value`")
     ap.add_argument("--deterministic", action="store_true",
@@ -505,7 +507,11 @@ def config_c2(dev, steps, warmup):
            "flowsci_launches_per_step": launches, "hot_path_kernels": hot, "dominant_hot_path_kernel": dom}
     g = m.graphed_update(imgs, gt, dataset="droplet2d")
     dg = _time_steps(lambda: g(imgs, gt, lr), steps, warmup)
+    # the step driver of Flow-2D's train.py at N = 1 is the graph replay (round 5): it is the leg's figure, eager beside it
+    out["eager"] = {"ms_per_step": dt * 1e3, "pairs_per_s": B / dt}
     out["graph_replay"] = {"ms_per_step": dg * 1e3, "pairs_per_s": B / dg}
+    out["ms_per_step"], out["pairs_per_s"] = dg * 1e3, B / dg
+    out["step_driver"] = "hip-graph replay (Model.graphed_update)"
     return out
 
 
@@ -630,16 +636,20 @@ def main():
 
     if rank == 0:
         log("data + model ready; %d warm-up steps" % args.warmup)
-    if args.graph and not ddp:
+    # step driver: one HIP graph replayed per step at N = 1 (round 5: the default; --eager opts out), eager launches under
+    # DistributedDataParallel (capture through DDP's reducer is refused, rife.py)
+    use_graph = (not ddp) and (not args.eager)
+    eager_step = lambda: model.update(imgs, gt, learning_rate=lr, training=True)
+    if use_graph:
         graph_step = model.graphed_update(imgs, gt)
         do_step = lambda: graph_step(imgs, gt, lr)
     else:
-        do_step = lambda: model.update(imgs, gt, learning_rate=lr, training=True)
+        do_step = eager_step
     # warm-up: every C-ABI launch is recorded (HIP events on the launch stream) -- this warms the event pool
     # and tells which entry point dominates the step
     ops.enable_kernel_timing(True)
     for i in range(args.warmup):
-        model.update(imgs, gt, learning_rate=lr, training=True) if (args.graph and i == 0) else do_step()
+        eager_step() if (use_graph and i == 0) else do_step()  # (one eager step: the warm-up's per-launch records)
         torch.cuda.synchronize()
         if rank == 0:
             log("warm-up step %d done" % i)
@@ -663,6 +673,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timed = ops.kernel_timings()
+    eager_dt = None
+    if use_graph:
+        # a replayed graph carries no per-launch events: the same K steps once more as eager launches, right behind the
+        # timed region, give the eager step time (`step_drivers`) and the dominant kernel's launch durations (`roofline`)
+        ops.enable_kernel_timing(True, only=[dom_guess] if dom_guess else None)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            eager_step()
+        barrier()
+        eager_dt = time.perf_counter() - t1
+        timed = ops.kernel_timings()
     # separate recording pass (outside the timed region) for the per-entry-point `kernels` table
     ksteps = max(1, args.record_steps)
     ops.enable_kernel_timing(True)
@@ -718,6 +740,9 @@ def main():
         elif dom in timed and timed[dom]:
             dom_rec = _aggregate(timed[dom], args.steps)
             dom_src = "HIP events on the launch stream inside the timed region (%d launches)" % dom_rec["launches"]
+        if use_graph and "inside the timed region" in dom_src:
+            dom_src = ("HIP events on the launch stream inside the eager pass of %d steps run right behind the graph-replayed "
+                       "timed region (a replayed graph carries no per-launch events; %d launches)" % (args.steps, dom_rec["launches"]))
         # the entry point with the largest total time, for continuity with rounds 1-3 (same definition of `frac` now)
         dom_ep = max(kern, key=lambda k: kern[k]["ms_per_step"])
         out = {
@@ -747,8 +772,12 @@ def main():
             # what in the environment could have changed dispatch or numerics (INTEGRATION.md "Switches")
             "switches": _lib_switches(),
             "deterministic": bool(torch.are_deterministic_algorithms_enabled()),
-            "step_driver": "hip-graph replay (Model.graphed_update)" if (args.graph and not ddp) else
+            "step_driver": "hip-graph replay (Model.graphed_update)" if use_graph else
                            "eager launches (Model.update%s)" % (" under DistributedDataParallel" if ddp else ""),
+            # both drivers on this run's N (N > 1: eager only -- graph capture through DDP's reducer is refused)
+            "step_drivers": {"hip_graph_replay_ms_per_step": (dt / args.steps * 1e3) if use_graph else None,
+                             "eager_ms_per_step": (eager_dt / args.steps * 1e3) if use_graph else dt / args.steps * 1e3,
+                             "default": "hip-graph replay at N = 1 (--eager opts out); eager under DDP"},
         }
         if ranks is not None:
             out["ranks"] = ranks

@@ -980,7 +980,7 @@ class _Merge(torch.autograd.Function):
         with torch.cuda.device(w0.device):
             _call("fs_merge_bwd", w0.data_ptr(), w1.data_ptr(), m.data_ptr(), gmerged.data_ptr(),
                   _ptr(gsig), _ptr(g0), _ptr(g1), _ptr(gm), B, C, S, _stream(w0),
-                  algo_bytes=4 * (5 * w0.numel() + 3 * m.numel()))
+                  algo_bytes=4 * ((3 + int(n0) + int(n1)) * w0.numel() + (1 + int(gsig is not None) + int(nm)) * m.numel()))
         return g0, g1, gm
 
 

@@ -196,6 +196,11 @@ def run(args, Model, nd):
 
     step, best = 0, None
     total = args.epoch * steps_per_epoch
+    # step driver (round 5): at N = 1 the whole step -- forward, losses, backward, AdamW -- is captured once into a HIP
+    # graph and replayed per batch (Model.graphed_update: 0.4-0.5 ms of an 83 ms Flow-3D step at 256^3, a quarter of
+    # the launch-bound Flow-2D step); --eager keeps per-launch dispatch; under DDP the step is always eager
+    use_graph = (not distributed) and (not getattr(args, "eager", False))
+    graph_step = None
     for epoch in range(args.epoch):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -204,7 +209,11 @@ def run(args, Model, nd):
             data = data.to(device, non_blocking=True)  # (already there on both data paths)
             imgs, gt = data[:, :2], data[:, 2:3]
             lr = get_learning_rate(step, max(total, 2001)) * world / 4  # train.py:167
-            if nd == 3:
+            if use_graph:
+                if graph_step is None:
+                    graph_step = model.graphed_update(imgs, gt, **({} if nd == 3 else {"dataset": args.dataset}))
+                pred, info = graph_step(imgs, gt, lr)
+            elif nd == 3:
                 pred, info = model.update(imgs, gt, lr, training=True)
             else:
                 pred, info = model.update(imgs, gt, args.dataset, lr, training=True)
@@ -216,9 +225,9 @@ def run(args, Model, nd):
         torch.cuda.synchronize(device)
         if rank == 0 and steps_per_epoch:
             dt = time.time() - te
-            print("epoch %d train loop: %d steps in %.2f s = %.1f ms/step = %.2f pairs/s per rank (%s data)" % (
+            print("epoch %d train loop: %d steps in %.2f s = %.1f ms/step = %.2f pairs/s per rank (%s data, %s)" % (
                 epoch, steps_per_epoch, dt, dt / steps_per_epoch * 1e3, steps_per_epoch * args.batch_size / dt,
-                "host" if args.host_data else "device-generated"))
+                "host" if args.host_data else "device-generated", "hip-graph replay" if use_graph else "eager launches"))
         loss, p, pt = evaluate(model, val_data, nd, args.dataset, device)
         if rank == 0:
             print("eval epoch %d: loss_G %.4e  PSNR %.2f dB  (teacher %.2f dB)" % (epoch, loss, p, pt))
@@ -245,6 +254,8 @@ def add_common_args(parser, nd):
     parser.add_argument('--host_data', action='store_true',
                         help='generate the synthetic triplets on the host and feed them through a DataLoader + '
                              'pinned-memory prefetcher (the reference\'s arrangement) instead of on the GPU')
+    parser.add_argument('--eager', action='store_true',
+                        help='N = 1: eager launches per step instead of replaying the step from one HIP graph')
     parser.add_argument('--log_every', type=int, default=10)
     parser.add_argument('--log_path', default='train_log')
     parser.add_argument('--model_name', default='flownet.pkl')
