@@ -42,8 +42,9 @@ enum {
  *        fs_conv3d_wprep_batch.
  *   320  round 4: fs_conv3d_wrw_kernel_id (which weight-gradient kernel a call dispatches to; nothing launched);
  *        fs_conv3d_wrw_det / fs_conv3d_wrw_det_ws_floats (workspace form without float atomics).
- *        The library reads no environment variable any more (measurement switches live in the -DFS_ABLATION build). */
-#define FS_ABI_VERSION 320
+ *        The library reads no environment variable any more (measurement switches live in the -DFS_ABLATION build).
+ *   330  round 5: fs_warp3d_kernel_id (which kernel a trilinear-warp call dispatches to; nothing launched). */
+#define FS_ABI_VERSION 330
 int fs_version(void);
 /* Static string for an FS_* code. */
 const char* fs_error_string(int code);
@@ -131,6 +132,18 @@ int fs_upsample_warp3d_pair_bwd3(const float* img0, const float* img1, const flo
                                  const float* add2, long long batch_stride2, float* grad_flow_total, float* grad_delta,
                                  float* ws, int B, int C, const int* in_dhw, int Ds, int Hs, int Ws,
                                  int factor, float scale, fs_stream_t stream);
+
+/* Which kernel the trilinear-warp entry points above dispatch a call of this geometry to (nothing is launched; the
+ * pointers are inspected for alignment only, `in0` / `in1` = the sampled volumes, in1 NULL for a single warp):
+ *   FS_W3_KERNEL_GATHER (0)  the global-gather kernels (rounds 1-4: warp3d_fwd_ring_kernel / warp3d_bwd_kernel)
+ *   FS_W3_KERNEL_RC     (1)  round 5: ring pipeline with the gather source in an LDS row cache (warp3d_rc_kernel;
+ *                            C == 1, W_in % 4 == 0, the 37-plane x 72-column window fits the sampled volume, 16-byte
+ *                            aligned tensors, flow gradient only)
+ * `backward` != 0: fs_warp3d*_bwd* with `with_grad_in` saying whether grad_in / grad_img* are asked for; a negative
+ * return value is -FS_ERR_*.  (bench.py names the kernel symbol of its roofline records with it.) */
+enum { FS_W3_KERNEL_GATHER = 0, FS_W3_KERNEL_RC = 1 };
+int fs_warp3d_kernel_id(const float* in0, const float* in1, const float* flow, int B, int C, const int* in_dhw,
+                        int D, int H, int W, int backward, int with_grad_in);
 
 /* ------------------------------------------------------------------------------------
  * 2-D bilinear backward warps.  in [B,C,H,W], flow [B,2,H,W] (ch0 = x, ch1 = y),

@@ -33,7 +33,7 @@ def switches():
     return {"library": "ablation build: " + LIB_PATH if ABLATION else "product",
             "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("FLOWSCI_")}}
 
-ABI_VERSION = 320  # FS_ABI_VERSION of the include/flowsci_hip.h the SIGNATURES below were written against
+ABI_VERSION = 330  # FS_ABI_VERSION of the include/flowsci_hip.h the SIGNATURES below were written against
 
 _f32p = ctypes.c_void_p  # device pointers travel as integers
 _int = ctypes.c_int
@@ -119,6 +119,7 @@ SIGNATURES = {
     "fs_corr3d_bwd": [_f32p] * 5 + [_int] * 6 + [_stream],
     "fs_conv3d_wrw": [_f32p] * 3 + [_int] * 12 + [_stream],
     "fs_conv3d_wrw_kernel_id": [_f32p] * 2 + [_int] * 12,
+    "fs_warp3d_kernel_id": [_f32p] * 3 + [_int, _int, _intp] + [_int] * 5,
     "fs_conv3d_wrw_det_ws_floats": [_f32p, _f32p, _ptrv, _i64p] + [_int] * 12,
     "fs_conv3d_wrw_det": [_f32p, _f32p, _ptrv, _i64p, _f32p, _f32p, _i64] + [_int] * 12 + [_stream],
     "fs_conv3d_fwd_prelu_ms": [_ptrv, _i64p] + [_f32p] * 6 + [_int] * 13 + [_stream],

@@ -1080,6 +1080,19 @@ extern "C" int fs_warp3d_pair_bwd_acc3(const float* img0, const float* img1, con
                     W3Add{{add0, add1, add2}, {batch_stride0, batch_stride1, batch_stride2}}, p, stream);
 }
 
+extern "C" int fs_warp3d_kernel_id(const float* in0, const float* in1, const float* flow, int B, int C, const int* in_dhw,
+                                   int D, int H, int W, int backward, int with_grad_in) {
+  W3P p;
+  const int rc = make_params(p, B, C, in_dhw, D, H, W);
+  if (rc != FS_OK) return -rc;
+  // launch_fwd / launch_bwd's own conditions (the remaining operands of a call are 16-byte aligned whenever these are:
+  // the binding allocates them)
+  const bool vec = vec_ok(p, flow, nullptr, nullptr, nullptr);
+  static const int rc_mode = (int)FS_AB_ENV_LL("FLOWSCI_W3_RC", 1);
+  if (vec && rc_mode != 0 && !(backward && with_grad_in) && rc::applicable(p, in0, in1)) return FS_W3_KERNEL_RC;
+  return FS_W3_KERNEL_GATHER;
+}
+
 // "upsample flow x scale -> warp" in one kernel.  flow_out = prev_flow + scale *
 // trilinear_upsample(delta, factor) (prev_flow nullable), out0 = warp(img0, flow_out[:, :3]),
 // out1 = warp(img1, flow_out[:, 3:6]); delta [B,6,Ds,Hs,Ws], everything else at factor x that extent.

@@ -295,6 +295,22 @@ def _check_pair(img0, img1, flow):
     return img0, img1, flow, nd
 
 
+_W3_SYMBOLS = {(0, 1): "warp3d_rc_kernel<false, 2, 6, 0>", (1, 1): "warp3d_rc_kernel<true, 4, 5, 0>"}
+
+
+def _warp3d_symbol(img0, img1, flow, backward, with_grad_in=False):
+    """Kernel symbol a trilinear-warp pair launch of this geometry dispatches to, where ops.py can name it for bench.py's
+    per-symbol records: the round-5 row-cache ring kernels (fs_warp3d_kernel_id; asked only while launches are being
+    timed).  None = the gather kernels (several instantiations)."""
+    if _timing is None:
+        return None
+    B, C = img0.shape[:2]
+    D, H, W = flow.shape[2:]
+    kid = int(_lib.lib().fs_warp3d_kernel_id(img0.data_ptr(), img1.data_ptr(), flow.data_ptr(), B, C, _in_dhw(img0, flow),
+                                             D, H, W, int(backward), int(with_grad_in)))
+    return _W3_SYMBOLS.get((int(backward), kid))
+
+
 def _pair_forward(img0, img1, flow, nd):
     oshape = tuple(img0.shape[:2]) + tuple(flow.shape[2:])  # the warps take the flow's extent
     out0, out1 = img0.new_empty(oshape), img1.new_empty(oshape)
@@ -304,7 +320,8 @@ def _pair_forward(img0, img1, flow, nd):
             D, H, W = flow.shape[2:]
             _call("fs_warp3d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
                   out0.data_ptr(), out1.data_ptr(), B, C, _in_dhw(img0, flow), D, H, W,
-                  _stream(flow), algo_bytes=4 * flow.numel() + 8 * out0.numel() * 2)
+                  _stream(flow), algo_bytes=4 * flow.numel() + 8 * out0.numel() * 2,
+                  kernel=_warp3d_symbol(img0, img1, flow, 0))
         else:
             H, W = flow.shape[2:]
             _call("fs_warp2d_pair_fwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
@@ -380,13 +397,15 @@ def _pair_backward(img0, img1, flow, g0, g1, need_img, need_flow, gflow_add=None
                 gflow = torch.empty_like(flow)
                 _call("fs_warp3d_pair_bwd_acc3", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
                       g0.data_ptr(), s0, g1.data_ptr(), s1, _ptr(gi0), _ptr(gi1), *aargs, gflow.data_ptr(),
-                      B, C, _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb + abytes)
+                      B, C, _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb + abytes,
+                      kernel=_warp3d_symbol(img0, img1, flow, 1, need_img))
                 del keep
             else:
                 gflow = torch.empty_like(flow) if need_flow else None
                 _call("fs_warp3d_pair_bwd", img0.data_ptr(), img1.data_ptr(), flow.data_ptr(),
                       g0.data_ptr(), g1.data_ptr(), _ptr(gi0), _ptr(gi1), _ptr(gflow), B, C,
-                      _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb)
+                      _in_dhw(img0, flow), D, H, W, _stream(flow), algo_bytes=nb,
+                      kernel=_warp3d_symbol(img0, img1, flow, 1, need_img))
         else:
             H, W = flow.shape[2:]
             gflow = torch.empty_like(flow) if need_flow else None

@@ -6,20 +6,23 @@
 # Results land in gpurun_out/final/; copy what is to be judged into profiles/.
 set -e
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 PART=${2:-all}   # 1 = bench line, PMC traffic, kernel trace; 2 = everything after (a gpurun call is limited to 20 minutes)
 O=gpurun_out/final
 if [ "$PART" != 2 ]; then
 rm -rf $O && mkdir -p $O
 python bench.py --no-cpu-baseline --no-configs > $O/bench_events.json 2> $O/bench_events.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-configs --no-bench-parity > $O/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-configs --no-bench-parity > $O/w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -- python bench.py --eager --steps 2 --warmup 2 --no-cpu-baseline --no-configs --no-bench-parity > $O/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -- python bench.py --eager --steps 2 --warmup 2 --no-cpu-baseline --no-configs --no-bench-parity > $O/w.log 2>&1
 python scripts/pmc_traffic.py "$(find $O/f -name '*counter_collection.csv' | head -1)" \
     "$(find $O/w -name '*counter_collection.csv' | head -1)" $O/bench_events.json > $O/pmc_traffic.json
 cp $O/pmc_traffic.json profiles/${R}_pmc_traffic.json
 rm -rf $O/f $O/w
 python bench.py > $O/bench.json 2> $O/bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --no-cpu-baseline --no-configs --no-bench-parity > $O/under_rocprof.json 2> $O/kt.log
+# the same command as the bench line (N = 1: the step replayed from one HIP graph, then the eager pass behind it); should the
+# tracer lose the kernels of a replayed graph, the eager form of the command is traced instead
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --no-cpu-baseline --no-configs --no-bench-parity > $O/under_rocprof.json 2> $O/kt.log \
+  || { rm -rf $O/kt; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --eager --no-cpu-baseline --no-configs --no-bench-parity > $O/under_rocprof.json 2> $O/kt.log; }
 python scripts/last_step_breakdown.py "$(find $O/kt -name '*kernel_trace.csv' | head -1)" 70 > $O/last_step.txt
 cp "$(find $O/kt -name '*kernel_stats.csv' | head -1)" $O/kernel_stats.csv
 rm -rf $O/kt

@@ -9,7 +9,8 @@ both are in KB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests of wide coa
 exact for 16-byte streaming stores and float atomics.  A kernel is filed under the entry point that launches it
 (the forward convolution entry point also launches `wprep_kernel`; the three backward-warp entry points share one
 kernel and are told apart by their order inside a step: teacher warp, block 2 (three addends), blocks 1 and 0
-(fused up-sampling)).  Only the LAST step of each pass is used (the first steps contain MIOpen find kernels).
+(fused up-sampling) -- and the up-sampling adjoint launches that FOLLOW the warp launch of those two are part of
+their entry point, fs_upsample_warp3d_pair_bwd3: every kernel of a multi-kernel entry point is attributed).  Only the LAST step of each pass is used (the first steps contain MIOpen find kernels).
 `algorithmic_bytes` per launch = algo_GBps x avg_ms of the bench line (the figures ops.py supplies).
 """
 import collections
@@ -42,12 +43,15 @@ RULES = [  # (substring of the kernel name, entry point, counts as a launch of t
     ("convtr_", "fs_conv3d_tr", True),
     ("warp3d_fwd_kernel<512, true, true>", "fs_upsample_warp3d_pair_fwd", True),
     ("warp3d_fwd_kernel<512, true, false>", "fs_warp3d_pair_fwd", True), ("warp3d_fwd_ring_kernel", "fs_warp3d_pair_fwd", True),
+    ("warp3d_rc_kernel<false", "fs_warp3d_pair_fwd", True),
     ("prelu_bwd_kernel", "fs_prelu_bwd", True), ("prelu_ga_kernel", "fs_prelu_bwd", False),
     ("merge_fwd_kernel", "fs_merge_fwd", True), ("merge_bwd_kernel", "fs_merge_bwd", True),
     ("distill3_fwd_kernel", "fs_distill_fwd", True), ("distill3_bwd_kernel", "fs_distill_bwd", True),
 ]
 # kernel SYMBOLS bench.py's `roofline` may name (ops.py labels their launches): traffic per launch of the symbol itself
-SYMBOLS = ["conv3d_wino2d_ps_kernel<0, 16>", "conv3d_wino2d_ps_kernel<0, 8>", "conv3d_wrw_wino4_kernel<0>"]
+SYMBOLS = ["conv3d_wino2d_ps_kernel<0, 16>", "conv3d_wino2d_ps_kernel<0, 8>", "conv3d_wrw_wino4_kernel<0>",
+           "warp3d_rc_kernel<true, 4, 5, 0>", "warp3d_rc_kernel<false, 2, 6, 0>"]
+ADJOINT = ("up_adjoint_fused_kernel", "interp_axis_adjoint_kernel", "interp3d_up_adjoint")  # kernels of fs_interp3d_bwd_scaled
 WARP_BWD_ORDER = ["fs_warp3d_pair_bwd", "fs_warp3d_pair_bwd_acc3", "fs_upsample_warp3d_pair_bwd3",
                   "fs_upsample_warp3d_pair_bwd3"]
 
@@ -64,18 +68,24 @@ def last_step(path, counter):
     seg = rows[marks[-2]:marks[-1]] if len(marks) >= 2 else rows
     out = collections.defaultdict(lambda: [0.0, 0])
     nwarp = 0
+    adjoint_of = None  # the fused entry point whose warp launch has just run: its adjoint launches follow directly
     for r in seg:
         name, val = r["Kernel_Name"], float(r["Counter_Value"])
         for sym in SYMBOLS:
             if sym in name:
                 out["symbol:" + sym][0] += val
                 out["symbol:" + sym][1] += 1
-        if "warp3d_bwd_kernel" in name:
+        if "warp3d_bwd_kernel" in name or "warp3d_rc_kernel<true" in name:
             ep = WARP_BWD_ORDER[nwarp % 4]
             nwarp += 1
             out[ep][0] += val
             out[ep][1] += 1
+            adjoint_of = ep if ep == "fs_upsample_warp3d_pair_bwd3" else None
             continue
+        if adjoint_of is not None and any(a in name for a in ADJOINT):
+            out[adjoint_of][0] += val  # (not a launch of the entry point: one call = the warp + its adjoint passes)
+            continue
+        adjoint_of = None
         for sub, ep, counts in RULES:
             if sub in name:
                 out[ep][0] += val
