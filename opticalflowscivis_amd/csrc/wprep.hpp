@@ -18,8 +18,40 @@
 //       (points 0, +-1, +-2, inf) of the same taps                                                  (convwino4.hpp)
 //   FS_WPREP_WINO2D p = {Cout, Cin, CinP, mode}            Ut[ci][kz][ty 0..3][tx 0..5][co 0..63]: F(2,3) along ky and F(4,3)
 //       along kx of the same taps                                                                   (convwino2d.hpp)
+//   FS_WPREP_S3K4 p = {Cout, Cin, ceil(Cin / 2), CP}      words [channel group][channel pair][kz][piece][kyp][kh][co][kx]:
+//       the weights of a k = 4 layer as three bf16 pieces, two channels per 4-byte word                 (convfwd_s3.hpp)
 enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4, FS_WPREP_WINO4 = 5,
-       FS_WPREP_WINO2D = 6 };
+       FS_WPREP_WINO2D = 6, FS_WPREP_S3K4 = 7 };
+
+// two floats -> one word of two bf16 (round to nearest even; low half = the first)
+__device__ __forceinline__ unsigned s3_pack(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t h = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+
+// one word of the FS_WPREP_S3K4 slab: bf16 piece `piece` (a = a0 + a1 + a2) of the weights of channels (2 cp, 2 cp + 1)
+__device__ __forceinline__ unsigned wprep_s3_word(const FsWprepJob& j, int e) {
+  const int Cout = j.p[0], Cin = j.p[1], CinP2 = j.p[2], CP = j.p[3];
+  const float* __restrict__ w = j.w;
+  const int kx = e & 3;
+  int r = e >> 2;
+  const int col = r % CP; r /= CP;
+  const int kh = r & 1, kyp = (r >> 1) & 1; r >>= 2;
+  const int piece = r % 3; r /= 3;
+  const int kz = r & 3; r >>= 2;
+  const int cp = r % CinP2, mg = r / CinP2;
+  const int co = mg * CP + col, tap = (kz * 4 + 2 * kyp + kh) * 4 + kx;
+  float v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = 2 * cp + i;
+    float a = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 64 + tap] : 0.f;
+    for (int q = 0; q < piece; ++q) a = a - (float)(__bf16)a;  // exact
+    v[i] = a;
+  }
+  return s3_pack(v[0], v[1]);
+}
 constexpr int FS_WINO_UCH = 9 * 4 * 64 + 16;  // floats per input channel of the Winograd slab (== WN_UCH)
 constexpr int FS_WINO4_UCH = 9 * 6 * 64;      // ... of the F(4,3) slab (== W4_UCH)
 constexpr int FS_WINO2D_UCH = 3 * 24 * 64;    // ... of the F(2,3) x F(4,3) slab (== W2_UCH)
@@ -164,6 +196,11 @@ __global__ __launch_bounds__(256) void wprep_one_kernel(FsWprepJob j) {
     wprep_wino2d_blocks(j, blockIdx.x, gridDim.x);
     return;
   }
+  if (j.kind == FS_WPREP_S3K4) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256)
+      reinterpret_cast<unsigned*>(j.ws)[e] = wprep_s3_word(j, e);
+    return;
+  }
   for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256) j.ws[e] = wprep_elem(j, e);
 }
 
@@ -172,6 +209,11 @@ __global__ __launch_bounds__(256) void wprep_batch_kernel(const FsWprepJob* __re
   const FsWprepJob j = jobs[blockIdx.y];
   if (j.kind == FS_WPREP_WINO2D && j.total == j.p[2] * FS_WINO2D_UCH) {
     wprep_wino2d_blocks(j, blockIdx.x, gridDim.x);
+    return;
+  }
+  if (j.kind == FS_WPREP_S3K4) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256)
+      reinterpret_cast<unsigned*>(j.ws)[e] = wprep_s3_word(j, e);
     return;
   }
   for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256) j.ws[e] = wprep_elem(j, e);

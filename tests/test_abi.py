@@ -113,7 +113,12 @@ def test_weight_relayout_plans_without_gpu():
     assert fwd(64, 64, 16, 3, 0) == 1 and buf[0].kind == 0 and buf[0].total == 64 * 27 * 64
     assert fwd(64, 64, 32, 3, 0) == 1 and buf[0].kind == 6   # rows of 32: 2 x 4 x 32 bricks, one per CU at 2 x 32^3
     assert fwd(64, 64, 64, 3, 0, x=0x4004) == 1 and buf[0].kind == 0
-    assert fwd(11, 32, 64, 4, 0) == 1 and buf[0].kind == 0 and buf[0].total == L.fs_conv3d_fwd_ws_floats(11, 32, 4) == 12 * 64 * 32
+    # k4 s2 layers: the fp32 taps (kind 0) on small volumes; from 256 bricks of 1 x 16 x 32 outputs on, the pre-split bf16
+    # slab of the fp32-accurate bf16-rate kernel (round 5, kind 7: three 2-byte pieces per weight = 1.5 x the floats)
+    assert fwd(11, 32, 64, 4, 0) == 1 and buf[0].kind == 0 and buf[0].total == 12 * 64 * 32 <= L.fs_conv3d_fwd_ws_floats(11, 32, 4)
+    assert fwd(11, 32, 128, 4, 0) == 1 and buf[0].kind == 7 and buf[0].total == L.fs_conv3d_fwd_ws_floats(11, 32, 4) == 32 * 6 * 4 * 48
+    assert fwd(32, 64, 128, 4, 0) == 1 and buf[0].kind == 7 and buf[0].total == L.fs_conv3d_fwd_ws_floats(32, 64, 4) == 64 * 16 * 4 * 48
+    assert fwd(32, 64, 128, 4, 0, x=0x4004) == 1 and buf[0].kind == 0   # misaligned input: the fp32 kernels
     assert L.fs_conv3d_fwd_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 1, 8, 8, 8, 8, 8, 4, 4, 4, 5, 1, 2, 0) == -3   # -FS_ERR_ARG
     assert fwd(8, 8, 8, 3, 0, w=None) == -1                                                                          # -FS_ERR_NULLPTR
     kinds = {}

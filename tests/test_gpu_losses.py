@@ -865,3 +865,76 @@ def test_res_unit_inner_prelu_backward_in_the_conv_epilogue(ops, C, size, nslope
     assert torch.equal(fused[0], ref[0])
     for got, want in zip(fused[1:], ref[1:]):
         assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def _k4_slab_kind(x_shape, cin, cout, dev_x, dev_w):
+    """FsWprepJob kind the library's dispatch picks for a k4 s2 p1 fs_conv3d_fwd call (7 = the pre-split bf16 slab of
+    csrc/convfwd_s3.hpp, 0 = the fp32 taps)."""
+    from opticalflowscivis_amd import _lib
+    L = _lib.lib()
+    buf = (_lib.FsWprepJob * 4)()
+    B, _, D, H, W = x_shape
+    ws = torch.empty(int(L.fs_conv3d_fwd_ws_floats(cin, cout, 4)), device=DEV)
+    n = L.fs_conv3d_fwd_wprep_jobs(buf, 4, dev_x.data_ptr(), dev_w.data_ptr(), ws.data_ptr(), B, cin, cout, D, H, W,
+                                   D // 2, H // 2, W // 2, 4, 2, 1, 0)
+    assert n == 1
+    return buf[0].kind
+
+
+@pytest.mark.parametrize("cin,cout,size,form", [
+    (12, 32, (64, 64, 128), "prelu"),      # conv0a of a block: bias + PReLU output
+    (11, 32, (64, 66, 132), "plain"),      # odd channel count (a dead half-pair), output rows / columns past the last tile
+    (32, 64, (64, 64, 128), "prelu_add"),  # conv0b: 64 output channels (two MFMA row tiles), residual addend
+    (6, 32, (64, 64, 128), "plain"),       # input gradient of the flow head's last deconvolution (few input channels)
+    (1, 32, (66, 70, 128), "dprelu"),      # ... of the mask head, with the fused PReLU-backward epilogue
+    (32, 64, (32, 128, 128), "plain"),
+])
+def test_conv3d_fwd_split_bf16_kernel_vs_fp64(ops, cin, cout, size, form):
+    """Round 5: the k4 s2 p1 forward convolution with fp32 accuracy on the bf16 matrix rate (csrc/convfwd_s3.hpp: every
+    operand as three bf16 pieces, six products, fp32 accumulation).  Against an fp64 convolution at the tolerance of the
+    fp32 kernels -- measured error is at fp32 rounding level -- in every epilogue form it is launched with, and the
+    library's dispatch must really have taken it (slab kind 7)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(cin * 7 + cout + size[1])
+    B = 2
+    x = torch.randn((B, cin) + size, generator=g)
+    w = torch.randn(cout, cin, 4, 4, 4, generator=g) / (cin * 64) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    assert _k4_slab_kind(x.shape, cin, cout, xd, wd) == 7
+    ref = F.conv3d(x.double(), w.double(), None if form == "dprelu" else bias.double(), 2, 1)
+    scale = float(ref.abs().max())
+    if form == "plain":
+        y = ops.conv3d_fwd(xd, wd, bd, 4, 2, 1, 0)
+        assert float((y.cpu().double() - ref).abs().max()) < 3e-6 * scale
+    elif form in ("prelu", "prelu_add"):
+        slope = torch.rand(cout, generator=g) * 0.5
+        add = torch.randn(ref.shape, generator=g) if form == "prelu_add" else None
+        y, z = ops.conv3d_fwd(xd, wd, bd, 4, 2, 1, 0, slope.to(DEV), None if add is None else add.to(DEV))
+        zr = torch.where(ref > 0, ref, ref * slope.double().view(1, -1, 1, 1, 1)) + (0 if add is None else add.double())
+        assert float((y.cpu().double() - ref).abs().max()) < 3e-6 * scale
+        assert float((z.cpu().double() - zr).abs().max()) < 3e-6 * max(scale, float(zr.abs().max()))
+    else:
+        # the head's fused form: result g = conv(gout) is the gradient w.r.t. prelu(act_y); stored g * prelu'(act_y) plus
+        # the slope / bias gradient sums
+        act_y = torch.randn(ref.shape, generator=g)
+        slope = torch.rand(cout, generator=g) * 0.5
+        from opticalflowscivis_amd import _lib
+        L = _lib.lib()
+        Do, Ho, Wo = [n // 2 for n in size]
+        out = torch.empty((B, cout, Do, Ho, Wo), device=DEV)
+        part = torch.zeros(int(L.fs_conv3d_fwd_dprelu_part_floats(B, cout, Do, Ho, Wo)), device=DEV)
+        ga, gb = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        ws = torch.empty(int(L.fs_conv3d_fwd_ws_floats(cin, cout, 4)), device=DEV)
+        ad, sd = act_y.to(DEV), slope.to(DEV)
+        rc = L.fs_conv3d_fwd_dprelu(xd.data_ptr(), wd.data_ptr(), ad.data_ptr(), sd.data_ptr(), cout, out.data_ptr(),
+                                    ga.data_ptr(), gb.data_ptr(), part.data_ptr(), ws.data_ptr(), B, cin, cout, *size, Do, Ho,
+                                    Wo, 4, 2, 1, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+        gy = torch.where(act_y.double() > 0, ref, ref * slope.double().view(1, -1, 1, 1, 1))
+        assert float((out.cpu().double() - gy).abs().max()) < 3e-6 * scale
+        gar = (ref * act_y.double() * (act_y.double() <= 0)).sum(dim=(0, 2, 3, 4))
+        gbr = gy.sum(dim=(0, 2, 3, 4))
+        n = float(ref[0, 0].numel() * B) ** 0.5
+        assert float((ga.cpu().double() - gar).abs().max()) < 2e-5 * max(1.0, float(gar.abs().max())) + 1e-5 * n * scale
+        assert float((gb.cpu().double() - gbr).abs().max()) < 2e-5 * max(1.0, float(gbr.abs().max())) + 1e-5 * n * scale
