@@ -181,6 +181,9 @@ __global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(cons
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWW + 2 * PASSES) : "memory");
       tie(ld);
+#ifdef FS_ABLATION
+      if (!(p.ab & 16))  // (measurement: no conversion / LDS writes -- FLOWSCI_S3_AB=16)
+#endif
       convert(s, ld);
       if (s + 2 < NS) issue_loads(s + 2, ld);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -227,6 +230,9 @@ __global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(cons
     const unsigned char* sb = lds + (s & 1) * S3_INB;   // input pieces of this stage
     const unsigned char* sw = lds + wslot * WBP;         // its weight slab (aO carries the ring's base)
     wslot = wslot == 2 ? 0 : wslot + 1;
+#ifdef FS_ABLATION
+    if (!(p.ab & 64))
+#endif
 #pragma unroll
     for (int kyp = 0; kyp < 2; ++kyp) {
       s3_bf16x8 a[3][MT], bq[3][NT];
@@ -243,6 +249,9 @@ __global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(cons
           bq[pc][n] = __builtin_bit_cast(s3_bf16x8, v);
         }
       }
+#ifdef FS_ABLATION
+      if (p.ab & 32) continue;  // (measurement: operand reads without the MFMAs -- FLOWSCI_S3_AB=32)
+#endif
       // the six products, small terms first: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -265,6 +274,10 @@ int launch_s3(const float* X, const float* Ws, const float* bias, float* Y, FP& 
   p.tiles = (long long)p.B * p.tz * p.ty * p.tx;
   const int mgroups = p.CoutP / (32 * MT);
   if (p.tiles >= (1ll << 31) || mgroups > 65535) return FS_ERR_SHAPE;
+#ifdef FS_ABLATION
+  static const int s3_ab = (int)FS_AB_ENV_LL("FLOWSCI_S3_AB", 0);  // 16: no conversion, 32: no MFMAs, 64: no operand reads either (wrong results by design)
+  p.ab = s3_ab;
+#endif
   hipLaunchKernelGGL((conv3d_fwd_s3_kernel<MT, NMW, NLW>), dim3((unsigned)p.tiles, mgroups), dim3(64 * (NMW + NLW)), 0, st, X,
                      reinterpret_cast<const unsigned*>(Ws), bias, Y, p);
   FS_LAUNCH_CHECK();
