@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (same guide: v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide: ~2.5 PF, v_mfma_f32_32x32x16_bf16 at 32 cycles per SIMD)
 
 # Algorithmic (compulsory) HBM bytes per launch are supplied by ops.py next to every C-ABI call
 # (DESIGN.md §4): e.g. one warp3d pair launch = 2 warps x 20 B/voxel forward (12 flow + 4 gather +
@@ -58,6 +59,15 @@ def roofline(dom, k, S, B):
     csrc/convwrwwino4.hpp) of the direct convolution's 2 * out * Cin * 27 flops: that ratio is `algorithmic_speedup`,
     and `direct_equivalent_TFLOPps` (= achieved x it) is a speed-up, not a roofline figure."""
     traffic, src = pmc_traffic(dom, S, B)
+    if "TFLOPps" in k and "s3_kernel" in dom:
+        # fp32-accurate convolution on the bf16 matrix rate (csrc/convfwd_s3.hpp): six v_mfma_f32_32x32x16_bf16 products per
+        # fp32 multiply-add are EXECUTED -- that rate against the dense bf16 MFMA peak; the useful fp32 rate beside it
+        ex = k["TFLOPps"]
+        de = k.get("TFLOPps_direct_equivalent", ex)
+        return {"bound": "mfma", "kernel": dom, "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ex / MFMA_BF16_PEAK_TFLOPS, 4), "useful_fp32_TFLOPps": de,
+                "arithmetic": "fp32 operands as 3 bf16 pieces, 6 products, fp32 accumulate",
+                "traffic": traffic, "traffic_source": src}
     if "TFLOPps" in k:
         ex = k["TFLOPps"]
         de = k.get("TFLOPps_direct_equivalent", ex)
@@ -312,13 +322,44 @@ def cpu_baseline(sizes, dataset, dev, steps=2):
         parity.append(rec)
         del g, m
         torch.cuda.empty_cache()
-    last = samples[-1]
+    # the metric's own size, measured instead of scaled: ONE timed oracle step at B = 1, 256^3 after
+    # one warm-up step -- only when the host can hold it (~35 GB) and the bounded samples say it fits the time budget
+    full = {"size": 256, "batch": 1, "measured": False}
+    try:
+        with open("/proc/meminfo") as f:
+            avail_gb = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable:")) / 2 ** 20
+    except (OSError, StopIteration, ValueError):
+        avail_gb = 0.0
+    est = samples[-1]["s_per_step"] * (256.0 / samples[-1]["size"]) ** 3 / samples[-1]["batch"] * 1.15
+    if 256 in sizes:
+        full = None  # already one of the samples
+    elif os.environ.get("FLOWSCI_BENCH_NO_CPU_256") == "1":
+        full["reason"] = "switched off (FLOWSCI_BENCH_NO_CPU_256=1)"
+    elif avail_gb < 48:
+        full["reason"] = "MemAvailable %.0f GB < 48 GB" % avail_gb
+    elif 2 * est > 200:
+        full["reason"] = "estimated %.0f s per step from the %d^3 sample: two steps exceed the 200 s budget" % (est, samples[-1]["size"])
+    else:
+        log("cpu_baseline: one timed oracle step at B=1 x 256^3 (estimate %.0f s per step, %.0f GB available)" % (est, avail_gb))
+        torch.manual_seed(1234)
+        m = ModelRef(3)
+        data = gen(1, 256, seed=1234)
+        imgs, gt = data[:, :2], data[:, 2:3]
+        m.update(imgs, gt, learning_rate=1e-4, training=True)      # warm-up (allocator, thread pool)
+        t0 = time.perf_counter()
+        m.update(imgs, gt, learning_rate=1e-4, training=True)
+        dt = time.perf_counter() - t0
+        full.update(measured=True, s_per_step=round(dt, 3), timed_steps=1, pairs_per_s=1.0 / dt, pairs_per_s_256eq=1.0 / dt)
+        del m, data, imgs, gt
+    if full is not None:
+        samples.append(full)
+    last = next(x for x in reversed(samples) if x.get("measured", True))
     base = {"value": last["pairs_per_s_256eq"], "unit": "volume-pairs/s (256^3-equivalent)",
             "cores": cores, "kind": "port",
             "sample": "oracle Flow-3D train step on %s: %s; value = the %d^3 sample scaled by voxel count "
                       "(x%.4f) to 256^3" % (dataset, "; ".join(
                           "B=%d at %d^3: %d timed steps, %.2f s/step" % (x["batch"], x["size"], x["timed_steps"],
-                                                                         x["s_per_step"]) for x in samples),
+                                                                         x["s_per_step"]) for x in samples if x.get("measured", True)),
                           last["size"], (last["size"] / 256.0) ** 3),
             "samples": samples}
     top = parity[-1]
@@ -674,9 +715,16 @@ def main():
     # the dominant KERNEL of the warm-up steps: the symbol with the largest total time among the launches ops.py can
     # name (the Winograd trunk kernels; `rocprofv3 --kernel-trace --stats` of this command, profiles/, names the same
     # one); its entry point is the one followed with events inside the timed region
+    # the dominant KERNEL of the warm-up steps: kernel symbols ops.py can name and, per entry point, the launches it
+    # cannot (the same candidates the final `roofline` record is chosen from); its entry point is the one followed with
+    # events inside the timed region
     wsym = by_symbol(wt)
-    dom_sym = max(wsym, key=lambda k: sum(r[0] for r in wsym[k][1])) if wsym else None
-    dom_guess = wsym[dom_sym][0] if dom_sym else (max(wt, key=lambda k: sum(r[0] for r in wt[k])) if wt else None)
+    wcand = {sym: (ep, sum(r[0] for r in recs)) for sym, (ep, recs) in wsym.items()}
+    for ep, recs in wt.items():
+        rest = sum(r[0] for r in recs if not (len(r) > 4 and r[4]))
+        if rest and (ep.startswith("fs_conv3d") or ep.startswith("fs_warp3d") or ep.startswith("fs_upsample")):
+            wcand.setdefault(ep, (ep, rest))
+    dom_guess = wcand[max(wcand, key=lambda k: wcand[k][1])][0] if wcand else (max(wt, key=lambda k: sum(r[0] for r in wt[k])) if wt else None)
     barrier()
     # timed region: only that entry point's launches carry events (~90 of ~430 launches per step), so the headline
     # time is free of profiling overhead while `roofline` is still measured inside the region
@@ -747,8 +795,16 @@ def main():
         ksym = {sym: dict(_aggregate(recs, ksteps), entry_point=ep) for sym, (ep, recs) in by_symbol(ktimes).items()}
         # `roofline` = the dominant hand-written KERNEL (by symbol, as rocprofv3's kernel stats name it); its record
         # comes from the events recorded inside the timed region when its entry point was the one followed there
-        dom = max(ksym, key=lambda k: ksym[k]["ms_per_step"]) if ksym else max(kern, key=lambda k: kern[k]["ms_per_step"])
-        dom_rec = (ksym if ksym else kern)[dom]
+        # candidates for the dominant hand-written kernel: every symbol ops.py could name, and per entry point the launches
+        # it could NOT name (several instantiations behind one entry point: filed under the entry point) -- so a symbol is
+        # only reported as dominant when nothing unnamed outweighs it
+        cand = dict(ksym)
+        for ep, recs in ktimes.items():
+            rest = [r for r in recs if not (len(r) > 4 and r[4])]
+            if rest and (ep.startswith("fs_conv3d") or ep.startswith("fs_warp3d") or ep.startswith("fs_upsample")):
+                cand.setdefault(ep, dict(_aggregate(rest, ksteps), entry_point=ep))
+        dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
+        dom_rec = cand[dom]
         dom_src = "HIP events, separate pass of %d steps after the timed region" % ksteps
         tsym = by_symbol(timed)
         if dom in tsym:
@@ -770,6 +826,10 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # every tensor and every accumulation is fp32; one kernel family multiplies on the bf16 matrix cores without
+            # giving up fp32 accuracy (error vs fp64 <= the fp32 MFMA kernels': profiles/r05_split_bf16.txt)
+            "arithmetic": "fp32; the k4 s2 forward convolutions (conv3d_fwd_s3_kernel) multiply fp32 operands as 3 bf16 pieces, "
+                          "6 products, fp32 accumulate",
             "config": {"workload": "Flow-3D %s %d^3, batch %d per GPU, IFNet-3D random init, "
                                    "3D trilinear warp HIP kernels" % (args.dataset, S, B),
                        "global_batch": world * B, "volume": [S, S, S],

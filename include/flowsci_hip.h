@@ -180,7 +180,10 @@ int fs_warp2d_bwd(const float* in, const float* flow, const float* start,
 
 /* Pair form for the IFNet call site (Flow-2D/model/IFNet.py:191-192, 230-231):
  *   warp(img0, flow[:, :2]); warp(img1, flow[:, 2:4])  with flow4 [B,4,H,W] used in place.
- * No mask, no start. */
+ * No mask, no start.  * Aliasing: grad_in / grad_img0 / grad_img1 are accumulated INTO (zero-fill them first).  Planes of <= 48 KB are added
+ * by plane-owning workgroups with plain read-modify-writes, which needs every grad_img of a pair launch to be present and
+ * the two to be different tensors; a pair launch whose grad_img0 == grad_img1 (or with one of them NULL where that is
+ * allowed) takes the float-atomic kernel instead, which tolerates the aliasing. */
 int fs_warp2d_pair_fwd(const float* img0, const float* img1, const float* flow4,
                        float* out0, float* out1,
                        int B, int C, const int* in_hw, int H, int W, int mode, fs_stream_t stream);

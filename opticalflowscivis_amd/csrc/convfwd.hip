@@ -666,9 +666,15 @@ static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, co
     const int cp = p.CoutP;  // one channel group per workgroup
     wprep_do(wprep_job(FS_WPREP_S3K4, w, ws, s3_slab_words(Cin, p.CoutP), Cout, Cin, (Cin + 1) / 2, cp, 0, 0), plan, st);
     if (plan != nullptr) return FS_OK;
-    static const int s3_nlw = (int)FS_AB_ENV_LL("FLOWSCI_S3_NLW", 4);  // loader waves (ablation build: 4 or 8)
-    const int rc = p.CoutP == 32 ? (s3_nlw == 8 ? launch_s3<1, S3_NMW, 8>(x, ws, bias, y, p, st) : launch_s3<1, S3_NMW, 4>(x, ws, bias, y, p, st))
-                                 : (s3_nlw == 8 ? launch_s3<2, S3_NMW, 8>(x, ws, bias, y, p, st) : launch_s3<2, S3_NMW, 4>(x, ws, bias, y, p, st));
+    // 8 matrix waves (two per SIMD) + 4 loader waves: 8 loaders measured 3-5 % slower on every layer (and spill at 64
+    // output channels); the ablation build keeps them behind FLOWSCI_S3_NLW=8
+    int rc;
+#ifdef FS_ABLATION
+    static const int s3_nlw = (int)FS_AB_ENV_LL("FLOWSCI_S3_NLW", 4);
+    if (s3_nlw == 8) rc = p.CoutP == 32 ? launch_s3<1, S3_NMW, 8>(x, ws, bias, y, p, st) : launch_s3<2, S3_NMW, 8>(x, ws, bias, y, p, st);
+    else
+#endif
+    rc = p.CoutP == 32 ? launch_s3<1, S3_NMW, 4>(x, ws, bias, y, p, st) : launch_s3<2, S3_NMW, 4>(x, ws, bias, y, p, st);
     if (rc != FS_OK || dp == nullptr) return rc;
     return dp_finish(32, S3_NMW);
   }

@@ -989,13 +989,16 @@ inline int wino2d_part_rows() { return wino2d_r3() ? 1 : 2; }
 
 template <int XT>
 void launch_wino2d_t(const float* X, const float* Ut, const float* bias, float* Y, const FP& p, hipStream_t st) {
-  static int ncu = 0;  // one persistent workgroup per CU
+  // one persistent workgroup per CU of the device the call runs on (per-device table: a process may drive several GPUs,
+  // and two threads may make their first call together -- an int store is the only shared write)
+  static int ncu_of[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int ncu = ncu_of[dev];
   if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-      n = 256;
-    ncu = n;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    ncu_of[dev] = ncu = n;
   }
   const dim3 g((unsigned)(p.tiles < ncu ? p.tiles : ncu), 1);
 #ifdef FS_ABLATION  // instantiations that SKIP work (wrong results by design) and the round-3 form: measurement builds only

@@ -393,7 +393,11 @@ void launch_bwd(const W2Bwd& io, int npair, const float* flow, const float* star
   hipLaunchKernelGGL((warp2d_bwd_kernel<MODE, MASK, GIN, SLN>), g, dim3(256), 0, st, io, flow, start, gflow, p)
   // planes that fit LDS: grad_in by plane-owning workgroups (no global atomics), grad_flow by the gather kernel
   const long long plane = (long long)p.Hi * p.Wi * 4;
-  if (io.gin[0] != nullptr && plane <= 48 * 1024 && (long long)p.B * p.C < (1ll << 31)) {
+  // (plane-owning workgroups add their planes with plain read-modify-writes: every grad_in of the launch must be present
+  // and they must be different tensors -- aliased or partly missing ones keep the atomic kernel; include/flowsci_hip.h)
+  bool own = io.gin[0] != nullptr;
+  for (int k = 1; k < npair; ++k) own = own && io.gin[k] != nullptr && io.gin[k] != io.gin[0];
+  if (own && plane <= 48 * 1024 && (long long)p.B * p.C < (1ll << 31)) {  // (grid.x = B * channel groups <= B * C)
     if (gflow != nullptr) {
       if (sl == 1) FS_W2_BWD(false, 1); else if (sl == 4) FS_W2_BWD(false, 4); else FS_W2_BWD(false, 16);
     }

@@ -1674,6 +1674,21 @@ def _fwd_k3_macs(xptr, B, Cin, Cout, dhw, wmode):
     return _wino_seen[key]
 
 
+def _fwd_k4_symbol(xptr, B, Cin, Cout, in_dhw, out_dhw):
+    """Kernel symbol of a k4 s2 p1 fs_conv3d_fwd* call where ops.py can name it: the round-5 kernel that runs the layer
+    with fp32 accuracy on the bf16 matrix rate (csrc/convfwd_s3.hpp; the library's re-layout plan says slab kind 7).  Asked
+    only while launches are being timed; None = the fp32-MFMA kernels (several instantiations)."""
+    if _timing is None:
+        return None
+    key = ("k4", xptr % 16, B, Cin, Cout) + tuple(int(v) for v in in_dhw)
+    if key not in _wino_seen:
+        buf = (_lib.FsWprepJob * 4)()
+        n = _lib.lib().fs_conv3d_fwd_wprep_jobs(buf, 4, 0x1000 + xptr % 16, 0x1000, 0x1000, B, Cin, Cout, *key[5:8],
+                                                *[int(v) for v in out_dhw], 4, 2, 1, 0)
+        _wino_seen[key] = (n == 1 and buf[0].kind == 7)
+    return ("conv3d_fwd_s3_kernel<%d, 8, 4>" % (1 if Cout <= 32 else 2)) if _wino_seen[key] else None
+
+
 def _fwd_k3_symbol(macs, W):
     """Kernel symbol of a k3 s1 p1 fs_conv3d_fwd* call whose dispatch executes `macs` multiply-adds per (output, input
     channel) -- the names `rocprofv3 --kernel-trace --stats` prints (csrc/convwino2d.hpp::launch_wino2d: 16 x-tiles per
@@ -2031,6 +2046,10 @@ def conv3d_fwd(x, w, bias, k, stride, pad, wmode=0, prelu_weight=None, addend=No
     if int(k) == 3 and int(stride) == 1 and int(pad) == 1:  # the Winograd forms execute fewer multiply-adds
         macs = _fwd_k3_macs(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), wmode)
         fl, sym = int(2 * y.numel() * Cin * macs), _fwd_k3_symbol(macs, Wi)
+    elif int(k) == 4 and int(stride) == 2 and int(pad) == 1 and not wmode:
+        sym = _fwd_k4_symbol(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), (Do, Ho, Wo))
+        if sym is not None:
+            fl = 6 * fq  # matrix-core flops EXECUTED: six bf16 products per fp32 multiply-add (priced against the bf16 peak)
     if addend is not None:
         addend = _need_cuda_f32("addend", addend, 5)
         if addend.shape != y.shape:
