@@ -76,6 +76,53 @@ class DeviceTripletLoader:
             yield torch.stack([self.dataset.item(i, self.device) for i in idx])
 
 
+class HostCachedLoader:
+    """The reference's data arrangement at volume sizes: the whole (small) training set lives in host memory -- its
+    `load_data` un-pickles every triplet into one numpy array (Flow-3D/load_datasets.py:47-48) -- and a batch is a gather of
+    B samples.  At 256^3 a triplet is 201 MB, so the gather goes straight into one of two PINNED staging buffers (no
+    per-sample collation, no worker processes copying through shared memory): `DevicePrefetcher` then moves the buffer
+    to the GPU on its side stream while the previous step computes.  Same batches (sampler, `drop_last`, item values) as
+    `DataLoader(SyntheticTriplets(...))`; the samples are generated once, on `device`, and parked on the host."""
+
+    def __init__(self, dataset, batch_size, device, sampler=None, shuffle=False, drop_last=False, seed=0):
+        self.batch_size, self.sampler, self.shuffle, self.drop_last = batch_size, sampler, shuffle, drop_last
+        self._gen = torch.Generator().manual_seed(seed)
+        first = dataset.item(0, device)
+        self.data = torch.empty((len(dataset),) + tuple(first.shape), dtype=first.dtype).pin_memory()
+        self.data[0].copy_(first)
+        for i in range(1, len(dataset)):
+            self.data[i].copy_(dataset.item(i, device))
+        self.stage = [torch.empty((batch_size,) + tuple(first.shape), dtype=first.dtype).pin_memory() for _ in range(3)]
+        self._copied = [None, None, None]  # per staging buffer: the event behind its last host-to-device copy
+        self._last = 0
+
+    def copy_issued(self, event):
+        """DevicePrefetcher: the copy of the buffer yielded last has been enqueued; `event` completes with it."""
+        self._copied[self._last] = event
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None else self.data.shape[0]
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        if self.sampler is not None:
+            order = list(iter(self.sampler))
+        elif self.shuffle:
+            order = torch.randperm(self.data.shape[0], generator=self._gen).tolist()
+        else:
+            order = list(range(self.data.shape[0]))
+        for k in range(len(self)):
+            idx = order[k * self.batch_size:(k + 1) * self.batch_size]
+            # three staging buffers: the one being filled, the one in flight to the GPU, the one the step may still read from
+            if self._copied[k % 3] is not None:
+                self._copied[k % 3].synchronize()  # (its previous contents have left for the GPU: three batches ago)
+            buf = self.stage[k % 3][:len(idx)]
+            for j, i in enumerate(idx):
+                buf[j].copy_(self.data[i])
+            self._last = k % 3
+            yield buf
+
+
 class DevicePrefetcher:
     """Host-resident data (any DataLoader with pin_memory=True): the H2D copy of batch k+1 runs on a side stream
     while step k computes -- what UPFlow's `tools.data_prefetcher` does in the reference (UPFlow/utils/tools.py:
@@ -95,7 +142,12 @@ class DevicePrefetcher:
         except StopIteration:
             return None
         with torch.cuda.stream(self.stream):
-            return host.to(self.device, non_blocking=True)
+            dev = host.to(self.device, non_blocking=True)
+            if hasattr(self.loader, "copy_issued"):  # a loader that reuses pinned staging buffers
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                self.loader.copy_issued(ev)
+            return dev
 
     def __iter__(self):
         it = iter(self.loader)
@@ -162,7 +214,13 @@ def run(args, Model, nd):
     train_set = SyntheticTriplets(args.dataset, args.samples, size, seed)
     val_set = SyntheticTriplets(args.dataset, max(args.batch_size, args.samples // 8), size, seed + 10 ** 6)
     sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True) if distributed else None
-    if args.host_data:
+    if args.host_data and getattr(args, "host_cache", False):
+        # the reference's arrangement at volume sizes: the training set resident in host memory, batches gathered into
+        # pinned staging buffers, the H2D copy of the next batch on a side stream under the current step
+        train_data = DevicePrefetcher(HostCachedLoader(train_set, args.batch_size, device, sampler=sampler, shuffle=True,
+                                                       drop_last=True, seed=seed), device)
+        val_data = DeviceTripletLoader(val_set, args.batch_size, device)
+    elif args.host_data:
         # the reference's arrangement (Flow-3D/train.py:84: DataLoader workers + pinned memory), with the H2D copy of
         # the next batch overlapped with the current step
         train_data = DevicePrefetcher(DataLoader(train_set, batch_size=args.batch_size, num_workers=args.workers,
@@ -254,6 +312,9 @@ def add_common_args(parser, nd):
     parser.add_argument('--host_data', action='store_true',
                         help='generate the synthetic triplets on the host and feed them through a DataLoader + '
                              'pinned-memory prefetcher (the reference\'s arrangement) instead of on the GPU')
+    parser.add_argument('--host_cache', action='store_true',
+                        help='with --host_data: keep the whole training set in (pinned) host memory, as the reference\'s '
+                             'load_data does, and gather batches from it (no per-sample generation in the loader)')
     parser.add_argument('--eager', action='store_true',
                         help='N = 1: eager launches per step instead of replaying the step from one HIP graph')
     parser.add_argument('--log_every', type=int, default=10)

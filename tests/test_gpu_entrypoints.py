@@ -136,6 +136,14 @@ def test_device_generated_batches_equal_the_dataloaders():
         pre = list(DevicePrefetcher(DataLoader(ds, batch_size=2, drop_last=True, sampler=sampler, pin_memory=True), dev))
         torch.cuda.synchronize()
         assert len(pre) == len(host) and all(torch.equal(a.cpu(), b) for a, b in zip(pre, host))
+        # round 5: the training set resident in pinned host memory, batches gathered into staging buffers (--host_cache)
+        from opticalflowscivis_amd.trainer import HostCachedLoader
+        sampler.set_epoch(3)
+        cached = list(DevicePrefetcher(HostCachedLoader(ds, 2, dev, sampler=sampler, drop_last=True), dev))
+        torch.cuda.synchronize()
+        assert len(cached) == len(host)
+        for a, b in zip(cached, host):
+            assert a.is_cuda and (float((a.cpu() - b).abs().max()) < 2e-6 if kind == "5jets3d" else torch.equal(a.cpu(), b))
     # without a sampler: a seeded permutation, all samples once, last short batch kept unless drop_last
     ds = SyntheticTriplets("droplet3d", 5, (16,), seed=1)
     assert [b.shape[0] for b in DeviceTripletLoader(ds, 2, dev, shuffle=True)] == [2, 2, 1]
