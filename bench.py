@@ -719,12 +719,8 @@ def main():
     # cannot (the same candidates the final `roofline` record is chosen from); its entry point is the one followed with
     # events inside the timed region
     wsym = by_symbol(wt)
-    wcand = {sym: (ep, sum(r[0] for r in recs)) for sym, (ep, recs) in wsym.items()}
-    for ep, recs in wt.items():
-        rest = sum(r[0] for r in recs if not (len(r) > 4 and r[4]))
-        if rest and (ep.startswith("fs_conv3d") or ep.startswith("fs_warp3d") or ep.startswith("fs_upsample")):
-            wcand.setdefault(ep, (ep, rest))
-    dom_guess = wcand[max(wcand, key=lambda k: wcand[k][1])][0] if wcand else (max(wt, key=lambda k: sum(r[0] for r in wt[k])) if wt else None)
+    dom_sym = max(wsym, key=lambda k: sum(r[0] for r in wsym[k][1])) if wsym else None
+    dom_guess = wsym[dom_sym][0] if dom_sym else (max(wt, key=lambda k: sum(r[0] for r in wt[k])) if wt else None)
     barrier()
     # timed region: only that entry point's launches carry events (~90 of ~430 launches per step), so the headline
     # time is free of profiling overhead while `roofline` is still measured inside the region
@@ -795,16 +791,19 @@ def main():
         ksym = {sym: dict(_aggregate(recs, ksteps), entry_point=ep) for sym, (ep, recs) in by_symbol(ktimes).items()}
         # `roofline` = the dominant hand-written KERNEL (by symbol, as rocprofv3's kernel stats name it); its record
         # comes from the events recorded inside the timed region when its entry point was the one followed there
-        # candidates for the dominant hand-written kernel: every symbol ops.py could name, and per entry point the launches
-        # it could NOT name (several instantiations behind one entry point: filed under the entry point) -- so a symbol is
-        # only reported as dominant when nothing unnamed outweighs it
-        cand = dict(ksym)
+        # `roofline` is the dominant hand-written KERNEL among the symbols ops.py can name (what `rocprofv3 --kernel-trace
+        # --stats` of this command lists first).  Launches it cannot name are filed under their entry point, which may
+        # stand for several kernels: the largest such group and the named kernel's share of the step are reported beside
+        # the record (`named_kernel_share_of_step`, `largest_unnamed_entry_point`), so that a reader sees when the named
+        # kernel is not what dominates
+        unnamed = {}
         for ep, recs in ktimes.items():
             rest = [r for r in recs if not (len(r) > 4 and r[4])]
-            if rest and (ep.startswith("fs_conv3d") or ep.startswith("fs_warp3d") or ep.startswith("fs_upsample")):
-                cand.setdefault(ep, dict(_aggregate(rest, ksteps), entry_point=ep))
-        dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
-        dom_rec = cand[dom]
+            if rest:
+                unnamed[ep] = _aggregate(rest, ksteps)
+        dom = max(ksym, key=lambda k: ksym[k]["ms_per_step"]) if ksym else max(kern, key=lambda k: kern[k]["ms_per_step"])
+        dom_rec = (ksym if ksym else kern)[dom]
+        big_unnamed = max(unnamed, key=lambda k: unnamed[k]["ms_per_step"]) if unnamed else None
         dom_src = "HIP events, separate pass of %d steps after the timed region" % ksteps
         tsym = by_symbol(timed)
         if dom in tsym:
@@ -836,7 +835,12 @@ def main():
                        "parallelism": "dp%d" % world},
             "roofline": dict(roofline(dom, dom_rec, S, B), launches=dom_rec["launches"], avg_ms=dom_rec["avg_ms"],
                              ms_per_step=dom_rec["ms_per_step"], entry_point=dom_rec.get("entry_point", dom),
-                             measured=dom_src),
+                             measured=dom_src,
+                             named_kernel_share_of_step=round(dom_rec["ms_per_step"] / (dt / args.steps * 1e3), 4),
+                             largest_unnamed_entry_point=(None if big_unnamed is None else
+                                                          {"entry_point": big_unnamed, "ms_per_step": unnamed[big_unnamed]["ms_per_step"],
+                                                           "launches_per_step": unnamed[big_unnamed]["launches"] / ksteps,
+                                                           "note": "several kernels behind one entry point, not one kernel"})),
             "roofline_entry_point": dict(roofline(dom_ep, kern[dom_ep], S, B), ms_per_step=kern[dom_ep]["ms_per_step"]),
             # the hot-path row the metric is named after (the trilinear backward warp pair)
             # against the HBM roofline, with its measured HBM traffic per launch; `roofline` above is the
