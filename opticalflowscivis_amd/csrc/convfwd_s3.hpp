@@ -42,8 +42,10 @@ constexpr int S3_ROWB = S3_XP * 4, S3_PIECEB = (S3_YT + 1) * S3_ROWB, S3_INB = 3
 // words of the pre-split weight slab: [channel group of CP][channel pair][kz][piece 3][kyp 2][kh 2][co CP][kx 4]
 inline long long s3_slab_words(int Cin, int CoutP) { return (long long)CoutP * ((Cin + 1) / 2) * 4 * 48; }
 
+// (MT = 1: 78 KB of LDS and <= 80 registers: TWO workgroups per CU -- a layer with 32 output channels has few stages per
+// workgroup (24 at 12 input channels), so one workgroup's prologue / epilogue and stage-start bubbles hide behind the other's MFMAs)
 template <int MT, int NMW, int NLW>
-__global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_s3_kernel(const float* __restrict__ X,
                                                                          const unsigned* __restrict__ Ws,
                                                                          const float* __restrict__ bias,
                                                                          float* __restrict__ Y, FP p) {
@@ -53,8 +55,9 @@ __global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(cons
   constexpr int WB = 192 * CP;                 // bytes of a stage's weight slab
   constexpr int WOFF = 2 * S3_INB;             // LDS: two input stages, then a ring of three weight slabs
   constexpr int NWI = WB / 1024;               // LDS-DMA instructions per weight slab
-  constexpr int NWW = (NWI + NLW - 1) / NLW;   // ... per loader wave (pieces past the slab read zeros into the padding)
-  constexpr int WBP = NWW * NLW * 1024;        // LDS stride of a slab
+  constexpr int NWW = (NWI + NLW - 1) / NLW;   // ... per loader wave (a wave whose piece would lie past the slab copies an earlier
+                                               // piece again: same bytes to the same place, and every wave issues NWW pieces)
+  constexpr int WBP = WB;                      // LDS stride of a slab
   constexpr int RPP = 3 * NLW;                 // rows per loader pass (3 rows of 18 pieces per wave)
   constexpr int PASSES = (S3_YT + RPP - 1) / RPP;
   static_assert(WOFF + 3 * WBP <= 160 * 1024, "the stages fit the CU's LDS");
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(cons
     // the loads of the NEXT stages as well -- the whole prefetch.  The loader's vector-memory traffic is counted by hand
     // instead; `tie` makes every use of a set come after the wait.
     typedef int s3_i32x4 __attribute__((ext_vector_type(4)));
-    s3_u32x4 ld2[2][PASSES][2];  // two register sets: the input pieces of stages s + 1 and s + 2 are in flight
+    s3_u32x4 ld2[MT == 1 ? 1 : 2][PASSES][2];  // register sets of input pieces in flight (MT = 2: stages s + 1 and s + 2)
     auto issue_loads = [&](int s, s3_u32x4 (&ld)[PASSES][2]) {
       const int cp = s >> 2, kz = s & 3;
       const int gz = oz0 * 2 - 1 + kz;
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(cons
       unsigned char* dst = lds + WOFF + (s % 3) * WBP;
 #pragma unroll
       for (int k = 0; k < NWW; ++k) {
-        const int i = lw + NLW * k;
+        int i = lw + NLW * k;
+        if (i >= NWI) i -= NLW;  // (wave-uniform)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + 1024 * i), 16, 1024 * i + 16 * lane, 0, 0, 0);
       }
     };
@@ -176,6 +180,30 @@ __global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(cons
     // The weight slab of a stage is requested a whole stage ahead (a ring of three slabs), its input pieces TWO stages
     // ahead (two register sets).  At the wait of stage s the requests younger than what it needs are the weight pieces of
     // stage s + 1 (NWW) and the input pieces of stage s + 1 (2 PASSES).
+    if constexpr (MT == 1) {
+      // two workgroups per CU (80 registers): ONE register set -- the pieces of stage s + 1 are requested while stage s is
+      // converted; the partner workgroup covers what that leaves exposed
+      s3_u32x4 (&ld)[PASSES][2] = ld2[0];
+      issue_wdma(0);
+      issue_loads(0, ld);
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) {
+          issue_wdma(s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWW) : "memory");   // the pieces of stage s and its weight slab have landed
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        tie(ld);
+#ifdef FS_ABLATION
+        if (!(p.ab & 16))
+#endif
+        convert(s, ld);
+        if (s + 1 < NS) issue_loads(s + 1, ld);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
     auto stage = [&](int s, s3_u32x4 (&ld)[PASSES][2]) {
       issue_wdma(s + 1);                               // (its slab was last read three stages ago)
       __builtin_amdgcn_sched_barrier(0);
@@ -203,6 +231,7 @@ __global__ __launch_bounds__(64 * (NMW + NLW), 1) void conv3d_fwd_s3_kernel(cons
     convert(s + 1, ld2[1]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    }
 #else
     (void)xvol; (void)NWW; (void)PASSES; (void)WBP;
 #endif

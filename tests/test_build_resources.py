@@ -33,19 +33,52 @@ def _resource_usage(src, extra=()):
     return out
 
 
-def _check(usage, needle, max_vgprs):
+def _check(usage, needle, max_vgprs, scratch_ok=False):
     hits = {k: v for k, v in usage.items() if needle in k}
     assert hits, "no kernel matching %r in %s" % (needle, sorted(usage)[:5])
     for name, u in hits.items():
-        assert u.get("ScratchSize [bytes/lane]") == 0 and u.get("VGPRs Spill") == 0, (name, u)
+        if not scratch_ok:
+            assert u.get("ScratchSize [bytes/lane]") == 0 and u.get("VGPRs Spill") == 0, (name, u)
         assert u["VGPRs"] <= max_vgprs, (name, u)
         assert u.get("LDS Size [bytes/block]", 0) <= 160 * 1024, (name, u)
+
+
+def _loader_regions(src, needle, extra=()):
+    """ISA of the loader-wave section (from its `s_setprio 3` to the next `s_endpgm`) of every kernel whose mangled name
+    contains `needle`."""
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+           "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", "-"] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out, name, body = {}, None, []
+    for line in r.stdout.splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name, body = (m.group(1) if needle in m.group(1) else None), []
+            continue
+        if name is None:
+            continue
+        body.append(line)
+        if "s_endpgm" in line and any("s_setprio 3" in b for b in body):
+            start = max(i for i, b in enumerate(body) if "s_setprio 3" in b)
+            out[name] = body[start:]
+            name = None
+    return out
 
 
 def test_hand_counted_wait_kernels_do_not_spill():
     fwd = _resource_usage("convfwd.hip")
     _check(fwd, "conv3d_wino2d_ps_kernel", 256)       # loader waves: inline-asm row loads + LDS-DMA slabs, vmcnt(21/39/12/9)
-    _check(fwd, "conv3d_fwd_s3_kernel", 168)          # round 5: inline-asm input pieces, vmcnt(NWW + 2 PASSES); 12 waves per CU
+    # round 5: inline-asm input pieces with counted waits.  64 channels: 12 waves per CU (168 registers), no scratch at all;
+    # 32 channels: TWO workgroups per CU (80 registers) -- its EPILOGUE spills a few address registers (matrix waves, after the
+    # last barrier), which is harmless, but the loader section must stay free of compiler-made memory traffic
+    _check({k: v for k, v in fwd.items() if "s3_kernelILi2" in k}, "conv3d_fwd_s3_kernel", 168)
+    _check({k: v for k, v in fwd.items() if "s3_kernelILi1" in k}, "conv3d_fwd_s3_kernel", 80, scratch_ok=True)
+    regions = _loader_regions("convfwd.hip", "conv3d_fwd_s3_kernel")
+    assert len(regions) >= 2, sorted(regions)
+    for name, isa in regions.items():
+        bad = [l for l in isa if re.search(r"\bscratch_|\bglobal_load|\bglobal_store|\bflat_", l)]
+        assert not bad, (name, bad[:4])
     w3 = _resource_usage("warp3d.hip", ["-fno-slp-vectorize"])
     _check(w3, "warp3d_fwd_ring_kernel", 128)         # mover waves: counted vmcnt over LDS-DMA flow tiles
     _check(w3, "warp3d_rc_kernel", 168)               # round 5: counted vmcnt over tile DMA, row DMA, addend loads
