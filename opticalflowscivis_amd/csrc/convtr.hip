@@ -49,7 +49,8 @@ struct TP {
   // slices' re-laid-out weights; the output-side pointers move by 32 channels per slice
   long long wslice;
 #ifdef FS_ABLATION
-  int ab = 0;  // measurement switches (FLOWSCI_TR_AB: 4 = the loader-wave kernels skip their epilogue -- wrong results by design)
+  int ab = 0;  // measurement switches (FLOWSCI_TR_AB: 4 = the loader-wave kernels skip their epilogue, 8 / 16 = their loaders re-use
+               // the input brick / weight slab of the first two chunks -- wrong results by design)
 #endif
 };
 
@@ -458,13 +459,18 @@ __device__ __forceinline__ void tr_loader(const float* __restrict__ X, const flo
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(Wt + (size_t)c0 * 64 * CPW), (short)0,
                                                                    0x7fffffff, 0x00020000);
     float* base = lds + buf * BUF;
+#ifdef FS_ABLATION  // measurement: chunks past the second re-use the staged bytes (8: the input brick, 16: the weight slab)
+    const bool skip_x = (p.ab & 8) && c0 >= 2 * CI, skip_w = (p.ab & 16) && c0 >= 2 * CI;
+#else
+    constexpr bool skip_x = false, skip_w = false;
+#endif
 #pragma unroll
     for (int k = 0; k < NXW; ++k)
-      if (256 * (wv + 4 * k) < NXL)  // wave-uniform
+      if (256 * (wv + 4 * k) < NXL && !skip_x)  // wave-uniform
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + 256 * (wv + 4 * k)), 16, xoff[k], 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < NWW; ++k)
-      if (256 * (wv + 4 * k) < NWL)  // wave-uniform
+      if (256 * (wv + 4 * k) < NWL && !skip_w)  // wave-uniform
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + NXL + 256 * (wv + 4 * k)), 16, woff[k], 0, 0, 0);
   };
   stage(0, 0);
