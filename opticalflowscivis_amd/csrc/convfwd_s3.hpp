@@ -132,13 +132,30 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
           asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ld[ps][c]) : "v"(goff[ps]), "s"(r));
       }
     };
-    auto tie = [&](s3_u32x4 (&ld)[PASSES][2]) {
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
-        asm volatile("" : "+v"(ld[ps][0]));
-        asm volatile("" : "+v"(ld[ps][1]));
-      }
+    // wait for EVERYTHING in flight and tie the set's registers to the wait in ONE statement (every use of the set comes
+    // after it; with the tie a statement of its own the compiler may place copies of the registers -- stale data -- in
+    // front of the wait)
+    auto wait_all = [&](s3_u32x4 (&ld)[PASSES][2]) {
+      static_assert(PASSES <= 3, "operand list below");
+      if constexpr (PASSES == 3)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ld[0][0]), "+v"(ld[0][1]), "+v"(ld[1][0]), "+v"(ld[1][1]), "+v"(ld[2][0]), "+v"(ld[2][1]) : : "memory");
+      else if constexpr (PASSES == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ld[0][0]), "+v"(ld[0][1]), "+v"(ld[1][0]), "+v"(ld[1][1]) : : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ld[0][0]), "+v"(ld[0][1]) : : "memory");
     };
+    // The lane offsets of the slab copies live in registers of their own, written once and kept (the empty statement): a
+    // 16-byte LDS-DMA copy reads its address register again after issue and nothing stalls a vector-ALU write to it -- with
+    // the offset in a temporary that the conversion re-used, parts of a copy can come from wherever the temporary points by
+    // then (found in csrc/convtr_s3.hpp; scripts/check_inflight_regs.py checks the compiled code for it)
+    unsigned woff[NWW];
+#pragma unroll
+    for (int k = 0; k < NWW; ++k) {
+      int i = lw + NLW * k;
+      if (i >= NWI) i -= NLW;  // (wave-uniform)
+      woff[k] = (unsigned)(1024 * i + 16 * lane);
+      asm volatile("" : "+v"(woff[k]));
+    }
     auto issue_wdma = [&](int s) {
       // the stage's slab: words [mg][cp][kz] x 48 CP, contiguous
       const unsigned* src = Ws + ((size_t)blockIdx.y * NS + s) * (size_t)(48 * CP);
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
       for (int k = 0; k < NWW; ++k) {
         int i = lw + NLW * k;
         if (i >= NWI) i -= NLW;  // (wave-uniform)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + 1024 * i), 16, 1024 * i + 16 * lane, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + 1024 * i), 16, woff[k], 0, 0, 0);
       }
     };
     auto convert = [&](int s, const s3_u32x4 (&ld)[PASSES][2]) {
@@ -187,14 +204,14 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
       issue_wdma(0);
       issue_loads(0, ld);
       for (int s = 0; s < NS; ++s) {
+        // everything requested so far has landed: the pieces of stage s and its weight slab.  (vmcnt(0), and the next slab
+        // requested BEHIND it: a count that lets younger slab copies stay in flight assumes that copies and register loads
+        // complete in the order they were issued -- they do not, csrc/convtr_s3.hpp.)  One statement with the tie: see tie.
+        wait_all(ld);
         if (s + 1 < NS) {
           issue_wdma(s + 1);
           __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWW) : "memory");   // the pieces of stage s and its weight slab have landed
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        tie(ld);
 #ifdef FS_ABLATION
         if (!(p.ab & 16))
 #endif
@@ -205,10 +222,11 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
       }
     } else {
     auto stage = [&](int s, s3_u32x4 (&ld)[PASSES][2]) {
+      // the pieces of stage s (requested two stages ago) and its slab have landed; so have, as a rule, the pieces of stage
+      // s + 1, a stage old: vmcnt(0) instead of a count that would rely on copies and loads completing in issue order
+      wait_all(ld);
       issue_wdma(s + 1);                               // (its slab was last read three stages ago)
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWW + 2 * PASSES) : "memory");
-      tie(ld);
 #ifdef FS_ABLATION
       if (!(p.ab & 16))  // (measurement: no conversion / LDS writes -- FLOWSCI_S3_AB=16)
 #endif
@@ -226,12 +244,15 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
       stage(s + 1, ld2[1]);
     }
     stage(s, ld2[0]);                                  // s = NS - 2: no more input pieces to request
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last stage: everything has landed
-    tie(ld2[1]);
+    wait_all(ld2[1]);                                  // last stage: everything has landed
     convert(s + 1, ld2[1]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     }
+    // (a use of the copies' address registers behind the last wait: their registers are not handed to anything else while
+    // a copy may still read them)
+#pragma unroll
+    for (int k = 0; k < NWW; ++k) asm volatile("" ::"v"(woff[k]));
 #else
     (void)xvol; (void)NWW; (void)PASSES; (void)WBP;
 #endif

@@ -487,6 +487,8 @@ __device__ __forceinline__ void tr_loader(const float* __restrict__ X, const flo
 #endif
 }
 
+#include "convtr_s3.hpp"
+
 template <int TZ, int TY>
 __global__ __launch_bounds__(512, 2) void convtr_mfma_ws_kernel(const float* __restrict__ X,
                                                              const float* __restrict__ Wt_,
@@ -960,16 +962,23 @@ __global__ __launch_bounds__(512, 2) void convtr_p8_kernel(const float* __restri
 #endif
 }
 
+// CUs of the device the call runs on (per-device table: a process may drive several GPUs; an int store is the only shared write)
+static int tr_ncu() {
+  static int ncu_of[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int ncu = ncu_of[dev];
+  if (ncu == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    ncu_of[dev] = ncu = n;
+  }
+  return ncu;
+}
+
 template <int RT, int NT, int CINP = 32>
 void launch_p8(const float* x, const float* ws, const float* bias, float* y, const TP& p, hipStream_t st) {
-  static int ncu = 0;  // one persistent workgroup per CU
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-      n = 256;
-    ncu = n;
-  }
+  const int ncu = tr_ncu();  // one persistent workgroup per CU
   const long long nwg = p.tiles < ncu ? p.tiles : ncu;
   const int per = (int)((p.tiles + nwg - 1) / nwg);
   const unsigned grid = (unsigned)((p.tiles + per - 1) / per);
@@ -1078,7 +1087,8 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   const long long cinp = (Cin + 3) / 4 * 4;
   // W'[ci][neighbour][row] (+ pad) of the all-parities kernel (<= 12 channels), or the slabs of the class kernels
   const long long p8 = Cout <= 12 ? cinp * p8_ws_ci(Cout <= 2 ? 1 : (Cout <= 6 ? 3 : 6)) : 0;
-  const long long cls = Cout <= 6 ? 0 : cinp * 64 * (Cout <= 16 ? 16 : 32);
+  long long cls = Cout <= 6 ? 0 : cinp * 64 * (Cout <= 16 ? 16 : 32);
+  if (Cout > 16 && t3_slab_words(Cin) > cls) cls = t3_slab_words(Cin);  // the split-bf16 slab (convtr_s3.hpp)
   return (p8 > cls ? p8 : cls) * slices;
 }
 
@@ -1170,6 +1180,29 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
     else
       hipLaunchKernelGGL((convtr_mfma16_kernel<2, 2>), dim3((unsigned)p.tiles), dim3(256), 0, st, x, ws, bias, y, p);
   } else {
+    // round 5: fp32 accuracy on the bf16 matrix rate (three bf16 pieces per operand, six products: convtr_s3.hpp) where the
+    // output is exactly twice the input, rows are 16-byte pieces and the 2 x 3 x 32-position bricks fill the chip
+    static const bool no_s3 = FS_AB_ENV("FLOWSCI_TR_NO_S3");
+    const long long t3 = (long long)B * fs::cdiv(Di, T3_TZ) * fs::cdiv(Hi, T3_TY) * fs::cdiv(Wi, T3_TW);
+    if (!no_s3 && !reg_only && Dout == 2 * Di && Hout == 2 * Hi && Wout == 2 * Wi && Wi % 4 == 0 &&
+        (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && (long long)Di * Hi * Wi * 4 < (1ll << 31) && t3 * slices >= 256 &&
+        t3 < (1ll << 31)) {
+      p.wslice = t3_slab_words(Cin);
+      for (int sl = 0; sl < slices; ++sl)
+        wprep_do(wprep_job(FS_WPREP_TRS3, w ? w + (size_t)sl * 32 * 64 : nullptr, ws + (size_t)sl * p.wslice, p.wslice, Cin,
+                           Cout, (Cin + 3) / 4, p.CoutT), plan, st);
+      if (plan != nullptr) return FS_OK;
+      p.tz = fs::cdiv(Di, T3_TZ); p.ty = fs::cdiv(Hi, T3_TY); p.tx = fs::cdiv(Wi, T3_TW);
+      p.tiles = t3;
+      // persistent workgroups: one per CU over all slices
+      const int ncu = tr_ncu();
+      long long gx = ncu / slices < 1 ? 1 : ncu / slices;
+      if (gx > p.tiles) gx = p.tiles;
+      hipLaunchKernelGGL(convtr_s3_kernel, dim3((unsigned)gx, slices), dim3(64 * (T3_NMW + T3_NLW)), 0, st, x,
+                         reinterpret_cast<const unsigned*>(ws), bias, y, p);
+      FS_LAUNCH_CHECK();
+      return FS_OK;
+    }
     p.wslice = (long long)cinp * 64 * 32;
     for (int sl = 0; sl < slices; ++sl)
       wprep_do(wprep_job(FS_WPREP_TR32, w ? w + (size_t)sl * 32 * 64 : nullptr, ws + (size_t)sl * p.wslice, p.wslice, Cin,

@@ -82,3 +82,39 @@ def test_hand_counted_wait_kernels_do_not_spill():
     w3 = _resource_usage("warp3d.hip", ["-fno-slp-vectorize"])
     _check(w3, "warp3d_fwd_ring_kernel", 128)         # mover waves: counted vmcnt over LDS-DMA flow tiles
     _check(w3, "warp3d_rc_kernel", 168)               # round 5: counted vmcnt over tile DMA, row DMA, addend loads
+
+
+def _device_asm(src, tmp_path, extra=()):
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("needs hipcc")
+    out = str(tmp_path / (src.replace(".hip", "") + ".s"))
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+           "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out
+
+
+def test_split_bf16_loaders_touch_no_register_or_address_in_flight(tmp_path):
+    """Round 5 (found while the transposed split-bf16 kernel was brought up): in the loader waves of the
+    split-bf16 kernels the compiled code must (1) never READ a register between the inline-assembly load that targets it
+    and the hand-counted wait that covers it -- the compiler is free to copy such a register -- and (2) never WRITE the
+    address register of a 16-byte LDS-DMA copy that may still be in flight.  Both are checked on the device assembly of
+    THIS build (scripts/check_inflight_regs.py simulates the request queue); the transposed kernel's loaders must also be
+    free of compiler-made scratch traffic (it would be counted by their vmcnt waits)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import check_inflight_regs as chk
+    fwd = _device_asm("convfwd.hip", tmp_path)
+    assert chk.check(fwd, "conv3d_fwd_s3_kernel") == 0
+    assert chk.check_dma_addr(fwd, "conv3d_fwd_s3_kernel") == 0
+    tr = _device_asm("convtr.hip", tmp_path)
+    assert chk.check(tr, "convtr_s3_kernel") == 0
+    assert chk.check_dma_addr(tr, "convtr_s3_kernel") == 0
+    regions = _loader_regions("convtr.hip", "convtr_s3_kernel")
+    assert len(regions) == 1, sorted(regions)
+    for name, isa in regions.items():
+        bad = [l for l in isa if re.search(r"\bscratch_|\bglobal_load|\bglobal_store|\bflat_", l)]
+        assert not bad, (name, bad[:4])
+    usage = _resource_usage("convtr.hip")
+    _check(usage, "convtr_s3_kernel", 168, scratch_ok=True)  # (a few epilogue address registers spill: matrix waves only)

@@ -938,3 +938,52 @@ def test_conv3d_fwd_split_bf16_kernel_vs_fp64(ops, cin, cout, size, form):
         n = float(ref[0, 0].numel() * B) ** 0.5
         assert float((ga.cpu().double() - gar).abs().max()) < 2e-5 * max(1.0, float(gar.abs().max())) + 1e-5 * n * scale
         assert float((gb.cpu().double() - gbr).abs().max()) < 2e-5 * max(1.0, float(gbr.abs().max())) + 1e-5 * n * scale
+
+
+def _tr_slab_kinds(x, w, cout, has_z):
+    """FsWprepJob kinds the library's dispatch picks for an fs_conv3d_tr call (8 = the pre-split bf16 slab of
+    csrc/convtr_s3.hpp, 1 = the fp32 taps of the 32-row class kernel)."""
+    from opticalflowscivis_amd import _lib
+    L = _lib.lib()
+    buf = (_lib.FsWprepJob * 8)()
+    B, cin, D, H, W = x.shape
+    ws = torch.empty(int(L.fs_conv3d_tr_ws_floats(cin, cout)), device=DEV)
+    n = L.fs_conv3d_tr_wprep_jobs(buf, 8, x.data_ptr(), w.data_ptr(), ws.data_ptr(), B, cin, cout, D, H, W, 2 * D, 2 * H, 2 * W,
+                                  int(has_z))
+    assert n >= 1
+    return [buf[i].kind for i in range(n)]
+
+
+@pytest.mark.parametrize("cin,cout,size,form", [
+    (64, 32, (32, 48, 32), "prelu"),     # deconv1 of a head: bias + PReLU output
+    (10, 32, (32, 50, 36), "plain"),     # channel count not a multiple of the 4-channel stage; ragged y / x bricks
+    (16, 20, (34, 48, 32), "add"),       # fewer than 32 output channels, odd number of z bricks, residual addend
+    (8, 64, (32, 24, 32), "prelu"),      # two 32-channel slices in one launch
+])
+def test_conv3d_tr_split_bf16_kernel_vs_fp64(ops, cin, cout, size, form):
+    """Round 5: ConvTranspose3d(4, 2, 1) / the input gradient of Conv3d(4, 2, 1) with fp32 accuracy on the bf16 matrix rate
+    (csrc/convtr_s3.hpp).  Against an fp64 transposed convolution at the tolerance of the fp32 kernels, in every epilogue form
+    it is launched with; the library's dispatch must really have taken it (slab kind 8)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(cin * 5 + cout + size[1])
+    B = 2
+    x = torch.randn((B, cin) + size, generator=g)
+    w = torch.randn(cin, cout, 4, 4, 4, generator=g) / (cin * 8) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    assert set(_tr_slab_kinds(xd, wd, cout, form == "prelu")) == {8}
+    ref = F.conv_transpose3d(x.double(), w.double(), bias.double(), 2, 1)
+    scale = float(ref.abs().max())
+    if form == "plain":
+        y = ops.conv3d_tr(xd, wd, bd)
+        assert float((y.cpu().double() - ref).abs().max()) < 3e-6 * scale
+    elif form == "add":
+        add = torch.randn(ref.shape, generator=g)
+        y = ops.conv3d_tr(xd, wd, bd, None, None, add.to(DEV))
+        assert float((y.cpu().double() - (ref + add.double())).abs().max()) < 3e-6 * max(scale, 4.0)
+    else:
+        slope = torch.rand(cout, generator=g) * 0.5
+        y, z = ops.conv3d_tr(xd, wd, bd, None, slope.to(DEV))
+        zr = torch.where(ref > 0, ref, ref * slope.double().view(1, -1, 1, 1, 1))
+        assert float((y.cpu().double() - ref).abs().max()) < 3e-6 * scale
+        assert float((z.cpu().double() - zr).abs().max()) < 3e-6 * scale
