@@ -827,8 +827,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             # every tensor and every accumulation is fp32; one kernel family multiplies on the bf16 matrix cores without
             # giving up fp32 accuracy (error vs fp64 <= the fp32 MFMA kernels': profiles/r05_split_bf16.txt)
-            "arithmetic": "fp32; the k4 s2 forward convolutions (conv3d_fwd_s3_kernel) multiply fp32 operands as 3 bf16 pieces, "
-                          "6 products, fp32 accumulate",
+            "arithmetic": "fp32; the k4 s2 forward convolutions (conv3d_fwd_s3_kernel) and the 17..32-channel transposed ones "
+                          "(convtr_s3_kernel) multiply fp32 operands as 3 bf16 pieces, 6 products, fp32 accumulate",
             "config": {"workload": "Flow-3D %s %d^3, batch %d per GPU, IFNet-3D random init, "
                                    "3D trilinear warp HIP kernels" % (args.dataset, S, B),
                        "global_batch": world * B, "volume": [S, S, S],

@@ -50,7 +50,7 @@ RULES = [  # (substring of the kernel name, entry point, counts as a launch of t
 ]
 # kernel SYMBOLS bench.py's `roofline` may name (ops.py labels their launches): traffic per launch of the symbol itself
 SYMBOLS = ["conv3d_wino2d_ps_kernel<0, 16>", "conv3d_wino2d_ps_kernel<0, 8>", "conv3d_wrw_wino4_kernel<0>",
-           "conv3d_fwd_s3_kernel<1, 8, 4>", "conv3d_fwd_s3_kernel<2, 8, 4>",
+           "conv3d_fwd_s3_kernel<1, 8, 4>", "conv3d_fwd_s3_kernel<2, 8, 4>", "convtr_s3_kernel",
            "warp3d_rc_kernel<true, 4, 5, 0>", "warp3d_rc_kernel<false, 2, 6, 0>"]
 ADJOINT = ("up_adjoint_fused_kernel", "interp_axis_adjoint_kernel", "interp3d_up_adjoint")  # kernels of fs_interp3d_bwd_scaled
 WARP_BWD_ORDER = ["fs_warp3d_pair_bwd", "fs_warp3d_pair_bwd_acc3", "fs_upsample_warp3d_pair_bwd3",
