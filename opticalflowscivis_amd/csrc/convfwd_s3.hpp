@@ -127,6 +127,10 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
         r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
         r[2] = __builtin_amdgcn_readfirstlane(live ? (int)planeB : 0);
         r[3] = 0x00020000;
+        // (s_nop 4: the resource words come from v_readfirstlane, and a vector-memory instruction must not read a scalar
+        // register within 5 cycles of a vector-ALU write to it -- the compiler inserts such wait states for its own
+        // instructions, not for text inside an asm statement)
+        asm volatile("s_nop 4" ::"s"(r));
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps)
           asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ld[ps][c]) : "v"(goff[ps]), "s"(r));

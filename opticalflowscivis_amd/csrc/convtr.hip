@@ -1088,7 +1088,8 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   // W'[ci][neighbour][row] (+ pad) of the all-parities kernel (<= 12 channels), or the slabs of the class kernels
   const long long p8 = Cout <= 12 ? cinp * p8_ws_ci(Cout <= 2 ? 1 : (Cout <= 6 ? 3 : 6)) : 0;
   long long cls = Cout <= 6 ? 0 : cinp * 64 * (Cout <= 16 ? 16 : 32);
-  if (Cout > 16 && t3_slab_words(Cin) > cls) cls = t3_slab_words(Cin);  // the split-bf16 slab (convtr_s3.hpp)
+  if (Cout > 16 && t3_slab_words(Cin) > cls) cls = t3_slab_words(Cin);  // the split-bf16 slabs (convtr_s3.hpp)
+  if (Cout > 6 && Cout <= 16 && t3_slab_words16(Cin) > cls) cls = t3_slab_words16(Cin);
   return (p8 > cls ? p8 : cls) * slices;
 }
 
@@ -1172,7 +1173,24 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   // its staging with its MFMAs, two half-empty 4-wave workgroups do not.  `FLOWSCI_TR_REG=1`: the register-staged kernels.
   const bool ws_ok = !reg_only && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && p.tiles * slices >= 128 &&
                      (long long)4 * Di * Hi * Wi * 4 < (1ll << 31);
+  static const bool no_s3 = FS_AB_ENV("FLOWSCI_TR_NO_S3");
+  const long long t3 = (long long)B * fs::cdiv(Di, T3_TZ) * fs::cdiv(Hi, T3_TY) * fs::cdiv(Wi, T3_TW);
+  const bool t3_ok = !no_s3 && !reg_only && Dout == 2 * Di && Hout == 2 * Hi && Wout == 2 * Wi && Wi % 4 == 0 &&
+                     (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && (long long)Di * Hi * Wi * 4 < (1ll << 31) &&
+                     t3 * slices >= 256 && t3 < (1ll << 31) && (long long)32 * Dout * Hout * Wout * 4 < (1ll << 32);
   if (Cout <= 16) {
+    if (t3_ok && slices == 1) {  // round 5: the 16-row split-bf16 form (convtr_s3.hpp)
+      wprep_do(wprep_job(FS_WPREP_TRS3_16, w, ws, t3_slab_words16(Cin), Cin, Cout, (Cin + 3) / 4, p.CoutT), plan, st);
+      if (plan != nullptr) return FS_OK;
+      p.tz = fs::cdiv(Di, T3_TZ); p.ty = fs::cdiv(Hi, T3_TY); p.tx = fs::cdiv(Wi, T3_TW);
+      p.tiles = t3;
+      const int ncu = tr_ncu();
+      const long long gx = ncu < p.tiles ? ncu : p.tiles;
+      hipLaunchKernelGGL(convtr_s3_kernel<true>, dim3((unsigned)gx, 1), dim3(64 * (T3_NMW + T3_NLW)), 0, st, x,
+                         reinterpret_cast<const unsigned*>(ws), bias, y, p);
+      FS_LAUNCH_CHECK();
+      return FS_OK;
+    }
     wprep_do(wprep_job(FS_WPREP_TR16, w, ws, (long long)cinp * 64 * 16, Cin, Cout, cinp), plan, st);
     if (plan != nullptr) return FS_OK;
     if (ws_ok)
@@ -1182,11 +1200,7 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   } else {
     // round 5: fp32 accuracy on the bf16 matrix rate (three bf16 pieces per operand, six products: convtr_s3.hpp) where the
     // output is exactly twice the input, rows are 16-byte pieces and the 2 x 3 x 32-position bricks fill the chip
-    static const bool no_s3 = FS_AB_ENV("FLOWSCI_TR_NO_S3");
-    const long long t3 = (long long)B * fs::cdiv(Di, T3_TZ) * fs::cdiv(Hi, T3_TY) * fs::cdiv(Wi, T3_TW);
-    if (!no_s3 && !reg_only && Dout == 2 * Di && Hout == 2 * Hi && Wout == 2 * Wi && Wi % 4 == 0 &&
-        (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 && (long long)Di * Hi * Wi * 4 < (1ll << 31) && t3 * slices >= 256 &&
-        t3 < (1ll << 31)) {
+    if (t3_ok) {
       p.wslice = t3_slab_words(Cin);
       for (int sl = 0; sl < slices; ++sl)
         wprep_do(wprep_job(FS_WPREP_TRS3, w ? w + (size_t)sl * 32 * 64 : nullptr, ws + (size_t)sl * p.wslice, p.wslice, Cin,
@@ -1198,7 +1212,7 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
       const int ncu = tr_ncu();
       long long gx = ncu / slices < 1 ? 1 : ncu / slices;
       if (gx > p.tiles) gx = p.tiles;
-      hipLaunchKernelGGL(convtr_s3_kernel, dim3((unsigned)gx, slices), dim3(64 * (T3_NMW + T3_NLW)), 0, st, x,
+      hipLaunchKernelGGL(convtr_s3_kernel<false>, dim3((unsigned)gx, slices), dim3(64 * (T3_NMW + T3_NLW)), 0, st, x,
                          reinterpret_cast<const unsigned*>(ws), bias, y, p);
       FS_LAUNCH_CHECK();
       return FS_OK;

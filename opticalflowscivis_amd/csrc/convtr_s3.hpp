@@ -37,21 +37,34 @@ constexpr int T3_NQ = T3_XP / 4;                                  // 16-byte pie
 constexpr int T3_ROWB = T3_XP * 8;                                // bytes per staged row of one piece image (4 bf16 per position)
 constexpr int T3_PIECEB = (T3_NROW + 1) * T3_ROWB;                // (+1: a spare row for the idle loader lanes)
 constexpr int T3_INB = 3 * T3_PIECEB;
-constexpr int T3_WB = 8 * 2 * 3 * 1024;                           // bytes of a stage's weight slab: [class][z tap][piece] x 1 KB
-constexpr int T3_WORDS = T3_WB / 4;
+constexpr int T3_WB32 = 8 * 2 * 3 * 1024;                         // bytes of a stage's weight slab: [class][z tap][piece] x 1 KB
+constexpr int T3_WORDS32 = T3_WB32 / 4;
 static_assert(T3_NROW * T3_NQ <= 64 * T3_NLW, "one (row, piece) item per loader lane");
 
 // 4-byte words of the pre-split slab of ONE 32-channel slice
-inline long long t3_slab_words(int Cin) { return (long long)((Cin + 3) / 4) * T3_WORDS; }
+inline long long t3_slab_words(int Cin) { return (long long)((Cin + 3) / 4) * T3_WORDS32; }
+// ... of the 16-row form (7..16 output channels): [stage][class 8][piece 3] x 1 KB = [x/y tap 4][co 16][z tap 2][channel 4]
+constexpr int T3_WB16 = 8 * 3 * 1024;
+inline long long t3_slab_words16(int Cin) { return (long long)((Cin + 3) / 4) * (T3_WB16 / 4); }
 
+// M16: the 16-row form for 7..16 output channels (the input gradient of conv0[0], 32 -> 11 / 12): v_mfma_f32_16x16x32_bf16,
+// whose 32 reduction elements are ALL eight taps of a class x 4 channels -- the lane quarter `kq` takes the (y tap, x tap)
+// pair, a lane's 8 values are the 4 channels at the two z taps (two ds_read_b64 of the same LDS image); a wave's 6 row tiles
+// become 12 tiles of 16 positions (48 accumulator registers).  Same loaders, same stages, half the slab.
+template <bool M16>
 __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(const float* __restrict__ X,
                                                                              const unsigned* __restrict__ Ws_,
                                                                              const float* __restrict__ bias_,
                                                                              float* __restrict__ Y_, TP p) {
   constexpr int NMW = T3_NMW, NLW = T3_NLW;
   constexpr int WOFF = 2 * T3_INB;
+  constexpr int T3_WB = M16 ? T3_WB16 : T3_WB32;  // (this instantiation's stage slab)
+  [[maybe_unused]] constexpr int T3_WORDS = T3_WB / 4;
   constexpr int NWW = T3_WB / 1024 / NLW;  // LDS-DMA instructions per weight slab and loader wave
-  constexpr int STGB = 4 * 256 * 16;       // staging area of the loader waves: [channel][item] x 16 bytes
+  constexpr int STG1 = 4 * 256 * 16;       // one staging area of the loader waves: [channel][item] x 16 bytes
+  constexpr int NSTG = M16 ? 2 : 1;        // the 16-row form has the LDS for two: bricks requested TWO stages ahead (its
+                                           // stages are half as long: with one, the loaders' request -> convert chain was the period)
+  constexpr int STGB = NSTG * STG1;
   static_assert(WOFF + 2 * T3_WB + STGB + 256 <= 160 * 1024, "the stages fit the CU's LDS");
   __shared__ __attribute__((aligned(16))) unsigned char lds[WOFF + 2 * T3_WB + STGB + 256];
   float* const sBias = reinterpret_cast<float*>(lds + WOFF + 2 * T3_WB + STGB);  // [32] bias, [32] PReLU slopes: a global
@@ -102,29 +115,44 @@ __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(co
     // whatever the source looked like (tied operands, live-range splits) -- stale data whenever memory was slow.  In LDS there
     // is nothing to copy, and the reads are ordinary ds_read the compiler waits for by itself.
     unsigned char* const stg = lds + WOFF + 2 * T3_WB + (lw * 64 + lane) * 16;
-    int l_i = 0, l_s = 0, l_b = 0;   // the request stream's (brick, stage) position: one stage ahead of the conversion
-    unsigned goff = DMA_OOB;
+    int l_i = 0, l_s = 0, l_b = 0;   // the request stream's (brick, stage) position: NSTG stages ahead of the conversion
+    // Two address registers, one per brick parity (`goff` of brick i is written while only copies of brick i - 1 can be in
+    // flight, which use the other one): a 16-byte LDS-DMA reads its address register again after issue -- see woff below --
+    // so a register may only change when no copy that uses it is in flight
+    unsigned goffA = DMA_OOB, goffB = DMA_OOB;
     auto l_brick = [&]() {
       int qz0, qy0, qx0;
       brick_origin(l_i, l_b, qz0, qy0, qx0);
       const int gz = qz0 - 1 + zr, gy = qy0 - 1 + yr, gx = qx0 - 4 + 4 * jq;
       const bool ok = act && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx + 3 < p.Wi;
-      goff = ok ? (((unsigned)gz * (unsigned)p.Hi + (unsigned)gy) * (unsigned)p.Wi + (unsigned)gx) * 4u : DMA_OOB;
+      const unsigned v = ok ? (((unsigned)gz * (unsigned)p.Hi + (unsigned)gy) * (unsigned)p.Wi + (unsigned)gx) * 4u : DMA_OOB;
+      if (l_i & 1) goffB = v; else goffA = v;
     };
     l_brick();
-    // (`goff` is written only by l_brick, which runs behind a vmcnt(0): a 16-byte LDS-DMA reads its address register again
-    // after issue -- see woff below -- so no copy that uses it may be in flight when it changes)
-    auto issue_stage = [&]() {
+    auto issue_stage = [&](int sbuf) {
+      unsigned char* const dst = lds + WOFF + 2 * T3_WB + sbuf * STG1 + lw * 64 * 16;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int ch = 4 * l_s + c;
         const int chc = ch < p.Cin ? ch : 0;
-        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(X + ((size_t)l_b * p.Cin + chc) * xvol), (short)0,
-                                                                      ch < p.Cin ? (int)volB : 0, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(lds + WOFF + 2 * T3_WB + (c * 256 + lw * 64) * 16), 16, goff, 0, 0, 0);
+        // (inline assembly: through the builtin the compiler selects between the two registers into a TEMPORARY and hands
+        // that to the copy -- and re-uses the temporary a few instructions later.  s_nop 4: the resource words may come from
+        // v_readfirstlane, and a vector-memory instruction must not read a scalar register within 5 cycles of a vector-ALU
+        // write to it -- a hazard the compiler handles for its own instructions, not for text inside an asm statement)
+        const unsigned long long a = (unsigned long long)(X + ((size_t)l_b * p.Cin + chc) * xvol);
+        t3_i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+        r[2] = __builtin_amdgcn_readfirstlane(ch < p.Cin ? (int)volB : 0);
+        r[3] = 0x00020000;
+        const unsigned m0v = (unsigned)(unsigned long long)(lds_ptr_t)(dst + c * 4096);
+        if (l_i & 1)
+          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(goffB), "s"(r) : "memory");
+        else
+          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(goffA), "s"(r) : "memory");
       }
     };
-    auto advance = [&]() {  // the next request position; a new brick's offsets (call only with no staging copy in flight)
+    auto advance = [&]() {  // the next request position (a new brick's offsets go to the register of ITS parity)
       if (++l_s == NS) { l_s = 0; if (l_i + 1 < nbr) { ++l_i; l_brick(); } }
     };
     // The lane offsets of the slab copies live in NWW registers of their own, written ONCE: with a single register
@@ -181,27 +209,36 @@ __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(co
     //   the slab of stage g is requested (into the weight buffer stage g - 2 has left), THEN the brick of stage g + 1 (the
     //   staging slots are free: this wave alone reads them, and has); the items are split and parked as stage g's image;
     //   vmcnt(4): copies complete in the order they were issued, so the slab is in, the four brick copies may still fly.
+    // (NSTG = 2: vmcnt(4) at the top lets the brick of stage g + 1 fly -- copies complete in the order they were issued --,
+    // the brick of stage g + 2 is requested into the staging area just read, and vmcnt(4) at the bottom has the slab and
+    // stage g + 1's brick in)
     const int total = nbr * NS;
-    issue_stage();
+    issue_stage(0);
+    if constexpr (NSTG == 2) {
+      if (total > 1) { advance(); issue_stage(1); }
+    }
     int s = 0;
     for (int g = 0; g < total; ++g) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (NSTG == 2 && g + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       t3_u32x4 ld[4];
+      const unsigned char* sp = stg + (NSTG == 2 ? (g & 1) * STG1 : 0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) ld[c] = *reinterpret_cast<const t3_u32x4*>(stg + c * 4096);
+      for (int c = 0; c < 4; ++c) ld[c] = *reinterpret_cast<const t3_u32x4*>(sp + c * 4096);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       issue_wdma(s, g & 1);
-      if (g + 1 < total) {
-        advance();       // (position g's copies are complete: the address register may change)
-        issue_stage();
+      const bool more = g + NSTG < total;
+      if (more) {
+        advance();
+        issue_stage(NSTG == 2 ? (g & 1) : 0);
       }
       __builtin_amdgcn_sched_barrier(0);
 #ifdef FS_ABLATION
       if (!(p.ab & 32))
 #endif
       convert(g & 1, ld);
-      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -213,6 +250,133 @@ __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(co
     return;
   }
 
+  // ---- matrix waves, 16-row form: wave = (pz, py, z row g), both x parities of three y rows = 12 tiles of 16 positions
+  if constexpr (M16) {
+    typedef float t3_f32x4 __attribute__((ext_vector_type(4)));
+    const int cg = wave & 3, g = wave >> 2;
+    const int pz = cg >> 1, py = cg & 1;
+    const int n16 = lane & 15, kq = lane >> 4, ay = kq >> 1, ax = kq & 1;
+    if (t < 32) {
+      sBias[t] = (bias != nullptr && t < p.Cout) ? bias[t] : 0.f;
+      sSlope[t] = (p.Z != nullptr) ? p.slope[p.nslope == 1 ? 0 : (t < p.Cout ? t : 0)] : 0.f;
+    }
+    // input: position (z row g + dz, y row 0 + py - ay, x = n16 + px - ax) of a piece image; weights: slot (kq, co = n16)
+    const unsigned bO = (unsigned)(((g + 1) * T3_YT + (1 + py - ay)) * T3_ROWB + (n16 + 4 - ax) * 8);
+    const unsigned aO = (unsigned)(WOFF + (cg * 2) * 3 * 1024 + (kq * 16 + n16) * 16);
+    const int dz0 = pz * T3_YT * T3_ROWB, dz1 = (pz - 1) * T3_YT * T3_ROWB;  // the two z taps
+    const size_t yvol = (size_t)p.Dout * p.Hout * p.Wout;
+    int gs = 0;
+    for (int bi = 0; bi < nbr; ++bi) {
+      t3_f32x4 acc[2][T3_TY][2];
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int y = 0; y < T3_TY; ++y)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) acc[px][y][h] = t3_f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < NS; ++s, ++gs) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sb = lds + (gs & 1) * T3_INB + bO;
+        const unsigned char* sw = lds + (gs & 1) * T3_WB + aO;
+#ifdef FS_ABLATION
+        if (p.ab & 64) continue;
+#endif
+        // operands of tile i + 1 are read before the MFMAs of tile i (two register sets; the scheduling barriers keep the
+        // compiler from hoisting ALL 36 operand reads of a stage to its top: 45 spilled registers)
+        auto read_b = [&](int px, int i, t3_bf16x8 (&bq)[3]) {
+          const int y = i >> 1, h = i & 1;
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            const unsigned char* q = sb + pc * T3_PIECEB + y * T3_ROWB + (16 * h + px) * 8;
+            const t3_u32x2 lo = *reinterpret_cast<const t3_u32x2*>(q + dz0), hi = *reinterpret_cast<const t3_u32x2*>(q + dz1);
+            const t3_u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+            bq[pc] = __builtin_bit_cast(t3_bf16x8, v);
+          }
+        };
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          t3_bf16x8 a[3], b0[3], b1[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            a[pc] = __builtin_bit_cast(t3_bf16x8, *reinterpret_cast<const t3_u32x4*>(sw + (px * 3 + pc) * 1024));
+          read_b(px, 0, b0);
+          constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+          for (int i = 0; i < 2 * T3_TY; i += 2) {
+            read_b(px, i + 1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef FS_ABLATION
+            if (!(p.ab & 128))
+#endif
+#pragma unroll
+            for (int q6 = 0; q6 < 6; ++q6)
+              acc[px][i >> 1][i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q6]], b0[PB[q6]], acc[px][i >> 1][i & 1], 0, 0, 0);
+            if (i + 2 < 2 * T3_TY) read_b(px, i + 2, b0);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef FS_ABLATION
+            if (!(p.ab & 128))
+#endif
+#pragma unroll
+            for (int q6 = 0; q6 < 6; ++q6)
+              acc[px][(i + 1) >> 1][(i + 1) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q6]], b1[PB[q6]], acc[px][(i + 1) >> 1][(i + 1) & 1], 0, 0, 0);
+          }
+        }
+      }
+#ifdef FS_ABLATION
+      if (p.ab & 4) continue;
+#endif
+      // ---- epilogue: lane = position n16 of a half row, its four registers = channels 4 kq .. 4 kq + 3; the two x parities
+      // of a channel are neighbours in memory (8 bytes), one quad exchange makes 16-byte stores as in the 32-row form
+      int b, qz0, qy0, qx0;
+      brick_origin(bi, b, qz0, qy0, qx0);
+      const int qz = qz0 + g;
+      if (qz >= p.Dq) continue;
+      const unsigned yv = (unsigned)yvol;
+      const size_t sb0 = (size_t)b * p.CoutT * yvol;
+      float* const yb = Y + sb0;
+      const float* const ab = p.addend != nullptr ? p.addend + (Y - p.Ybase) + sb0 : nullptr;
+      float* const zb = p.Z != nullptr ? p.Z + sb0 : nullptr;
+      int kqe = kq;
+      asm volatile("" : "+v"(kqe));
+      const bool evn = (n16 & 1) == 0;
+#pragma unroll
+      for (int y = 0; y < T3_TY; ++y) {
+        const int qy = qy0 + y;
+        if (qy >= p.Hq) break;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int qx = qx0 + 16 * h + n16, qxe = evn ? qx : qx - 1;
+          const bool xin = qxe < p.Wq;
+          const unsigned lo = 4u * (unsigned)kqe * yv + ((unsigned)(2 * qz + pz) * (unsigned)p.Hout + (unsigned)(2 * qy + py)) * (unsigned)p.Wout + 2u * (unsigned)qxe;
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const float a0 = acc[0][y][h][r], a1 = acc[1][y][h][r], b0 = acc[0][y][h][r + 1], b1 = acc[1][y][h][r + 1];
+            const float s0 = evn ? b0 : a0, s1 = evn ? b1 : a1;
+            const float r0 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s0), 0xB1, 0xF, 0xF, false));
+            const float r1 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s1), 0xB1, 0xF, 0xF, false));
+            float4 o = evn ? make_float4(a0, a1, r0, r1) : make_float4(r0, r1, b0, b1);
+            const int rr = evn ? r : r + 1;
+            const int co = 4 * kqe + rr;
+            if (co >= p.Cout || !xin) continue;
+            const unsigned lo2 = lo + (unsigned)rr * yv;
+            const float bv = sBias[co];
+            o.x += bv; o.y += bv; o.z += bv; o.w += bv;
+            if (ab != nullptr) {
+              const float4 a4 = *reinterpret_cast<const float4*>(ab + lo2);
+              o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+            }
+            *reinterpret_cast<float4*>(yb + lo2) = o;
+            if (zb != nullptr) {
+              const float sl = sSlope[co];
+              *reinterpret_cast<float4*>(zb + lo2) = make_float4(o.x > 0.f ? o.x : sl * o.x, o.y > 0.f ? o.y : sl * o.y,
+                                                                 o.z > 0.f ? o.z : sl * o.z, o.w > 0.f ? o.w : sl * o.w);
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- matrix waves: wave = (pz, py, z row g); both x parities of the three y rows
   const int wv = wave;
   if (t < 32) {  // (visible to every wave behind the first stage's barrier)

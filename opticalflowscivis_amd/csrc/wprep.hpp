@@ -22,8 +22,10 @@
 //       the weights of a k = 4 layer as three bf16 pieces, two channels per 4-byte word                 (convfwd_s3.hpp)
 //   FS_WPREP_TRS3 p = {Cin, Cout, ceil(Cin / 4), CoutT}   words [stage of 4 channels][parity class 8][z tap 2][piece 3][y tap 2]
 //       [co 0..31][x tap 2][channel pair]: the transposed layers' weights as three bf16 pieces (`w` as for FS_WPREP_TR32) (convtr_s3.hpp)
+//   FS_WPREP_TRS3_16 p = {Cin, Cout <= 16, ceil(Cin / 4), CoutT}  words [stage][parity class 8][piece 3][(y tap, x tap) 4][co 0..15]
+//       [z tap 2][channel pair]: the same for the 16-row form (all eight taps of a class in one 32-element reduction)
 enum { FS_WPREP_FWD = 0, FS_WPREP_TR32 = 1, FS_WPREP_TR16 = 2, FS_WPREP_P8 = 3, FS_WPREP_WINO = 4, FS_WPREP_WINO4 = 5,
-       FS_WPREP_WINO2D = 6, FS_WPREP_S3K4 = 7, FS_WPREP_TRS3 = 8 };
+       FS_WPREP_WINO2D = 6, FS_WPREP_S3K4 = 7, FS_WPREP_TRS3 = 8, FS_WPREP_TRS3_16 = 9 };
 
 // two floats -> one word of two bf16 (round to nearest even; low half = the first)
 __device__ __forceinline__ unsigned s3_pack(float a, float b) {
@@ -68,6 +70,27 @@ __device__ __forceinline__ unsigned wprep_t3_word(const FsWprepJob& j, int e) {
   const int az = r & 1, cls = (r >> 1) & 7, st = r >> 4;
   const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
   const int tap = (wprep_p8_k(pz, az) * 4 + wprep_p8_k(py, kh)) * 4 + wprep_p8_k(px, 1 - dxa);  // x slot 0 = tap 1 (the lower input position)
+  float v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = 4 * st + 2 * c2 + i;
+    float a = (co < Cout && ci < Cin) ? w[((size_t)ci * CoutT + co) * 64 + tap] : 0.f;
+    for (int q = 0; q < piece; ++q) a = a - (float)(__bf16)a;  // exact
+    v[i] = a;
+  }
+  return s3_pack(v[0], v[1]);
+}
+// one word of the FS_WPREP_TRS3_16 slab.  Word index: ((((stage 8 + class) 3 + piece) 4 + (y tap 2 + x tap)) 16 + co) 4 +
+// z tap 2 + channel pair
+__device__ __forceinline__ unsigned wprep_t3_word16(const FsWprepJob& j, int e) {
+  const int Cin = j.p[0], Cout = j.p[1], CoutT = j.p[3];
+  const float* __restrict__ w = j.w;
+  const int c2 = e & 1, az = (e >> 1) & 1, co = (e >> 2) & 15, kq = (e >> 6) & 3;
+  int r = e >> 8;
+  const int piece = r % 3; r /= 3;
+  const int cls = r & 7, st = r >> 3;
+  const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+  const int tap = (wprep_p8_k(pz, az) * 4 + wprep_p8_k(py, kq >> 1)) * 4 + wprep_p8_k(px, kq & 1);
   float v[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -220,9 +243,10 @@ __global__ __launch_bounds__(256) void wprep_one_kernel(FsWprepJob j) {
     wprep_wino2d_blocks(j, blockIdx.x, gridDim.x);
     return;
   }
-  if (j.kind == FS_WPREP_S3K4 || j.kind == FS_WPREP_TRS3) {
+  if (j.kind == FS_WPREP_S3K4 || j.kind == FS_WPREP_TRS3 || j.kind == FS_WPREP_TRS3_16) {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256)
-      reinterpret_cast<unsigned*>(j.ws)[e] = j.kind == FS_WPREP_S3K4 ? wprep_s3_word(j, e) : wprep_t3_word(j, e);
+      reinterpret_cast<unsigned*>(j.ws)[e] = j.kind == FS_WPREP_S3K4 ? wprep_s3_word(j, e)
+                                             : (j.kind == FS_WPREP_TRS3 ? wprep_t3_word(j, e) : wprep_t3_word16(j, e));
     return;
   }
   for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256) j.ws[e] = wprep_elem(j, e);
@@ -235,9 +259,10 @@ __global__ __launch_bounds__(256) void wprep_batch_kernel(const FsWprepJob* __re
     wprep_wino2d_blocks(j, blockIdx.x, gridDim.x);
     return;
   }
-  if (j.kind == FS_WPREP_S3K4 || j.kind == FS_WPREP_TRS3) {
+  if (j.kind == FS_WPREP_S3K4 || j.kind == FS_WPREP_TRS3 || j.kind == FS_WPREP_TRS3_16) {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256)
-      reinterpret_cast<unsigned*>(j.ws)[e] = j.kind == FS_WPREP_S3K4 ? wprep_s3_word(j, e) : wprep_t3_word(j, e);
+      reinterpret_cast<unsigned*>(j.ws)[e] = j.kind == FS_WPREP_S3K4 ? wprep_s3_word(j, e)
+                                             : (j.kind == FS_WPREP_TRS3 ? wprep_t3_word(j, e) : wprep_t3_word16(j, e));
     return;
   }
   for (int e = blockIdx.x * 256 + threadIdx.x; e < j.total; e += gridDim.x * 256) j.ws[e] = wprep_elem(j, e);
