@@ -1689,6 +1689,21 @@ def _fwd_k4_symbol(xptr, B, Cin, Cout, in_dhw, out_dhw):
     return ("conv3d_fwd_s3_kernel<%d, 8, 4>" % (1 if Cout <= 32 else 2)) if _wino_seen[key] else None
 
 
+def _tr_symbol(xptr, B, Cin, Cout, in_dhw, out_dhw, has_z):
+    """Kernel symbol of an fs_conv3d_tr* call where ops.py can name it: the round-5 split-bf16 kernels (csrc/convtr_s3.hpp;
+    the library's re-layout plan says slab kind 8 = the 32-row form, 9 = the 16-row form).  Asked only while launches are
+    being timed; None = the fp32-MFMA kernels."""
+    if _timing is None:
+        return None
+    key = ("tr", xptr % 16, B, Cin, Cout, int(has_z)) + tuple(int(v) for v in in_dhw) + tuple(int(v) for v in out_dhw)
+    if key not in _wino_seen:
+        buf = (_lib.FsWprepJob * 8)()
+        n = _lib.lib().fs_conv3d_tr_wprep_jobs(buf, 8, 0x1000 + xptr % 16, 0x1000, 0x1000, B, Cin, Cout, *key[6:12], int(has_z))
+        kinds = set(buf[i].kind for i in range(max(n, 0)))
+        _wino_seen[key] = "convtr_s3_kernel<false>" if kinds == {8} else ("convtr_s3_kernel<true>" if kinds == {9} else None)
+    return _wino_seen[key]
+
+
 def _fwd_k3_symbol(macs, W):
     """Kernel symbol of a k3 s1 p1 fs_conv3d_fwd* call whose dispatch executes `macs` multiply-adds per (output, input
     channel) -- the names `rocprofv3 --kernel-trace --stats` prints (csrc/convwino2d.hpp::launch_wino2d: 16 x-tiles per
@@ -2112,7 +2127,10 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
                        lambda jobs, cap, slab: L.fs_conv3d_tr_wprep_jobs(jobs, cap, x.data_ptr(), w.data_ptr(),
                                                                         slab.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho,
                                                                         Wo, has_z))
-    nb, fl = 4 * (x.numel() + y.numel()), 2 * x.numel() * Cout * 64
+    nb, fq = 4 * (x.numel() + y.numel()), 2 * x.numel() * Cout * 64
+    sym = _tr_symbol(x.data_ptr(), B, Cin, Cout, (Di, Hi, Wi), (Do, Ho, Wo), has_z)
+    # matrix-core flops EXECUTED: six bf16 products per fp32 multiply-add on the split-bf16 kernels (32 / 16 channel rows)
+    fl = fq if sym is None else 6 * 2 * x.numel() * (32 * ((Cout + 31) // 32) if sym.endswith("<false>") else 16) * 64
     with torch.cuda.device(x.device):
         if addend is not None:
             if prelu_weight is not None:
@@ -2122,11 +2140,11 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
                 raise ValueError("addend %s must have the output shape %s" % (tuple(addend.shape), tuple(y.shape)))
             _call("fs_conv3d_tr_add", x.data_ptr(), wp, _ptr(bias), addend.data_ptr(), y.data_ptr(),
                   ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb + 4 * y.numel(),
-                  algo_flops=fl, record_as="fs_conv3d_tr")
+                  algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_tr", kernel=sym)
             return y
         if prelu_weight is None:
             _call("fs_conv3d_tr", x.data_ptr(), wp, _ptr(bias), y.data_ptr(), ws.data_ptr(), B, Cin,
-                  Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb, algo_flops=fl)
+                  Cout, Di, Hi, Wi, Do, Ho, Wo, _stream(x), algo_bytes=nb, algo_flops=fl, equiv_flops=fq, kernel=sym)
             return y
         a = _need_cuda_f32("prelu_weight", prelu_weight, 1)
         if a.numel() not in (1, Cout):
@@ -2134,7 +2152,7 @@ def conv3d_tr(x, w, bias, out_dhw=None, prelu_weight=None, addend=None):
         z = torch.empty_like(y)
         _call("fs_conv3d_tr_prelu", x.data_ptr(), wp, _ptr(bias), a.data_ptr(), y.data_ptr(),
               z.data_ptr(), ws.data_ptr(), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, a.numel(), _stream(x),
-              algo_bytes=nb + 4 * y.numel(), algo_flops=fl, record_as="fs_conv3d_tr")
+              algo_bytes=nb + 4 * y.numel(), algo_flops=fl, equiv_flops=fq, record_as="fs_conv3d_tr", kernel=sym)
     return y, z
 
 

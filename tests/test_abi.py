@@ -123,13 +123,16 @@ def test_weight_relayout_plans_without_gpu():
     assert fwd(8, 8, 8, 3, 0, w=None) == -1                                                                          # -FS_ERR_NULLPTR
     kinds = {}
     for cin, cout, di, z in ((64, 32, 64, 0), (32, 6, 128, 0), (32, 1, 128, 0), (32, 11, 128, 0), (128, 64, 16, 0),
-                             (32, 6, 128, 1), (5, 3, 9, 0)):
+                             (32, 6, 128, 1), (5, 3, 9, 0), (64, 32, 16, 0), (32, 11, 16, 0)):
         n = L.fs_conv3d_tr_wprep_jobs(buf, 4, 0x4000, 0x1000, 0x2000, 2, cin, cout, di, di, di, 2 * di, 2 * di, 2 * di, z)
         assert n >= 0
         assert sum(buf[i].total for i in range(n)) <= L.fs_conv3d_tr_ws_floats(cin, cout)
         kinds[(cin, cout, di, z)] = [buf[i].kind for i in range(n)]
-    assert kinds[(64, 32, 64, 0)] == [1] and kinds[(128, 64, 16, 0)] == [1, 1]           # 32-channel slices
-    assert kinds[(32, 11, 128, 0)] == [2] and kinds[(32, 6, 128, 0)] == [3] and kinds[(32, 1, 128, 0)] == [3]
+    # round 5: the split-bf16 slabs where the 2 x 3 x 32-position bricks fill the chip (kind 8: 17..32 channels, 9: 7..16);
+    # the fp32 class kernels' slabs below that (kind 1: 32-channel slices, 2: 16 rows)
+    assert kinds[(64, 32, 64, 0)] == [8] and kinds[(128, 64, 16, 0)] == [1, 1] and kinds[(64, 32, 16, 0)] == [1]
+    assert kinds[(32, 11, 128, 0)] == [9] and kinds[(32, 11, 16, 0)] == [2]
+    assert kinds[(32, 6, 128, 0)] == [3] and kinds[(32, 1, 128, 0)] == [3]
     assert kinds[(32, 6, 128, 1)] == [] and kinds[(5, 3, 9, 0)] == []                      # kernels that read w as stored
     # a misaligned input rules out the loader-wave / all-parities kernels: another layout (or none) is planned
     n = L.fs_conv3d_tr_wprep_jobs(buf, 4, 0x4004, 0x1000, 0x2000, 2, 32, 6, 128, 128, 128, 256, 256, 256, 0)
