@@ -28,6 +28,7 @@ typedef __bf16 t3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned t3_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned t3_u32x2 __attribute__((ext_vector_type(2)));
 typedef int t3_i32x4 __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) t3_u32x2* t3_lds_v64;  // (volatile LDS read of 8 bytes: never paired)
 
 constexpr int T3_TZ = 2, T3_TY = 3, T3_TW = 32;
 constexpr int T3_NMW = 8, T3_NLW = 4;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(co
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) {
             const unsigned char* q = sb + pc * T3_PIECEB + y * T3_ROWB + (16 * h + px) * 8;
-            const t3_u32x2 lo = *reinterpret_cast<const t3_u32x2*>(q + dz0), hi = *reinterpret_cast<const t3_u32x2*>(q + dz1);
+            const t3_u32x2 lo = *(t3_lds_v64)(lds_ptr_t)(q + dz0), hi = *(t3_lds_v64)(lds_ptr_t)(q + dz1);  // (volatile: see the 32-row form)
             const t3_u32x4 v = {lo.x, lo.y, hi.x, hi.y};
             bq[pc] = __builtin_bit_cast(t3_bf16x8, v);
           }
@@ -422,7 +423,9 @@ __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(co
           for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
             for (int d = 0; d < 3; ++d)
-              P[pc][d] = *reinterpret_cast<const t3_u32x2*>(sb + dzr + pc * T3_PIECEB + y * T3_ROWB + (d - 1) * 8);
+              // (volatile: the compiler would pair two of these into one ds_read2_b64, which is banked on 32 banks -- 2-way
+              // conflicts on 256 contiguous bytes -- where ds_read_b64 uses all 64)
+              P[pc][d] = *(t3_lds_v64)(lds_ptr_t)(sb + dzr + pc * T3_PIECEB + y * T3_ROWB + (d - 1) * 8);
           t3_bf16x8 bq[2][3];
 #pragma unroll
           for (int px = 0; px < 2; ++px)
