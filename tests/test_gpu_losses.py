@@ -990,3 +990,32 @@ def test_conv3d_tr_split_bf16_kernel_vs_fp64(ops, cin, cout, size, form):
         zr = torch.where(ref > 0, ref, ref * slope.double().view(1, -1, 1, 1, 1))
         assert float((y.cpu().double() - ref).abs().max()) < 3e-6 * scale
         assert float((z.cpu().double() - zr).abs().max()) < 3e-6 * scale
+
+
+@pytest.mark.parametrize("kind", ["fwd32", "fwd64", "tr32", "tr16"])
+def test_split_bf16_kernels_on_a_cold_cache(ops, kind):
+    """The three loader hazards of the split-bf16 kernels (compiler copies of registers in flight, vmcnt
+    counts across LDS-DMA copies and register loads, the address register of a copy re-written after issue) were silent
+    whenever the operands were hot in L2: only the FIRST bricks of a launch on a cold cache came out wrong, and not every
+    time.  So: fresh weights (a new slab), every cache evicted by a 1 GiB fill, ONE launch, fp64 check -- six times."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(77)
+    cin, cout, size = {"fwd32": (12, 32, (64, 64, 128)), "fwd64": (32, 64, (32, 64, 128)),
+                       "tr32": (16, 32, (32, 48, 32)), "tr16": (16, 12, (32, 48, 32))}[kind]
+    x = torch.randn((2, cin) + size, generator=g)
+    xd = x.to(DEV)
+    trash = torch.empty(1 << 28, device=DEV)
+    worst = 0.0
+    for rep in range(6):
+        if kind.startswith("fwd"):
+            w = torch.randn(cout, cin, 4, 4, 4, generator=g) / (cin * 64) ** 0.5
+            ref = F.conv3d(x.double(), w.double(), None, 2, 1)
+        else:
+            w = torch.randn(cin, cout, 4, 4, 4, generator=g) / (cin * 8) ** 0.5
+            ref = F.conv_transpose3d(x.double(), w.double(), None, 2, 1)
+        wd = w.to(DEV)
+        trash.fill_(float(rep))          # 1 GiB through L2 / MALL: x, the slab-to-be and the LDS-adjacent state go cold
+        torch.cuda.synchronize()
+        y = ops.conv3d_fwd(xd, wd, None, 4, 2, 1, 0) if kind.startswith("fwd") else ops.conv3d_tr(xd, wd, None)
+        worst = max(worst, float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max()))
+    assert worst < 3e-6, worst
