@@ -1089,7 +1089,7 @@ extern "C" long long fs_conv3d_tr_ws_floats(int Cin, int Cout) {
   const long long p8 = Cout <= 12 ? cinp * p8_ws_ci(Cout <= 2 ? 1 : (Cout <= 6 ? 3 : 6)) : 0;
   long long cls = Cout <= 6 ? 0 : cinp * 64 * (Cout <= 16 ? 16 : 32);
   if (Cout > 16 && t3_slab_words(Cin) > cls) cls = t3_slab_words(Cin);  // the split-bf16 slabs (convtr_s3.hpp)
-  if (Cout > 6 && Cout <= 16 && t3_slab_words16(Cin) > cls) cls = t3_slab_words16(Cin);
+  if (Cout <= 16 && t3_slab_words16(Cin) > cls) cls = t3_slab_words16(Cin);
   return (p8 > cls ? p8 : cls) * slices;
 }
 
@@ -1126,7 +1126,8 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
   // FLOWSCI_TR_P8_ALL=1 -- but measured 2.50 vs 2.44 ms against the 16-row class kernel on the 32 -> 11 input
   // gradient at 128^3, so those layers stay there)
   static const bool p8_all = FS_AB_ENV("FLOWSCI_TR_P8_ALL");
-  if (Cout <= (p8_all ? 12 : 6) && !reg_only && z == nullptr && ws != nullptr && Cin <= (Cout <= 6 ? 64 : 32) && Dout == 2 * Di && Hout == 2 * Hi &&
+  static const bool s3_small = FS_AB_ENV("FLOWSCI_TR_S3_SMALL");  // (measurement: <= 6 channels on the 16-row split-bf16 form)
+  if (!s3_small && Cout <= (p8_all ? 12 : 6) && !reg_only && z == nullptr && ws != nullptr && Cin <= (Cout <= 6 ? 64 : 32) && Dout == 2 * Di && Hout == 2 * Hi &&
       Wout == 2 * Wi && Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0 &&
       (long long)4 * Di * Hi * Wi * 4 < (1ll << 31)) {
     // all-parities-in-rows MFMA kernel: 2x2 position rows x 128 (64) positions per brick; positions 0..Di, 0..Hi, 0..Wi
@@ -1148,7 +1149,7 @@ static int conv3d_tr_slice(const float* x, const float* w, const float* bias, co
       return FS_OK;
     }
   }
-  if (Cout <= 6) {
+  if (Cout <= 6 && !s3_small) {
     if (plan != nullptr) return FS_OK;        // the vector-ALU kernels read `w` as stored: nothing to prepare
     if (w == nullptr) return FS_ERR_NULLPTR;  // ... and therefore need it
     if (Cout == 1) launch_valu<1>(x, w, bias, y, p, st);
