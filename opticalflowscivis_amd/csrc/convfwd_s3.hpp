@@ -136,9 +136,12 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
           asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ld[ps][c]) : "v"(goff[ps]), "s"(r));
       }
     };
-    // wait for EVERYTHING in flight and tie the set's registers to the wait in ONE statement (every use of the set comes
-    // after it; with the tie a statement of its own the compiler may place copies of the registers -- stale data -- in
-    // front of the wait)
+    // wait for EVERYTHING in flight and tie the set's registers to the wait in ONE statement.  To the compiler the
+    // destination of an inline-assembly load is an ordinary value from the asm statement on: it may COPY it (tied operands,
+    // live-range splits, loop exits) -- the copy reads stale data -- and then hand the original register to another value,
+    // which the load overwrites when it lands.  Silent on a warm cache, wrong on a cold one.  With wait and tie in one
+    // statement every use comes behind the wait and the registers stay the set's; scripts/check_inflight_regs.py verifies on
+    // the compiled code of every build that nothing reads OR writes a register between its load and the wait that covers it
     auto wait_all = [&](s3_u32x4 (&ld)[PASSES][2]) {
       static_assert(PASSES <= 3, "operand list below");
       if constexpr (PASSES == 3)
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
       else
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(ld[0][0]), "+v"(ld[0][1]) : : "memory");
     };
-    // The lane offsets of the slab copies live in registers of their own, written once and kept (the empty statement): a
-    // 16-byte LDS-DMA copy reads its address register again after issue and nothing stalls a vector-ALU write to it -- with
-    // the offset in a temporary that the conversion re-used, parts of a copy can come from wherever the temporary points by
-    // then (found in csrc/convtr_s3.hpp; scripts/check_inflight_regs.py checks the compiled code for it)
+    // The lane offsets of the slab copies live in registers of their own, written once and kept to the last wait (a
+    // precaution from the bring-up of csrc/convtr_s3.hpp; scripts/micro/lds_dma_hazards.hip later showed that a copy does
+    // tolerate a rewrite of its address register -- what had corrupted the offsets there was a register handed out while an
+    // inline-assembly load into it was still in flight, see wait_all)
     unsigned woff[NWW];
 #pragma unroll
     for (int k = 0; k < NWW; ++k) {
@@ -208,9 +211,8 @@ __global__ __launch_bounds__(64 * (NMW + NLW), MT == 1 ? 6 : 1) void conv3d_fwd_
       issue_wdma(0);
       issue_loads(0, ld);
       for (int s = 0; s < NS; ++s) {
-        // everything requested so far has landed: the pieces of stage s and its weight slab.  (vmcnt(0), and the next slab
-        // requested BEHIND it: a count that lets younger slab copies stay in flight assumes that copies and register loads
-        // complete in the order they were issued -- they do not, csrc/convtr_s3.hpp.)  One statement with the tie: see tie.
+        // everything requested so far has landed: the pieces of stage s and its weight slab (vmcnt(0), the next slab requested
+        // BEHIND it: nothing is counted past).  One statement with the tie: see wait_all.
         wait_all(ld);
         if (s + 1 < NS) {
           issue_wdma(s + 1);

@@ -111,15 +111,17 @@ __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(co
     const unsigned loff = (unsigned)(row * T3_ROWB + jq * 32);
     const unsigned volB = (unsigned)(xvol * 4u);
     // The brick of a stage reaches the conversion through LDS, not through registers: a 16 KB staging area
-    // [channel 4][item 256] x 16 bytes that every loader wave fills (LDS-DMA) and reads back for its OWN 64 items.  Loads in
-    // flight into registers are invisible to the compiler: it copied such registers in front of the hand-counted wait
-    // whatever the source looked like (tied operands, live-range splits) -- stale data whenever memory was slow.  In LDS there
-    // is nothing to copy, and the reads are ordinary ds_read the compiler waits for by itself.
+    // [channel 4][item 256] x 16 bytes that every loader wave fills (LDS-DMA) and reads back for its OWN 64 items.  A first
+    // form kept the bricks in flight in inline-assembly register sets (as csrc/convfwd_s3.hpp does): the compiler copied such
+    // registers in front of the hand-counted wait whatever the source looked like (tied operands, live-range splits, loop
+    // exits), read the stale copy, and handed the original registers to other values -- the lane offsets of the slab copies,
+    // conversion temporaries -- which the loads then overwrote when they landed: wrong first bricks on a cold cache, fine on a
+    // warm one.  In LDS there is nothing to copy, and the reads are ordinary ds_read the compiler waits for by itself.
     unsigned char* const stg = lds + WOFF + 2 * T3_WB + (lw * 64 + lane) * 16;
     int l_i = 0, l_s = 0, l_b = 0;   // the request stream's (brick, stage) position: NSTG stages ahead of the conversion
     // Two address registers, one per brick parity (`goff` of brick i is written while only copies of brick i - 1 can be in
-    // flight, which use the other one): a 16-byte LDS-DMA reads its address register again after issue -- see woff below --
-    // so a register may only change when no copy that uses it is in flight
+    // flight, which use the other one): kept from the bring-up, when a corrupted offset register was first read as "a copy
+    // reads its address register again after issue" -- scripts/micro/lds_dma_hazards.hip shows it does not; see above
     unsigned goffA = DMA_OOB, goffB = DMA_OOB;
     auto l_brick = [&]() {
       int qz0, qy0, qx0;
@@ -156,11 +158,10 @@ __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(co
     auto advance = [&]() {  // the next request position (a new brick's offsets go to the register of ITS parity)
       if (++l_s == NS) { l_s = 0; if (l_i + 1 < nbr) { ++l_i; l_brick(); } }
     };
-    // The lane offsets of the slab copies live in NWW registers of their own, written ONCE: with a single register
-    // re-computed between the copies (what the compiler makes of `1024 i + 16 lane`) parts of a copy arrived from the NEXT
-    // copy's source offset whenever the memory pipeline was backed up -- a 16-byte LDS-DMA evidently reads its address
-    // register again after issue, and nothing stalls a vector-ALU write to it (found with an in-kernel comparison of the LDS
-    // slab against memory: mismatches rose with the copy's place in the queue; wrong results on the first bricks only).
+    // The lane offsets of the slab copies live in NWW registers of their own, written once (kept from the bring-up: with one
+    // temporary per copy the slab in LDS came out wrong, the more so the later the copy in the queue -- the temporary's
+    // register was one that an in-flight brick load later landed in, see above; the reproducer in scripts/micro/ shows the
+    // copies themselves are indifferent to the rewrite)
     unsigned woff[NWW];
 #pragma unroll
     for (int k = 0; k < NWW; ++k) {
@@ -204,13 +205,12 @@ __global__ __launch_bounds__(64 * (T3_NMW + T3_NLW), 1) void convtr_s3_kernel(co
       }
     };
     // Iteration g of the stream (stage g % NS of brick g / NS) runs beside the matrix waves' stage g - 1 and ends in barrier
-    // #g.  Waits that never rely on the order in which DIFFERENT kinds of request complete (a first version counted the
-    // younger slab copies past older register loads: on a cold start the copies, hot in L2, overtook the loads from HBM):
+    // #g.  Only LDS-DMA copies are ever in flight here, and they complete in the order they were issued:
     //   vmcnt(0): the staged brick of stage g has landed (requested an iteration ago) -> the wave's items to registers;
     //   the slab of stage g is requested (into the weight buffer stage g - 2 has left), THEN the brick of stage g + 1 (the
     //   staging slots are free: this wave alone reads them, and has); the items are split and parked as stage g's image;
-    //   vmcnt(4): copies complete in the order they were issued, so the slab is in, the four brick copies may still fly.
-    // (NSTG = 2: vmcnt(4) at the top lets the brick of stage g + 1 fly -- copies complete in the order they were issued --,
+    //   vmcnt(4): the slab is in, the four brick copies behind it may still fly.
+    // (NSTG = 2: vmcnt(4) at the top lets the brick of stage g + 1 fly,
     // the brick of stage g + 2 is requested into the staging area just read, and vmcnt(4) at the bottom has the slab and
     // stage g + 1's brick in)
     const int total = nbr * NS;

@@ -1,6 +1,6 @@
 """Static check on the compiled device assembly of the kernels whose LOADER waves keep global loads in flight across
 hand-counted `s_waitcnt vmcnt(N)` (inline-assembly `buffer_load_dwordx4` into registers): no instruction may READ such a
-register before the wait that covers its load.  The compiler does not know the load is asynchronous and is free to COPY
+register -- or WRITE anything else to it -- before the wait that covers its load.  The compiler does not know the load is asynchronous and is free to COPY
 the register (live-range splits, tied inline-assembly operands) -- a copy of stale data, wrong only when memory is slow.
 
 The loader region (from its `s_setprio` to the next `s_endpgm`) is scanned in text order with the in-order queue of
@@ -83,6 +83,11 @@ def check(path, kernel):
             inflight = set().union(*queue) if queue else set()
             if src & inflight:
                 bad.append((i, t))
+            # ... nor may anything else be WRITTEN to such a register (the compiler handed it to another value -- after a
+            # copy, or because the loaded value is never used --: the load lands later and overwrites that value)
+            dst = set() if is_store else regs_of(ops[0])
+            if dst & inflight:
+                bad.append((i, t + '    ; WRITE to a register with a load in flight'))
         seen, uniq = set(), []
         for b in bad:
             if b not in seen:
@@ -95,10 +100,11 @@ def check(path, kernel):
 
 
 def check_dma_addr(path, kernel):
-    """Second rule (found on gfx950 with 16-byte LDS-DMA copies, csrc/convtr_s3.hpp): the ADDRESS register of a
-    `buffer_load_dwordx4 ... lds` must not be written while the copy is in flight -- the copy reads it again after issue and
-    nothing stalls the write (parts of the copy then come from the new offset).  In the loader region, a vector instruction
-    that writes the address register of a copy issued since the last `s_waitcnt vmcnt(0)` is a violation."""
+    """A precaution kept from the bring-up of csrc/convtr_s3.hpp, NOT a hardware requirement: in the split-bf16 kernels the
+    address register of a `buffer_load_dwordx4 ... lds` copy is not written while the copy may be in flight.  (The corrupted
+    copies that prompted it came from a register handed out under an in-flight load -- rule one above --;
+    scripts/micro/lds_dma_hazards.hip shows that the copies themselves tolerate the rewrite.)  In the loader region, a vector
+    instruction that writes the address register of a copy issued since the last `s_waitcnt vmcnt(0)` is reported."""
     s = open(path).read()
     total = 0
     for m in re.finditer(r'^(_Z[^\n]*%s[^:\n]*):' % re.escape(kernel), s, re.M):

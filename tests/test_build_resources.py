@@ -96,12 +96,14 @@ def _device_asm(src, tmp_path, extra=()):
 
 
 def test_split_bf16_loaders_touch_no_register_or_address_in_flight(tmp_path):
-    """Round 5 (found while the transposed split-bf16 kernel was brought up): in the loader waves of the
-    split-bf16 kernels the compiled code must (1) never READ a register between the inline-assembly load that targets it
-    and the hand-counted wait that covers it -- the compiler is free to copy such a register -- and (2) never WRITE the
-    address register of a 16-byte LDS-DMA copy that may still be in flight.  Both are checked on the device assembly of
-    THIS build (scripts/check_inflight_regs.py simulates the request queue); the transposed kernel's loaders must also be
-    free of compiler-made scratch traffic (it would be counted by their vmcnt waits)."""
+    """Round 5 (found while the transposed split-bf16 kernel was brought up): to the compiler the destination
+    of an inline-assembly load is an ordinary value -- it may copy it in front of the hand-counted wait (stale data) and hand
+    the register to another value, which the load then overwrites when it lands; silent on a warm cache.  So the compiled
+    loader code of the kernels that keep such loads in flight (forward split-bf16; the transposed one stages through LDS
+    instead) must neither READ nor WRITE a register between its load and the wait that covers it -- checked on the device
+    assembly of THIS build (scripts/check_inflight_regs.py simulates the request queue).  Also kept: no write to the address
+    register of an LDS-DMA copy in flight (a precaution, not a requirement: scripts/micro/lds_dma_hazards.hip), and the
+    transposed kernel's loaders free of compiler-made scratch traffic (it would be counted by their vmcnt waits)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import check_inflight_regs as chk

@@ -994,10 +994,10 @@ def test_conv3d_tr_split_bf16_kernel_vs_fp64(ops, cin, cout, size, form):
 
 @pytest.mark.parametrize("kind", ["fwd32", "fwd64", "tr32", "tr16"])
 def test_split_bf16_kernels_on_a_cold_cache(ops, kind):
-    """The three loader hazards of the split-bf16 kernels (compiler copies of registers in flight, vmcnt
-    counts across LDS-DMA copies and register loads, the address register of a copy re-written after issue) were silent
-    whenever the operands were hot in L2: only the FIRST bricks of a launch on a cold cache came out wrong, and not every
-    time.  So: fresh weights (a new slab), every cache evicted by a 1 GiB fill, ONE launch, fp64 check -- six times."""
+    """What the bring-up of the transposed split-bf16 kernel ran into (registers under an in-flight
+    inline-assembly load copied and handed out by the compiler) was silent whenever the operands were hot in L2: only the
+    FIRST bricks of a launch on a cold cache came out wrong, and not every time.  So: fresh weights (a new slab), every
+    cache evicted by a 1 GiB fill, ONE launch, fp64 check -- six times."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(77)
     cin, cout, size = {"fwd32": (12, 32, (64, 64, 128)), "fwd64": (32, 64, (32, 64, 128)),
