@@ -50,7 +50,7 @@ def unroll_loops(lines):
     return out
 
 
-def check(path, kernel):
+def check(path, kernel, collect=None):
     s = open(path).read()
     total = 0
     for m in re.finditer(r'^(_Z[^\n]*%s[^:\n]*):' % re.escape(kernel), s, re.M):
@@ -96,6 +96,8 @@ def check(path, kernel):
         for i, t in uniq[:16]:
             print('    line %d: %s' % (i, t))
         total += len(uniq)
+        if collect is not None:
+            collect.extend(t for _, t in uniq)
     return total
 
 
